@@ -1,0 +1,242 @@
+"""Golden-vector generator (runs ONLY in the build container; needs /root/reference).
+
+Imports the reference's own Python files from /root/reference, runs them on seeded inputs and writes
+small ``.npz`` fixtures (inputs + expected outputs) to ``tests/golden/``.  Nothing from the reference
+travels: the fixtures are data, this script is ours.
+
+What is imported unchanged from the reference:
+  core/pose/pose_head.py, core/geometry/pinhole_transforms.py, core/optimization/declerative_node_lie.py
+      (need the names ``lietorch`` and ``core.ddn.ddn.pytorch.node``: both are absent third-party
+      dependencies -- README.md:35-37, .gitmodules:1-6 -- so ``oracle.se3`` and three empty base
+      classes are seeded into ``sys.modules`` under those names; the objective, masks, normalisation,
+      closure and the real ``torch.optim.LBFGS`` are the reference's)
+  core/interpol/flow_utils.py, core/utils/pytorch.py, core/metrics/trajectory_metrics.py  (import as is)
+
+Usage:  python -m oracle.gen_golden            (from the repo root)
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def load_reference():
+    from oracle import se3 as ose3
+    liet = types.ModuleType('lietorch')
+    liet.SE3 = ose3.SE3
+    liet.LieGroupParameter = ose3.LieGroupParameter
+    sys.modules['lietorch'] = liet
+
+    from torch.autograd import grad
+    node = types.ModuleType('core.ddn.ddn.pytorch.node')
+
+    class AbstractDeclarativeNode:
+        def __init__(self, eps=1e-12, gamma=None, chunk_size=None):
+            self.eps, self.gamma, self.chunk_size = eps, gamma, chunk_size
+
+    class DeclarativeFunction(torch.autograd.Function):
+        pass
+
+    class DeclarativeLayer(torch.nn.Module):
+        def __init__(self, problem):
+            super().__init__()
+            self.problem = problem
+
+    node.AbstractDeclarativeNode = AbstractDeclarativeNode
+    node.DeclarativeFunction = DeclarativeFunction
+    node.DeclarativeLayer = DeclarativeLayer
+    node.torch, node.grad, node.warnings = torch, grad, warnings
+    node.__all__ = ['AbstractDeclarativeNode', 'DeclarativeFunction', 'DeclarativeLayer', 'torch', 'grad', 'warnings']
+    for name in ('core.ddn', 'core.ddn.ddn', 'core.ddn.ddn.pytorch'):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules['core.ddn.ddn.pytorch.node'] = node
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import core.geometry.pinhole_transforms as pt
+    import core.pose.pose_head as ph
+    import core.interpol.flow_utils as fu
+    import core.utils.pytorch as up
+    import core.metrics.trajectory_metrics as tm
+    return dict(pt=pt, ph=ph, fu=fu, up=up, tm=tm, se3=ose3)
+
+
+def ref_eval(R, args, T7):
+    """Reference objective + clipped tangent gradient at pose T7 (n,7) f64, exactly as the closure does."""
+    ph, ose3 = R['ph'], R['se3']
+    h, w = args[0].shape[-2:]
+    head = ph.DPoseSE3Head(R['pt'].create_img_coords_t(h, w))
+    xs = [x.detach().clone() for x in args]
+    xs = [x.double() if x.dtype == torch.float32 else x for x in xs]
+    n = xs[0].shape[0]
+    y = ose3.LieGroupParameter(ose3.SE3(T7.reshape(n, 1, 7).double()))
+    with torch.enable_grad():
+        f = head.objective(*xs, y=(y,))
+        f.sum().backward()
+    raw = y.grad.clone().reshape(n, 6)
+    torch.nn.utils.clip_grad_norm_(y, 10)
+    return f.detach(), raw, y.grad.clone().reshape(n, 6)
+
+
+def ref_solve(R, args, iters):
+    ph = R['ph']
+    h, w = args[0].shape[-2:]
+    head = ph.DPoseSE3Head(R['pt'].create_img_coords_t(h, w), lbgfs_iters=iters)
+    layer = ph.DeclarativeLayerLie(head)
+    y, _ = head.solve(*args)
+    vec7, log6 = layer(*args)
+    return y.group.data.detach().reshape(-1, 7), vec7, log6
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **conv)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+def gen_solver(R):
+    from oracle import synth
+    from oracle import se3 as ose3
+    cases = {
+        # name: (seed, n, h, w, kwargs)
+        'solver_a': (11, 1, 40, 56, dict()),
+        'solver_b': (12, 3, 32, 40, dict(unit_weights=True)),
+        'solver_c': (13, 2, 24, 32, dict(outliers=False, full_masks=True, noise=0.0)),
+        # z < 1e-12 points (clamp branch of project()): residuals ~1e24, gradients clipped from ~1e20
+        'solver_d': (14, 1, 24, 32, dict(outliers='clamp')),
+    }
+    for name, (seed, n, h, w, kw) in cases.items():
+        c = synth.solver_case(seed, n, h, w, **kw)
+        args = synth.solver_args(c)
+        out = {k: v for k, v in c.items()}
+        T_id = torch.zeros(n, 7, dtype=torch.float64)
+        T_id[:, 6] = 1
+        rng = np.random.default_rng(seed + 1000)
+        T_rnd = ose3.se3_exp(torch.from_numpy(rng.normal(0, 0.02, size=(n, 6))))
+        for tag, T in (('id', T_id), ('rnd', T_rnd)):
+            f, graw, gclip = ref_eval(R, args, T)
+            out['T_' + tag], out['f_' + tag], out['graw_' + tag], out['gclip_' + tag] = T, f, graw, gclip
+        for k in ((1, 3) if name == 'solver_d' else (1, 2, 3, 8, 20, 100)):
+            T, v7, l6 = ref_solve(R, args, k)       # reference semantics at batch n: coupled
+            out['T_k%d' % k], out['vec7_k%d' % k], out['log6_k%d' % k] = T, v7, l6
+        if n > 1:                                   # per-row (n == 1) solves: what inference does
+            for k in (3, 8, 20):
+                rows = [ref_solve(R, tuple(a[i:i + 1] for a in args), k)[0] for i in range(n)]
+                out['Tind_k%d' % k] = torch.cat(rows)
+        save(name + '.npz', **out)
+
+    # NaN behaviour: one NaN flow value in an unmasked pixel, one NaN point in a masked pixel
+    c = synth.solver_case(21, 1, 16, 24, outliers=False)
+    c['flow'][0, 0, 4, 4] = float('nan')
+    args = synth.solver_args(c)
+    T_id = torch.zeros(1, 7, dtype=torch.float64)
+    T_id[:, 6] = 1
+    f, graw, gclip = ref_eval(R, args, T_id)
+    T3, v7, l6 = ref_solve(R, args, 3)
+    save('solver_nan.npz', **c, f_id=f, graw_id=graw, T_k3=T3, vec7_k3=v7)
+
+
+def gen_kat(R):
+    """Reference known-answer test tests/unit_test_pose_head.py:13-50 run on the reference itself.
+    Inputs are regenerated from the seed by the tests; only scalar outcomes are stored."""
+    from oracle import synth
+    c = synth.solver_case(12345, 5, 180, 180, sigma_t=0.01, sigma_r=0.01, noise=0.0, unit_weights=True,
+                          full_masks=True, outliers=False)
+    c['loss_weight'] = torch.tensor([[0.001, 1.0]]).repeat(5, 1)
+    args = synth.solver_args(c)
+    from oracle import se3 as ose3
+    Tgt = ose3.se3_exp(c['xi_gt'])
+    f_gt, _, _ = ref_eval(R, args, Tgt)
+    T100, v7, l6 = ref_solve(R, args, 100)
+    f_pred, _, _ = ref_eval(R, args, T100)
+    sup = (l6.reshape(5, 6).double() - ose3.se3_log(Tgt)).abs().sum() / 5
+    print('KAT: loss_gt max %.3e  loss_pred max %.3e  supervised %.3e' % (f_gt.max(), f_pred.max(), sup))
+    save('solver_kat.npz', f_gt=f_gt, f_pred=f_pred, sup=sup, T_k100=T100, log6_k100=l6)
+
+
+def gen_warp(R):
+    """remap_from_flow / remap_from_flow_nearest (core/interpol/flow_utils.py:4-26) and skewmat."""
+    fu, up = R['fu'], R['up']
+    rng = np.random.default_rng(31)
+    n, h, w = 2, 24, 40
+    x = torch.from_numpy(rng.normal(size=(n, 3, h, w)).astype(np.float32))
+    flow = torch.from_numpy(rng.normal(0, 3.0, size=(n, 2, h, w)).astype(np.float32))
+    flow[0, :, 0, 0] = torch.tensor([0.5, 0.5])        # exact .5 -> round-half-even in nearest mode
+    flow[0, :, 0, 1] = torch.tensor([1.5, 2.5])
+    flow[0, :, 1, 0] = torch.tensor([-0.5, 3.5])
+    flow[1, :, 2, 2] = torch.tensor([-40.0, 2.0])      # far outside -> zero padding
+    flow[1, :, 3, 3] = torch.tensor([36.0, 20.0])      # lands exactly on the last pixel
+    mask = torch.from_numpy(rng.uniform(size=(n, 1, h, w)) > 0.3)
+    xb, vb = fu.remap_from_flow(x, flow)
+    mn, vn = fu.remap_from_flow_nearest(mask, flow)
+    vecs = torch.from_numpy(rng.normal(size=(7, 3)))
+    save('warp.npz', x=x, flow=flow, mask=mask, bilinear=xb, bilinear_valid=vb, nearest=mn, nearest_valid=vn,
+         skew_in=vecs, skew_out=up.skewmat(vecs))
+
+
+def gen_geometry(R):
+    """create_img_coords_t, reproject, project (core/geometry/pinhole_transforms.py:7-19,79-99)."""
+    pt, ose3 = R['pt'], R['se3']
+    rng = np.random.default_rng(41)
+    n, h, w = 2, 12, 20
+    K = torch.tensor([[22.0, 0.3, 10.0], [0.0, 21.0, 6.0], [0.0, 0.0, 1.0]]).repeat(n, 1, 1)
+    depth = torch.from_numpy(rng.uniform(0.1, 1.0, size=(n, 1, h, w)).astype(np.float32))
+    coords = pt.create_img_coords_t(h, w)
+    opts = pt.reproject(depth, K, coords)
+    T = ose3.SE3.exp(torch.from_numpy(rng.normal(0, 0.05, size=(n, 1, 6)).astype(np.float32)))
+    pts = opts[:, :3].clone()
+    pts[0, 2, 5] = -1.0                                 # z clamp branch
+    proj = pt.project(pts, K, T)
+    tr = pt.transform(pts, T)
+    save('geometry.npz', K=K, depth=depth, coords=coords, reproject=opts, T=T.data, pts=pts, project=proj,
+         transform=tr, matrix=T.matrix())
+
+
+def gen_metrics(R):
+    """absolute_trajectory_error / relative_pose_error (core/metrics/trajectory_metrics.py:38-105)."""
+    tm, ose3 = R['tm'], R['se3']
+    rng = np.random.default_rng(51)
+    m = 40
+    xi = torch.from_numpy(np.concatenate((rng.normal(0, 2.0, size=(m, 3)), rng.normal(0, 0.02, size=(m, 3))), 1))
+    rel = ose3.se3_exp(xi)
+    gt = [torch.tensor([0, 0, 0, 0, 0, 0, 1.0], dtype=torch.float64)]
+    for i in range(m):
+        gt.append(ose3.se3_mul(gt[-1][None], rel[i][None])[0])
+    gt = torch.stack(gt)
+    noise = ose3.se3_exp(torch.from_numpy(np.concatenate((rng.normal(0, 0.3, size=(m + 1, 3)),
+                                                          rng.normal(0, 0.003, size=(m + 1, 3))), 1)))
+    pred = ose3.se3_mul(gt, noise)
+    G = ose3.se3_matrix(gt).numpy()
+    Pm = ose3.se3_matrix(pred).numpy()
+    ate, terr = tm.absolute_trajectory_error(G, Pm)
+    ate_na, _ = tm.absolute_trajectory_error(G, Pm, prealign=False)
+    rpe_t, rpe_r = tm.relative_pose_error(G, Pm)
+    save('metrics.npz', gt=gt, pred=pred, ate=np.float64(ate), trans_err=np.asarray(terr), ate_noalign=np.float64(ate_na),
+         rpe_trans=np.asarray(rpe_t), rpe_rot=np.asarray(rpe_r))
+
+
+def main():
+    torch.set_num_threads(8)
+    R = load_reference()
+    gen_solver(R)
+    gen_kat(R)
+    gen_warp(R)
+    gen_geometry(R)
+    gen_metrics(R)
+
+
+if __name__ == '__main__':
+    main()
