@@ -1,0 +1,172 @@
+/*
+ * rpe.h -- C ABI of librpe_hip.so: the MI355X (gfx950) hot path of the per-frame stereo pose solve.
+ *
+ * Drop-in boundary for aimi-lab/robust-pose-estimator (reference paths are relative to its repo root).
+ * Every entry point takes raw DEVICE pointers, explicit shapes and a HIP stream (passed as void*, a
+ * hipStream_t; NULL = the default stream).  All tensors are caller-owned, contiguous, NCHW, row-major,
+ * x fastest.  Inputs are const; outputs and scratch are pre-allocated by the caller (size-query
+ * functions below).  The library keeps no mutable global state and is re-entrant (one host thread per
+ * GPU).  Return value: 0 = ok; <0 = RPE_E_* below.  No C++ exception crosses this boundary.  Numerical
+ * failure is signalled in-band exactly like the reference (NaN pose -> caller's failure gate,
+ * core/pose/pose_estimator.py:81-87).
+ */
+#ifndef RPE_H
+#define RPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPE_OK 0
+#define RPE_E_BADARG (-1)  /* null pointer, non-positive size, unsupported dtype / radius / level count */
+#define RPE_E_LAUNCH (-2)  /* hipGetLastError() != hipSuccess after a launch                            */
+#define RPE_E_UNSUPPORTED (-3)
+
+#define RPE_F32 0
+#define RPE_F64 1
+
+/* solver modes of rpe_pose_solve */
+#define RPE_SOLVER_LBFGS 0 /* reference-faithful: torch.optim.LBFGS(lr=1, line_search_fn=None) iterates */
+#define RPE_SOLVER_GN 1    /* Gauss-Newton: 6x6 normal equations, Cholesky in f64                        */
+
+/* stop reasons written to info[.][2] by rpe_pose_solve (0 = still running / not started) */
+#define RPE_STOP_OPT_AT_START 1 /* max|g| <= 1e-7 at the first evaluation                                */
+#define RPE_STOP_GTD 2          /* directional derivative g.d > -1e-9                                    */
+#define RPE_STOP_MAX_ITER 3
+#define RPE_STOP_MAX_EVAL 4     /* evals >= max_iter*5/4                                                 */
+#define RPE_STOP_OPT 5          /* max|g| <= 1e-7                                                        */
+#define RPE_STOP_STEP 6         /* max|t*d| <= 1e-9                                                      */
+#define RPE_STOP_LOSS 7         /* |loss - prev_loss| < 1e-9                                             */
+#define RPE_STOP_NOT_PD 8       /* GN only: H not positive definite or g not finite; pose left unchanged */
+
+/* Library / build identification, e.g. "rpe-hip 0.1 gfx950". */
+const char *rpe_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * SE(3) group ops -- replace the lietorch C++/CUDA kernels the reference calls through
+ * `from lietorch import SE3` (core/geometry/pinhole_transforms.py:3,29,51; core/pose/pose_estimator.py:81-91;
+ * core/optimization/declerative_node_lie.py:233-234).  Pose = 7 scalars [tx ty tz qx qy qz qw]; tangent =
+ * 6 scalars [tau(3) phi(3)].  dtype = RPE_F32 | RPE_F64 for every pointer of the call.
+ * --------------------------------------------------------------------------------------------------------- */
+int rpe_se3_exp(const void *xi, void *T, int64_t n, int dtype, void *stream);            /* (n,6) -> (n,7)   */
+int rpe_se3_log(const void *T, void *xi, int64_t n, int dtype, void *stream);            /* (n,7) -> (n,6)   */
+int rpe_se3_mul(const void *A, const void *B, void *C, int64_t n, int dtype, void *stream); /* C = A * B     */
+int rpe_se3_inv(const void *T, void *Tinv, int64_t n, int dtype, void *stream);
+/* T (n,7) acts on pts (n,m,3) -> out (n,m,3): `T * pts` with the (n,1) pose broadcast over m points.      */
+int rpe_se3_act(const void *T, const void *pts, void *out, int64_t n, int64_t m, int dtype, void *stream);
+/* Trajectory chaining of core/pose/pose_estimator.py:90-91 as an inclusive scan over m relative poses:
+ * P_k = P_{k-1} * inv(scale(rel_k, s)), P_{-1} = init (7 scalars, may be NULL = identity). f64 or f32.    */
+int rpe_se3_chain(const void *rel, const void *init, void *out, int64_t m, double scale, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Pose layer -- replaces DPoseSE3Head.objective / .solve (core/pose/pose_head.py:12-79) together with
+ * torch.optim.LBFGS, transform/project (core/geometry/pinhole_transforms.py:28-30,90-99) and
+ * DeclarativeFunctionLie.forward (core/optimization/declerative_node_lie.py:223-247).
+ *
+ * Inputs (all float32 unless noted), n rows, H*W pixels each:
+ *   flow (n,2,H,W)  pcl1 (n,3,H,W)  pcl2 (n,3,H,W)  w1 (n,1,H,W)  w2 (n,1,H,W)
+ *   mask1, mask2 (n,1,H,W) uint8 (torch.bool storage, 0/1)   K (n,3,3)   loss_weight (n,2) = [w3d, w2d]
+ * All arithmetic is float64, as in the reference (pose_head.py:64).
+ * --------------------------------------------------------------------------------------------------------- */
+/* Scratch bytes needed by rpe_pose_reduce / rpe_pose_solve for n rows of h*w pixels. */
+size_t rpe_pose_workspace_bytes(int n, int h, int w);
+
+/* One objective evaluation at poses T (n,7) f64.  out (n,32) f64 per row:
+ *   [0] loss2d  [1] loss3d  [2] f = lw[1]*loss2d + lw[0]*loss3d  [3..8] g = df/dxi (left perturbation,
+ *   unclipped)  [9..29] upper triangle of the Gauss-Newton Hessian H (row-major: 00 01 .. 05 11 12 .. 55;
+ *   zeros unless need_hessian != 0)  [30],[31] reserved.                                                  */
+int rpe_pose_reduce(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
+                    const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
+                    const double *T, int n, int h, int w, int need_hessian, double *out, void *workspace,
+                    void *stream);
+
+/* Whole solve on the device, no host synchronisation: start at identity, run `iters` iterations of
+ * `mode`, n independent rows.  Outputs: T_out (n,7) f64 group element; vec7 (n,7) f32 and log6 (n,6) f32
+ * (the two tensors DeclarativeFunctionLie.forward returns); info (n,4) int32 = [n_iter, func_evals,
+ * stop_reason, 0].  Any output pointer except T_out may be NULL.                                          */
+int rpe_pose_solve(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
+                   const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
+                   int n, int h, int w, int mode, int iters, double *T_out, float *vec7, float *log6,
+                   int32_t *info, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stereo depth, back-projection, flow warps and the 1/8 stacks of the weight heads -- replaces
+ * core/pose/pose_net.py:73-79 (depth from disparity, validity, proj), :104-108 (remap_from_flow x3,
+ * remap_from_flow_nearest; core/interpol/flow_utils.py:4-26) and :110-113 (bilinear x0.125 of the two
+ * 8-channel stacks) in ONE pass.  h and w must be multiples of 8.
+ *
+ *   in : stereo_flow2 (n,2,h,w)  time_flow (n,2,h,w)  baseline (n)  K (n,3,3)  depth1 (n,1,h,w)
+ *        image1l, image2l (n,3,h,w)  stereo_flow1 (n,2,h,w)  mask2 (n,1,h,w) u8
+ *   out: depth2 (n,1,h,w)  mask2_valid (n,1,h,w) u8 = mask2 & (0 < depth <= 1)   [pose_net.py:75-77]
+ *        pcl1 (n,3,h,w)  pcl2w (n,3,h,w) = remap_from_flow(proj(depth2), time_flow)
+ *        mask2w (n,1,h,w) u8 = valid_mapping & remap_nearest(mask2_valid)           [pose_net.py:107-108]
+ *        inp1 (n,8,h/8,w/8) = down8(cat(stereo_flow1, image1l, pcl1))
+ *        inp2 (n,8,h/8,w/8) = down8(cat(warp(stereo_flow2), warp(image2l), pcl2w))
+ *        pcl2 (n,3,h,w) un-warped cloud, may be NULL
+ * --------------------------------------------------------------------------------------------------------- */
+int rpe_depth_backproject_warp(const float *stereo_flow2, const float *time_flow, const float *baseline,
+                               const float *K, const float *depth1, const float *image1l, const float *image2l,
+                               const float *stereo_flow1, const uint8_t *mask2, int n, int h, int w,
+                               float *depth2, uint8_t *mask2_valid, float *pcl1, float *pcl2w, uint8_t *mask2w,
+                               float *inp1, float *inp2, float *pcl2, void *stream);
+
+/* flow2depth of core/pose/pose_net.py:127-135 (first frame): depth (n,1,h,w), valid (n,1,h,w) u8. */
+int rpe_flow2depth(const float *stereo_flow, const float *baseline, int n, int h, int w, float *depth,
+                   uint8_t *valid, void *stream);
+
+/* Integer sampling taps of the two warps for index-parity tests: x0,y0 = floor (bilinear), xn,yn =
+ * round-half-even (nearest) of the un-normalised grid_sample position.  Each (n,h,w) int32.            */
+int rpe_warp_taps(const float *flow, int n, int h, int w, int32_t *x0, int32_t *y0, int32_t *xn, int32_t *yn,
+                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RAFT correlation -- replaces CorrBlock (core/RAFT/core/corr.py of the aimi-lab/RAFT submodule: all-pairs
+ * correlation / sqrt(C), 4-level 2x2 average-pool pyramid, radius-r bilinear window lookup), called from
+ * RAFT.forward (call sites core/pose/pose_net.py:47,65,129).
+ *
+ * The pyramid is an opaque device buffer owned by the caller; its internal layout (8x4 tiles of f32 per
+ * query) is private to build/lookup.
+ * --------------------------------------------------------------------------------------------------------- */
+size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels);
+/* fmap1, fmap2: (b,c,h8,w8) f32.  Computes corr[b,q1,q2] = <fmap1[:,q1], fmap2[:,q2]> / sqrt(c) and the
+ * average-pooled levels. */
+int rpe_corr_build(const float *fmap1, const float *fmap2, int b, int c, int h8, int w8, int levels,
+                   void *pyramid, void *stream);
+/* coords (b,2,h8,w8) f32 (channel 0 = x, 1 = y) -> out (b, levels*(2r+1)^2, h8, w8) f32, channel order
+ * level-major then window index i*(2r+1)+j with x offset (i-r) and y offset (j-r) (upstream's transposed
+ * window).  radius must be 4, levels <= 4. */
+int rpe_corr_lookup(const void *pyramid, const float *coords, int b, int h8, int w8, int levels, int radius,
+                    float *out, void *stream);
+/* Integer taps of the lookup for index-parity tests: x0,y0 (b,levels,2r+1,h8*w8) int32 = floor of the
+ * un-normalised grid_sample position of window tap i on each axis (x0[..,i,q] pairs with x offset i-r,
+ * y0[..,j,q] with y offset j-r) -- the very indices rpe_corr_lookup reads.  -1000000 marks a non-finite tap. */
+int rpe_corr_lookup_taps(const float *coords, int b, int h8, int w8, int levels, int32_t *x0, int32_t *y0,
+                         void *stream);
+/* Copy one level of the pyramid out as a dense (b*h8*w8, h8>>l, w8>>l) f32 tensor (tests only). */
+int rpe_corr_export_level(const void *pyramid, int b, int h8, int w8, int levels, int level, float *dense,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RAFT update block, element-wise halves of SepConvGRU (core/RAFT/core/update.py) fused around the
+ * convolutions, and the convex 8x up-sampling of RAFT.upsample_flow (core/RAFT/core/raft.py).
+ * --------------------------------------------------------------------------------------------------------- */
+/* zr_pre (b,2c,hw): pre-activations of the z and r convolutions stacked on the channel axis; h is read from
+ * channels [0,c) of a (b,h_channels,hw) buffer.  Writes z = sigmoid(zr_pre[:, :c]) to z_out (b,c,hw) and
+ * r*h = sigmoid(zr_pre[:, c:]) * h into channels [0,c) of rh_out (b,rh_channels,hw), so rh_out can be the
+ * (r*h | x) buffer the q convolution reads. */
+int rpe_gru_gates_zr(const float *zr_pre, const float *h, int h_channels, int b, int c, int hw, float *z_out,
+                     float *rh_out, int rh_channels, void *stream);
+/* h_out = (1 - z) * h + z * tanh(q_pre); h_out may alias h.  h / h_out are channels [0,c) of buffers with
+ * h_channels / hout_channels channels per batch row, so the new state lands straight in the (h|x) buffer. */
+int rpe_gru_gates_h(const float *z, const float *q_pre, const float *h, int h_channels, int b, int c, int hw,
+                    float *h_out, int hout_channels, void *stream);
+/* flow (b,2,h8,w8), mask (b,576,h8,w8) raw logits already scaled by .25 -> out (b,2,8*h8,8*w8). */
+int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int w8, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPE_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of librpe_hip.so (the C ABI declared in include/rpe.h).
+
+The product path has NO CPU or PyTorch fallback: if the library is missing or a call returns a non-zero
+status, an exception is raised.  ``import torch`` must precede the dlopen so that the HIP runtime the
+library binds to (SONAME libamdhip64.so.7) is the copy PyTorch-ROCm already loaded -- two HIP runtimes
+in one process cannot share streams or device pointers.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (loads libamdhip64 first, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librpe_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_c = ctypes
+_vp, _i, _i64, _d, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/rpe.h one to one
+SIGNATURES = {
+    'rpe_version': (_c.c_char_p, []),
+    'rpe_se3_exp': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'rpe_se3_log': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'rpe_se3_mul': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    'rpe_se3_inv': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'rpe_se3_act': (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp]),
+    'rpe_se3_chain': (_i, [_vp, _vp, _vp, _i64, _d, _i, _vp]),
+    'rpe_pose_workspace_bytes': (_sz, [_i, _i, _i]),
+    'rpe_pose_reduce': (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp, _vp, _vp]),
+    'rpe_pose_solve': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rpe_depth_backproject_warp': (_i, [_vp] * 9 + [_i, _i, _i] + [_vp] * 9),
+    'rpe_flow2depth': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'rpe_warp_taps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'rpe_corr_pyramid_bytes': (_sz, [_i, _i, _i, _i]),
+    'rpe_corr_build': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_corr_lookup': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_corr_lookup_taps': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'rpe_corr_export_level': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_gru_gates_zr': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'rpe_gru_gates_h': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'rpe_upsample_convex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class RpeError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into librpe_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise RpeError('building librpe_hip.so failed')
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library, with argtypes set.  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RpeError(f'{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) or `make -C {CSRC}`. '
+                           'There is no CPU fallback for the HIP path.')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+_ERR = {-1: 'RPE_E_BADARG', -2: 'RPE_E_LAUNCH', -3: 'RPE_E_UNSUPPORTED'}
+
+
+def check(status, what):
+    if status != 0:
+        raise RpeError(f'{what} failed with {_ERR.get(status, status)}')
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)

@@ -1,0 +1,515 @@
+// Pose layer on gfx950: fused residual / gradient / Gauss-Newton-Hessian reduction over dense
+// correspondences and the on-device L-BFGS / GN iteration loop.
+//
+// Replaces (reference paths): core/pose/pose_head.py:12-79 (reprojection_objective, depth_objective,
+// objective, solve), core/geometry/pinhole_transforms.py:28-30,39-42,90-99 (transform, [I|-[X]x], project),
+// torch.optim.LBFGS.step (line_search_fn=None) and declerative_node_lie.py:233-234 (vec7/log6 outputs).
+//
+// Kernel plan per objective evaluation (HBM-bound, 42 B/pixel algorithmic):
+//   k_pose_reduce : grid (nblk, n).  Each thread streams 4 pixels per step with 16-byte loads from the ten
+//                   f32 planes + two u8 planes, does all arithmetic in f64 (as the reference), keeps 8 (+21
+//                   with the Hessian) f64 accumulators, then 64-lane butterfly -> LDS -> one partial row
+//                   per block.  No atomics: the result is bit-reproducible run to run.
+//   k_pose_update : grid (n), one wave.  Fixed-order sum of the block partials, gradient clipping, one
+//                   L-BFGS (or GN) iteration in R^6, left retraction T <- exp(t d) T.  State lives in the
+//                   caller's workspace, so the whole N-iteration solve is 2N launches and zero host syncs.
+#include "rpe_common.h"
+#include "se3_device.h"
+
+#define NPART 32          // doubles per partial row: loss2d, loss3d, g[6], H[21], pad
+#define HIST 100          // torch.optim.LBFGS history_size default
+#define RED_THREADS 256
+
+struct RowState {
+    double T[7];
+    double g[6];          // clipped gradient of the latest evaluation
+    double prev_g[6];
+    double d[6];
+    double t, loss, prev_loss, H_diag;
+    int n_iter, evals, stop, num_old;
+    double old_dirs[HIST][6];
+    double old_stps[HIST][6];
+    double ro[HIST];
+};
+
+// Wave-uniform per-row constants, pre-converted to f64 so the reduce kernel can keep them in SGPRs
+// (scalar loads) instead of spending 46 VGPRs per lane on them.
+struct RowUniform {
+    double R[9];
+    double t[3];
+    double K[9];
+    double c2, c3;      // loss_weight[1]/(hw*hw), loss_weight[0]/hw
+    double pad;
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int pose_nblk(int n, int h, int w) {
+    int64_t hw = (int64_t)h * w;
+    int64_t quads = (hw + 3) / 4;
+    // >= 2 quads per thread, and aim for >= ~1024 blocks chip-wide so all 256 CUs get several waves
+    int64_t per_row = (quads + RED_THREADS * 2 - 1) / (RED_THREADS * 2);
+    int64_t want = (1024 + n - 1) / n;
+    int64_t nblk = per_row < want ? per_row : want;
+    if (nblk < 1) nblk = 1;
+    int64_t maxblk = (quads + RED_THREADS - 1) / RED_THREADS;
+    if (nblk > maxblk) nblk = maxblk;
+    if (nblk > 2048) nblk = 2048;
+    return (int)nblk;
+}
+
+extern "C" size_t rpe_pose_workspace_bytes(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    size_t st = align_up(sizeof(RowState) * (size_t)n, 256) + align_up(sizeof(RowUniform) * (size_t)n, 256);
+    size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(n, h, w) * n, 256);
+    return st + pa + 256;
+}
+
+struct PoseArgs {
+    const float* flow; const float* pcl1; const float* pcl2; const float* w1; const float* w2;
+    const uint8_t* m1; const uint8_t* m2; const float* K; const float* lw;
+    int n, h, w;
+};
+
+__device__ __forceinline__ int tri(int i, int j) {   // upper-triangle index, i <= j
+    return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <bool HESS>
+__device__ __forceinline__ void pixel_terms(double* acc, double px, double py, double fl_x, double fl_y,
+                                            const double p[3], const double q[3], double w1, double w2, bool m1, bool m2,
+                                            const double R[9], const double t[3], const double K[9],
+                                            double c2, double c3, double Wd, double Hd) {
+    // X = R p + t   (pinhole_transforms.py:28-30)
+    double X = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
+    double Y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
+    double Z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+    // ipts = K X ; depth = clamp(iz, 1e-12)   (pinhole_transforms.py:93-98)
+    double ix = K[0] * X + K[1] * Y + K[2] * Z;
+    double iy = K[3] * X + K[4] * Y + K[5] * Z;
+    double iz = K[6] * X + K[7] * Y + K[8] * Z;
+    double dep = iz < 1e-12 ? 1e-12 : iz;                 // NaN stays NaN, like torch.clamp
+    double passz = iz >= 1e-12 ? 1.0 : 0.0;
+    double u = ix / dep, v = iy / dep;
+    double fx = px + fl_x, fy = py + fl_y;                // pose_head.py:19
+    double ex = fx - u, ey = fy - v;
+    double r2 = (ex * ex + ey * ey) * w1;                 // :21-22
+    bool inimg = (fx > 0.0) && (fy > 0.0) && (fx < Wd) && (fy < Hd);   // :24
+    bool bad = isinf(r2) || isnan(r2) || !inimg || !m1;   // :25
+    double gate2 = bad ? 0.0 : 1.0;
+    acc[0] += bad ? 0.0 : r2;                             // :28-29
+    double ex3 = X - q[0], ey3 = Y - q[1], ez3 = Z - q[2];   // :41-43
+    double r3 = (ex3 * ex3 + ey3 * ey3 + ez3 * ez3) * w2;
+    bool ok3 = m1 && m2;                                  // :47
+    double gate3 = ok3 ? 1.0 : 0.0;
+    acc[1] += ok3 ? r3 : 0.0;
+    // gradient, multiplied out the way autograd does (0 * nan = nan reaches the pose, as in the reference)
+    double a2 = -2.0 * w1 * gate2 * c2;
+    double gu = a2 * ex, gv = a2 * ey;
+    double g_ix = gu / dep, g_iy = gv / dep;
+    double g_iz = -(gu * ix + gv * iy) / (dep * dep) * passz;
+    double a3 = 2.0 * w2 * gate3 * c3;
+    double gX = K[0] * g_ix + K[3] * g_iy + K[6] * g_iz + a3 * ex3;
+    double gY = K[1] * g_ix + K[4] * g_iy + K[7] * g_iz + a3 * ey3;
+    double gZ = K[2] * g_ix + K[5] * g_iy + K[8] * g_iz + a3 * ez3;
+    acc[2] += gX; acc[3] += gY; acc[4] += gZ;            // [I | -[X]x]^T gX
+    acc[5] += Y * gZ - Z * gY;
+    acc[6] += Z * gX - X * gZ;
+    acc[7] += X * gY - Y * gX;
+    if (HESS) {
+        double* Hh = acc + 8;
+        double s2 = bad ? 0.0 : 2.0 * w1 * c2;
+        double s3 = ok3 ? 2.0 * w2 * c3 : 0.0;
+        double up = u * passz, vp = v * passz;
+        double Ju[6], Jv[6];
+        Ju[0] = (K[0] - up * K[6]) / dep; Ju[1] = (K[1] - up * K[7]) / dep; Ju[2] = (K[2] - up * K[8]) / dep;
+        Jv[0] = (K[3] - vp * K[6]) / dep; Jv[1] = (K[4] - vp * K[7]) / dep; Jv[2] = (K[5] - vp * K[8]) / dep;
+        Ju[3] = Y * Ju[2] - Z * Ju[1]; Ju[4] = Z * Ju[0] - X * Ju[2]; Ju[5] = X * Ju[1] - Y * Ju[0];
+        Jv[3] = Y * Jv[2] - Z * Jv[1]; Jv[4] = Z * Jv[0] - X * Jv[2]; Jv[5] = X * Jv[1] - Y * Jv[0];
+        if (s2 != 0.0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double su = s2 * Ju[i], sv = s2 * Jv[i];
+#pragma unroll
+                for (int j = i; j < 6; ++j) Hh[tri(i, j)] += su * Ju[j] + sv * Jv[j];
+            }
+        }
+        if (s3 != 0.0) {
+            // J^T J for J = [I | -[X]x]:  [[I, -[X]x], [[X]x, |X|^2 I - X X^T]]
+            Hh[tri(0, 0)] += s3; Hh[tri(1, 1)] += s3; Hh[tri(2, 2)] += s3;
+            Hh[tri(0, 4)] += s3 * Z;  Hh[tri(0, 5)] -= s3 * Y;
+            Hh[tri(1, 3)] -= s3 * Z;  Hh[tri(1, 5)] += s3 * X;
+            Hh[tri(2, 3)] += s3 * Y;  Hh[tri(2, 4)] -= s3 * X;
+            double n2 = X * X + Y * Y + Z * Z;
+            Hh[tri(3, 3)] += s3 * (n2 - X * X); Hh[tri(3, 4)] -= s3 * X * Y; Hh[tri(3, 5)] -= s3 * X * Z;
+            Hh[tri(4, 4)] += s3 * (n2 - Y * Y); Hh[tri(4, 5)] -= s3 * Y * Z;
+            Hh[tri(5, 5)] += s3 * (n2 - Z * Z);
+        }
+    }
+}
+
+template <bool HESS, int VEC>
+__global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 4) void k_pose_reduce(PoseArgs A, const RowUniform* __restrict__ uni,
+                                                             const RowState* __restrict__ states,
+                                                             double* __restrict__ partials) {
+    constexpr int NACC = HESS ? 29 : 8;
+    const int row = blockIdx.y;
+    const int nblk = gridDim.x;
+    double* prow = partials + ((size_t)row * nblk + blockIdx.x) * NPART;
+    if (states && states[row].stop != 0) return;          // finished rows cost nothing
+    const int64_t hw = (int64_t)A.h * A.w;
+    const RowUniform& U = uni[row];
+    double R[9], t[3], K[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { R[i] = U.R[i]; K[i] = U.K[i]; }
+    t[0] = U.t[0]; t[1] = U.t[1]; t[2] = U.t[2];
+    const double c2 = U.c2, c3 = U.c3;
+    const double Wd = (double)A.w, Hd = (double)A.h;
+
+    const float* flx = A.flow + (size_t)row * 2 * hw; const float* fly = flx + hw;
+    const float* p1 = A.pcl1 + (size_t)row * 3 * hw;
+    const float* p2 = A.pcl2 + (size_t)row * 3 * hw;
+    const float* w1 = A.w1 + (size_t)row * hw; const float* w2 = A.w2 + (size_t)row * hw;
+    const uint8_t* m1 = A.m1 + (size_t)row * hw; const uint8_t* m2 = A.m2 + (size_t)row * hw;
+
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+
+    const int64_t nvec = (hw + VEC - 1) / VEC;
+    for (int64_t vq = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; vq < nvec; vq += (int64_t)nblk * RED_THREADS) {
+        const int64_t base = vq * VEC;
+        float f0[VEC], f1[VEC], a0[VEC], a1[VEC], a2[VEC], b0[VEC], b1[VEC], b2[VEC], ww1[VEC], ww2[VEC];
+        uint8_t mm1[VEC], mm2[VEC];
+        if constexpr (VEC == 4) {
+            *(float4*)f0 = *(const float4*)(flx + base); *(float4*)f1 = *(const float4*)(fly + base);
+            *(float4*)a0 = *(const float4*)(p1 + base); *(float4*)a1 = *(const float4*)(p1 + hw + base);
+            *(float4*)a2 = *(const float4*)(p1 + 2 * hw + base);
+            *(float4*)b0 = *(const float4*)(p2 + base); *(float4*)b1 = *(const float4*)(p2 + hw + base);
+            *(float4*)b2 = *(const float4*)(p2 + 2 * hw + base);
+            *(float4*)ww1 = *(const float4*)(w1 + base); *(float4*)ww2 = *(const float4*)(w2 + base);
+            *(uint32_t*)mm1 = *(const uint32_t*)(m1 + base); *(uint32_t*)mm2 = *(const uint32_t*)(m2 + base);
+        } else {
+            f0[0] = flx[base]; f1[0] = fly[base];
+            a0[0] = p1[base]; a1[0] = p1[hw + base]; a2[0] = p1[2 * hw + base];
+            b0[0] = p2[base]; b1[0] = p2[hw + base]; b2[0] = p2[2 * hw + base];
+            ww1[0] = w1[base]; ww2[0] = w2[base]; mm1[0] = m1[base]; mm2[0] = m2[base];
+        }
+        const int y = (int)(base / A.w);
+        const int x = (int)(base - (int64_t)y * A.w);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            double p[3] = {(double)a0[k], (double)a1[k], (double)a2[k]};
+            double q[3] = {(double)b0[k], (double)b1[k], (double)b2[k]};
+            pixel_terms<HESS>(acc, (double)(x + k) + 0.5, (double)y + 0.5, (double)f0[k], (double)f1[k], p, q,
+                              (double)ww1[k], (double)ww2[k], mm1[k] != 0, mm2[k] != 0, R, t, K, c2, c3, Wd, Hd);
+            if (VEC > 1) __builtin_amdgcn_sched_barrier(0);   // one pixel at a time: bounds f64 live ranges
+        }
+    }
+
+    __shared__ double red[RED_THREADS / RPE_WAVE][NPART];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double s = wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NPART) {
+        double s = 0.0;
+        if (threadIdx.x < NACC) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        prow[threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- update
+__device__ __forceinline__ void write_rt(RowUniform& U, const double* Tp) {
+    double qx = Tp[3], qy = Tp[4], qz = Tp[5], qw = Tp[6];
+    U.R[0] = 1.0 - 2.0 * (qy * qy + qz * qz); U.R[1] = 2.0 * (qx * qy - qz * qw); U.R[2] = 2.0 * (qx * qz + qy * qw);
+    U.R[3] = 2.0 * (qx * qy + qz * qw); U.R[4] = 1.0 - 2.0 * (qx * qx + qz * qz); U.R[5] = 2.0 * (qy * qz - qx * qw);
+    U.R[6] = 2.0 * (qx * qz - qy * qw); U.R[7] = 2.0 * (qy * qz + qx * qw); U.R[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
+    U.t[0] = Tp[0]; U.t[1] = Tp[1]; U.t[2] = Tp[2];
+}
+__device__ __forceinline__ void write_consts(RowUniform& U, const float* K, const float* lw, int row, int h, int w) {
+    for (int i = 0; i < 9; ++i) U.K[i] = (double)K[(size_t)row * 9 + i];
+    const double hwd = (double)h * (double)w;
+    U.c2 = (double)lw[row * 2 + 1] / hwd / hwd;     // mean then /(h*w)  (pose_head.py:29)
+    U.c3 = (double)lw[row * 2 + 0] / hwd;           // mean              (pose_head.py:51)
+    U.pad = 0.0;
+}
+// uniforms for rpe_pose_reduce's explicit poses
+__global__ void k_pose_prep(RowUniform* uni, const double* T, const float* K, const float* lw, int n, int h, int w) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    write_rt(uni[row], T + (size_t)row * 7);
+    write_consts(uni[row], K, lw, row, h, w);
+}
+
+__device__ __forceinline__ double absmax6(const double* v) {   // torch .abs().max(): NaN propagates
+    double m = 0.0;
+    for (int i = 0; i < 6; ++i) { double a = fabs(v[i]); if (a > m || isnan(a)) m = a; if (isnan(m)) return m; }
+    return m;
+}
+__device__ __forceinline__ double dot6(const double* a, const double* b) {
+    double s = 0.0;
+    for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+    return s;
+}
+
+__device__ void apply_step(RowState& S, RowUniform& U, const double* dir, double tstep) {
+    // LieGroupParameter.add_: group <- exp(alpha * update) * group
+    V3<double> tau = v3<double>(tstep * dir[0], tstep * dir[1], tstep * dir[2]);
+    V3<double> phi = v3<double>(tstep * dir[3], tstep * dir[4], tstep * dir[5]);
+    Pose<double> E = se3_exp(tau, phi);
+    Pose<double> Tn = se3_mul(E, pose_load(S.T));
+    pose_store(S.T, Tn);
+    write_rt(U, S.T);
+}
+
+// Sums the block partials of one row in a fixed order: lane l owns value (l & 31), lanes >= 32 take the odd
+// blocks; the two halves are combined with one shuffle.
+__device__ __forceinline__ double sum_partials(const double* partials, int row, int nblk, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+    const double* p = partials + (size_t)row * nblk * NPART + j;
+    double s = 0.0;
+    for (int b = half; b < nblk; b += 2) s += p[(size_t)b * NPART];
+    s += __shfl_xor(s, 32, RPE_WAVE);
+    return s;
+}
+
+__global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform* uni, const double* partials, int nblk,
+                                                    const float* lw, int h, int w, int mode, int max_iter) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    RowState& S = states[row];
+    if (S.stop != 0) return;
+    __shared__ double vals[NPART];
+    double sv = sum_partials(partials, row, nblk, lane);
+    if (lane < NPART) vals[lane] = sv;
+    __syncthreads();
+    if (lane != 0) return;
+
+    const double hwd = (double)h * (double)w;
+    const double loss2d = vals[0] / hwd / hwd, loss3d = vals[1] / hwd;
+    const double loss = (double)lw[row * 2 + 1] * loss2d + (double)lw[row * 2 + 0] * loss3d;
+    double g[6];
+    for (int i = 0; i < 6; ++i) g[i] = vals[2 + i];
+    const double tol_grad = 1e-7, tol_change = 1e-9, lr = 1.0;
+
+    if (mode == RPE_SOLVER_GN) {
+        S.n_iter += 1; S.evals += 1; S.loss = loss;
+        for (int i = 0; i < 6; ++i) S.g[i] = g[i];
+        // Cholesky H = L L^T on the 6x6 upper triangle
+        double L[6][6];
+        bool ok = true;
+        for (int i = 0; i < 6; ++i) ok = ok && isfinite(g[i]);
+        for (int i = 0; i < 6 && ok; ++i) {
+            for (int j = 0; j <= i; ++j) {
+                double s = vals[8 + tri(j, i)];
+                for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+                if (i == j) { if (!(s > 0.0) || !isfinite(s)) { ok = false; break; } L[i][i] = sqrt(s); }
+                else L[i][j] = s / L[j][j];
+            }
+        }
+        if (!ok) { S.stop = RPE_STOP_NOT_PD; return; }
+        double yv[6], dl[6];
+        for (int i = 0; i < 6; ++i) { double s = -g[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * yv[k]; yv[i] = s / L[i][i]; }
+        for (int i = 5; i >= 0; --i) { double s = yv[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * dl[k]; dl[i] = s / L[i][i]; }
+        for (int i = 0; i < 6; ++i) S.d[i] = dl[i];
+        S.t = 1.0;
+        apply_step(S, uni[row], dl, 1.0);
+        if (absmax6(dl) <= tol_change) S.stop = RPE_STOP_STEP;
+        else if (S.n_iter == max_iter) S.stop = RPE_STOP_MAX_ITER;
+        return;
+    }
+
+    // ---- closure tail: clip_grad_norm_(y, 10)   (pose_head.py:76)
+    double nrm = sqrt(dot6(g, g));
+    double coef = 10.0 / (nrm + 1e-6);
+    if (coef > 1.0) coef = 1.0;
+    for (int i = 0; i < 6; ++i) g[i] *= coef;
+    for (int i = 0; i < 6; ++i) S.g[i] = g[i];
+
+    const int max_eval = max_iter * 5 / 4;
+    if (S.evals == 0) {                       // initial evaluation of LBFGS.step
+        S.evals = 1; S.loss = loss;
+        if (absmax6(g) <= tol_grad) { S.stop = RPE_STOP_OPT_AT_START; return; }
+        if (max_iter <= 0) { S.stop = RPE_STOP_MAX_ITER; return; }
+    } else {                                  // evaluation that closes iteration S.n_iter
+        S.evals += 1; S.loss = loss;
+        bool opt = absmax6(g) <= tol_grad;
+        double td[6];
+        for (int i = 0; i < 6; ++i) td[i] = S.d[i] * S.t;
+        if (S.evals >= max_eval) { S.stop = RPE_STOP_MAX_EVAL; return; }
+        if (opt) { S.stop = RPE_STOP_OPT; return; }
+        if (absmax6(td) <= tol_change) { S.stop = RPE_STOP_STEP; return; }
+        if (fabs(loss - S.prev_loss) < tol_change) { S.stop = RPE_STOP_LOSS; return; }
+    }
+    // ---- next iteration: direction
+    S.n_iter += 1;
+    double d[6];
+    if (S.n_iter == 1) {
+        for (int i = 0; i < 6; ++i) d[i] = -g[i];
+        S.H_diag = 1.0; S.num_old = 0;
+    } else {
+        double yk[6], sk[6];
+        for (int i = 0; i < 6; ++i) { yk[i] = g[i] - S.prev_g[i]; sk[i] = S.d[i] * S.t; }
+        double ys = dot6(yk, sk);
+        if (ys > 1e-10) {
+            if (S.num_old == HIST) {
+                for (int k = 1; k < HIST; ++k) {
+                    for (int i = 0; i < 6; ++i) { S.old_dirs[k - 1][i] = S.old_dirs[k][i]; S.old_stps[k - 1][i] = S.old_stps[k][i]; }
+                    S.ro[k - 1] = S.ro[k];
+                }
+                S.num_old = HIST - 1;
+            }
+            for (int i = 0; i < 6; ++i) { S.old_dirs[S.num_old][i] = yk[i]; S.old_stps[S.num_old][i] = sk[i]; }
+            S.ro[S.num_old] = 1.0 / ys;
+            S.num_old += 1;
+            S.H_diag = ys / dot6(yk, yk);
+        }
+        double al[HIST];
+        double qv[6];
+        for (int i = 0; i < 6; ++i) qv[i] = -g[i];
+        for (int k = S.num_old - 1; k >= 0; --k) {
+            al[k] = dot6(S.old_stps[k], qv) * S.ro[k];
+            for (int i = 0; i < 6; ++i) qv[i] += S.old_dirs[k][i] * (-al[k]);
+        }
+        for (int i = 0; i < 6; ++i) d[i] = qv[i] * S.H_diag;
+        for (int k = 0; k < S.num_old; ++k) {
+            double be = dot6(S.old_dirs[k], d) * S.ro[k];
+            for (int i = 0; i < 6; ++i) d[i] += S.old_stps[k][i] * (al[k] - be);
+        }
+    }
+    for (int i = 0; i < 6; ++i) { S.prev_g[i] = g[i]; S.d[i] = d[i]; }
+    S.prev_loss = loss;
+    double tstep;
+    if (S.n_iter == 1) {
+        double l1 = 0.0;
+        for (int i = 0; i < 6; ++i) l1 += fabs(g[i]);
+        double inv = 1.0 / l1;
+        tstep = (inv < 1.0 ? inv : 1.0) * lr;         // python min(1., x): x if x < 1. else 1.
+    } else tstep = lr;
+    S.t = tstep;
+    double gtd = dot6(g, d);
+    if (gtd > -tol_change) { S.stop = RPE_STOP_GTD; return; }
+    apply_step(S, uni[row], d, tstep);
+    if (S.n_iter == max_iter) S.stop = RPE_STOP_MAX_ITER;
+}
+
+__global__ void k_pose_init(RowState* states, RowUniform* uni, const float* K, const float* lw, int n, int h, int w) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    RowState& S = states[row];
+    for (int i = 0; i < 6; ++i) { S.T[i] = 0.0; S.g[i] = 0.0; S.prev_g[i] = 0.0; S.d[i] = 0.0; }
+    S.T[6] = 1.0;
+    S.t = 0.0; S.loss = 0.0; S.prev_loss = 0.0; S.H_diag = 1.0;
+    S.n_iter = 0; S.evals = 0; S.stop = 0; S.num_old = 0;
+    write_rt(uni[row], S.T);
+    write_consts(uni[row], K, lw, row, h, w);
+}
+
+__global__ void k_pose_finalize(RowState* states, int n, double* T_out, float* vec7, float* log6, int32_t* info) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    RowState& S = states[row];
+    if (S.stop == 0) S.stop = RPE_STOP_MAX_ITER;
+    for (int i = 0; i < 7; ++i) {
+        T_out[row * 7 + i] = S.T[i];
+        if (vec7) vec7[row * 7 + i] = (float)S.T[i];       // out.group.vec().float()
+    }
+    if (log6) {                                           // out.log().float()
+        V3<double> tau, phi;
+        se3_log(pose_load(S.T), tau, phi);
+        float* o = log6 + row * 6;
+        o[0] = (float)tau.x; o[1] = (float)tau.y; o[2] = (float)tau.z;
+        o[3] = (float)phi.x; o[4] = (float)phi.y; o[5] = (float)phi.z;
+    }
+    if (info) { info[row * 4 + 0] = S.n_iter; info[row * 4 + 1] = S.evals; info[row * 4 + 2] = S.stop; info[row * 4 + 3] = 0; }
+}
+
+// Packs the reduced sums of one row into the rpe_pose_reduce output layout.
+__global__ __launch_bounds__(64) void k_pose_pack(const double* partials, int nblk, const float* lw, int h, int w, double* out) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    double sv = sum_partials(partials, row, nblk, lane);
+    __shared__ double vals[NPART];
+    if (lane < NPART) vals[lane] = sv;
+    __syncthreads();
+    if (lane >= 32) return;
+    const double hwd = (double)h * (double)w;
+    double* o = out + (size_t)row * 32;
+    double l2 = vals[0] / hwd / hwd, l3 = vals[1] / hwd;
+    if (lane == 0) o[0] = l2;
+    else if (lane == 1) o[1] = l3;
+    else if (lane == 2) o[2] = (double)lw[row * 2 + 1] * l2 + (double)lw[row * 2 + 0] * l3;
+    else if (lane < 9) o[lane] = vals[lane - 1];
+    else if (lane < 30) o[lane] = vals[lane - 1];
+    else o[lane] = 0.0;
+}
+
+static void launch_reduce(const PoseArgs& A, const RowUniform* T, const RowState* st, double* partials, int nblk,
+                          bool hess, hipStream_t s) {
+    dim3 grid(nblk, A.n), block(RED_THREADS);
+    bool vec = ((int64_t)A.h * A.w) % 4 == 0 && A.w % 4 == 0;
+    const void* ptrs[] = {A.flow, A.pcl1, A.pcl2, A.w1, A.w2};
+    for (const void* p : ptrs) vec = vec && ((uintptr_t)p % 16 == 0);
+    vec = vec && ((uintptr_t)A.m1 % 4 == 0) && ((uintptr_t)A.m2 % 4 == 0);
+    if (hess) {
+        if (vec) hipLaunchKernelGGL((k_pose_reduce<true, 4>), grid, block, 0, s, A, T, st, partials);
+        else hipLaunchKernelGGL((k_pose_reduce<true, 1>), grid, block, 0, s, A, T, st, partials);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_pose_reduce<false, 4>), grid, block, 0, s, A, T, st, partials);
+        else hipLaunchKernelGGL((k_pose_reduce<false, 1>), grid, block, 0, s, A, T, st, partials);
+    }
+}
+
+static bool carve(void* ws, int n, int h, int w, RowState** st, RowUniform** uni, double** partials) {
+    if (!ws) return false;
+    uintptr_t p = ((uintptr_t)ws + 255) / 256 * 256;
+    *st = (RowState*)p;
+    p += align_up(sizeof(RowState) * (size_t)n, 256);
+    *uni = (RowUniform*)p;
+    p += align_up(sizeof(RowUniform) * (size_t)n, 256);
+    *partials = (double*)p;
+    return true;
+}
+
+extern "C" int rpe_pose_reduce(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
+                               const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
+                               const double* T, int n, int h, int w, int need_hessian, double* out, void* workspace,
+                               void* stream) {
+    if (!flow || !pcl1 || !pcl2 || !w1 || !w2 || !mask1 || !mask2 || !K || !loss_weight || !T || !out || n <= 0 || h <= 0 || w <= 0)
+        return RPE_E_BADARG;
+    RowState* st; RowUniform* uni; double* partials;
+    if (!carve(workspace, n, h, w, &st, &uni, &partials)) return RPE_E_BADARG;
+    PoseArgs A{flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w};
+    hipStream_t s = (hipStream_t)stream;
+    int nblk = pose_nblk(n, h, w);
+    hipLaunchKernelGGL(k_pose_prep, dim3(ceil_div(n, 64)), dim3(64), 0, s, uni, T, K, loss_weight, n, h, w);
+    launch_reduce(A, uni, nullptr, partials, nblk, need_hessian != 0, s);
+    hipLaunchKernelGGL(k_pose_pack, dim3(n), dim3(64), 0, s, (const double*)partials, nblk, loss_weight, h, w, out);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_pose_solve(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
+                              const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
+                              int n, int h, int w, int mode, int iters, double* T_out, float* vec7, float* log6,
+                              int32_t* info, void* workspace, void* stream) {
+    if (!flow || !pcl1 || !pcl2 || !w1 || !w2 || !mask1 || !mask2 || !K || !loss_weight || !T_out || n <= 0 || h <= 0 || w <= 0 || iters < 0)
+        return RPE_E_BADARG;
+    if (mode != RPE_SOLVER_LBFGS && mode != RPE_SOLVER_GN) return RPE_E_BADARG;
+    RowState* st; RowUniform* uni; double* partials;
+    if (!carve(workspace, n, h, w, &st, &uni, &partials)) return RPE_E_BADARG;
+    PoseArgs A{flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w};
+    hipStream_t s = (hipStream_t)stream;
+    int nblk = pose_nblk(n, h, w);
+    hipLaunchKernelGGL(k_pose_init, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, uni, K, loss_weight, n, h, w);
+    // LBFGS with max_iter = N costs N evaluations (the last iteration moves without re-evaluating);
+    // torch evaluates the closure once even for max_iter = 0.
+    int evals = mode == RPE_SOLVER_LBFGS && iters == 0 ? 1 : iters;
+    for (int it = 0; it < evals; ++it) {
+        launch_reduce(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s);
+        hipLaunchKernelGGL(k_pose_update, dim3(n), dim3(64), 0, s, st, uni, (const double*)partials, nblk, loss_weight, h, w, mode, iters);
+    }
+    hipLaunchKernelGGL(k_pose_finalize, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, n, T_out, vec7, log6, info);
+    return rpe_check_launch();
+}

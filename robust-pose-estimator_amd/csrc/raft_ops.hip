@@ -1,0 +1,124 @@
+// Element-wise halves of RAFT's SepConvGRU fused around the convolutions, and the convex 8x up-sampling.
+//
+// Replaces (reference's RAFT submodule): core/RAFT/core/update.py SepConvGRU.forward
+//     z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq(cat[r*h, x])); h = (1-z)*h + z*q
+// and core/RAFT/core/raft.py RAFT.upsample_flow (softmax over the 9 neighbours, weighted sum of 8*flow).
+// The convolutions themselves stay on MIOpen (dense contractions); these kernels remove the sigmoid / mul /
+// cat / tanh / blend round trips through HBM between them.
+#include "rpe_common.h"
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// zr_pre (b,2c,hw) ; h (b, h_ch, hw) channels [0,c) ; z_out (b,c,hw) ; rh_out (b, rh_ch, hw) channels [0,c)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, const float* __restrict__ h, int c, int hw,
+                                                  int h_ch, float* __restrict__ z_out, float* __restrict__ rh, int rh_ch) {
+    const int bz = blockIdx.y;
+    const size_t per = (size_t)c * hw;
+    for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        const float* zp = zr + (size_t)bz * 2 * per + e;
+        const float* rp = zp + per;
+        const float* hp = h + (size_t)bz * h_ch * hw + e;
+        float* zo = z_out + (size_t)bz * per + e;
+        float* ro = rh + (size_t)bz * rh_ch * hw + e;
+        if (VEC == 4) {
+            float4 zv = *(const float4*)zp, rv = *(const float4*)rp, hv = *(const float4*)hp;
+            float4 zz = make_float4(sigmoidf_(zv.x), sigmoidf_(zv.y), sigmoidf_(zv.z), sigmoidf_(zv.w));
+            float4 rr = make_float4(sigmoidf_(rv.x) * hv.x, sigmoidf_(rv.y) * hv.y, sigmoidf_(rv.z) * hv.z, sigmoidf_(rv.w) * hv.w);
+            *(float4*)zo = zz; *(float4*)ro = rr;
+        } else {
+            zo[0] = sigmoidf_(zp[0]); ro[0] = sigmoidf_(rp[0]) * hp[0];
+        }
+    }
+}
+
+// h_out = (1 - z) * h + z * tanh(q_pre)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gates_h(const float* __restrict__ z, const float* __restrict__ q, const float* h, int c,
+                                                 int hw, int h_ch, float* h_out, int ho_ch) {
+    const int bz = blockIdx.y;
+    const size_t per = (size_t)c * hw;
+    for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        const float* zp = z + (size_t)bz * per + e;
+        const float* qp = q + (size_t)bz * per + e;
+        const float* hp = h + (size_t)bz * h_ch * hw + e;
+        float* ho = h_out + (size_t)bz * ho_ch * hw + e;
+        if (VEC == 4) {
+            float4 zv = *(const float4*)zp, qv = *(const float4*)qp, hv = *(const float4*)hp;
+            float4 o;
+            o.x = (1.0f - zv.x) * hv.x + zv.x * tanhf(qv.x); o.y = (1.0f - zv.y) * hv.y + zv.y * tanhf(qv.y);
+            o.z = (1.0f - zv.z) * hv.z + zv.z * tanhf(qv.z); o.w = (1.0f - zv.w) * hv.w + zv.w * tanhf(qv.w);
+            *(float4*)ho = o;
+        } else {
+            ho[0] = (1.0f - zp[0]) * hp[0] + zp[0] * tanhf(qp[0]);
+        }
+    }
+}
+
+// One thread per 1/8-resolution cell; loops over the 64 sub-pixels.  Mask channel = k*64 + i*8 + j.
+__global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict__ flow, const float* __restrict__ mask, int h8,
+                                                         int w8, float* __restrict__ out) {
+    const int bz = blockIdx.y;
+    const int nq = h8 * w8;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int y = q / w8, x = q - y * w8;
+    float fx[9], fy[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {                              // F.unfold(8*flow, 3, padding=1): zero padded
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        const bool ok = yy >= 0 && yy < h8 && xx >= 0 && xx < w8;
+        fx[k] = ok ? 8.0f * flow[((size_t)bz * 2 + 0) * nq + (size_t)yy * w8 + xx] : 0.0f;
+        fy[k] = ok ? 8.0f * flow[((size_t)bz * 2 + 1) * nq + (size_t)yy * w8 + xx] : 0.0f;
+    }
+    const float* mb = mask + (size_t)bz * 576 * nq + q;
+    const int W = 8 * w8;
+    float* ox = out + ((size_t)bz * 2 + 0) * 64 * nq;
+    float* oy = out + ((size_t)bz * 2 + 1) * 64 * nq;
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float m[9], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { m[k] = mb[(size_t)(k * 64 + i * 8 + j) * nq]; mx = fmaxf(mx, m[k]); }
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); sum += m[k]; }
+            float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { float p = m[k] / sum; ax += p * fx[k]; ay += p * fy[k]; }
+            const size_t o = (size_t)(8 * y + i) * W + 8 * x + j;
+            ox[o] = ax; oy[o] = ay;
+        }
+    }
+}
+
+static bool vec_ok(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+extern "C" int rpe_gru_gates_zr(const float* zr_pre, const float* h, int h_channels, int b, int c, int hw, float* z_out,
+                                float* rh_out, int rh_channels, void* stream) {
+    if (!zr_pre || !h || !z_out || !rh_out || b <= 0 || c <= 0 || hw <= 0 || h_channels < c || rh_channels < c) return RPE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t per = (size_t)c * hw;
+    bool v4 = hw % 4 == 0 && vec_ok(zr_pre) && vec_ok(h) && vec_ok(z_out) && vec_ok(rh_out);
+    if (v4) hipLaunchKernelGGL(k_gates_zr<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, zr_pre, h, c, hw, h_channels, z_out, rh_out, rh_channels);
+    else hipLaunchKernelGGL(k_gates_zr<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, zr_pre, h, c, hw, h_channels, z_out, rh_out, rh_channels);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_gru_gates_h(const float* z, const float* q_pre, const float* h, int h_channels, int b, int c, int hw,
+                               float* h_out, int hout_channels, void* stream) {
+    if (!z || !q_pre || !h || !h_out || b <= 0 || c <= 0 || hw <= 0 || h_channels < c || hout_channels < c) return RPE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t per = (size_t)c * hw;
+    bool v4 = hw % 4 == 0 && vec_ok(z) && vec_ok(q_pre) && vec_ok(h) && vec_ok(h_out);
+    if (v4) hipLaunchKernelGGL(k_gates_h<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, z, q_pre, h, c, hw, h_channels, h_out, hout_channels);
+    else hipLaunchKernelGGL(k_gates_h<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, z, q_pre, h, c, hw, h_channels, h_out, hout_channels);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_upsample_convex(const float* flow, const float* mask, int b, int h8, int w8, float* out, void* stream) {
+    if (!flow || !mask || !out || b <= 0 || h8 <= 0 || w8 <= 0) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_upsample_convex, dim3(ceil_div((size_t)h8 * w8, 256), b), dim3(256), 0, (hipStream_t)stream, flow, mask, h8, w8, out);
+    return rpe_check_launch();
+}

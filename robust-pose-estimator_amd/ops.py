@@ -1,0 +1,245 @@
+"""Tensor-level wrappers of the C ABI (include/rpe.h): argument checking, output allocation from torch's
+caching allocator, and launch on torch's current HIP stream.  PyTorch is plumbing here (device memory and
+streams); every operation below runs in librpe_hip.so.  Tensors must live on a ROCm device -- there is no
+CPU path."""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+SOLVER_LBFGS, SOLVER_GN = 0, 1
+_DT = {torch.float32: 0, torch.float64: 1}
+
+
+def _dev(t, dtype=None, name='tensor'):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.RpeError(f'{name}: expected a tensor on the GPU (the HIP path has no CPU fallback)')
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.RpeError(f'{name}: expected dtype {dtype}, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _mask(t, name):
+    t = _dev(t, None, name)
+    if t.dtype == torch.bool:
+        return t.view(torch.uint8)
+    if t.dtype == torch.uint8:
+        return t
+    raise _lib.RpeError(f'{name}: expected bool/uint8 mask')
+
+
+# ------------------------------------------------------------------------------------------------- SE(3)
+def _se3_unary(fn, x, din, dout):
+    x = _dev(x, None, 'se3 input')
+    if x.dtype not in _DT or x.shape[-1] != din:
+        raise _lib.RpeError('se3: bad dtype/shape')
+    out = torch.empty(*x.shape[:-1], dout, dtype=x.dtype, device=x.device)
+    n = x.numel() // din
+    check(fn(ptr(x), ptr(out), n, _DT[x.dtype], stream_ptr()), 'rpe_se3')
+    return out
+
+
+def se3_exp(xi):
+    return _se3_unary(lib().rpe_se3_exp, xi, 6, 7)
+
+
+def se3_log(T):
+    return _se3_unary(lib().rpe_se3_log, T, 7, 6)
+
+
+def se3_inv(T):
+    return _se3_unary(lib().rpe_se3_inv, T, 7, 7)
+
+
+def se3_mul(A, B):
+    A, B = torch.broadcast_tensors(A, B)
+    A, B = _dev(A, None, 'A'), _dev(B, A.dtype, 'B')
+    out = torch.empty_like(A)
+    check(lib().rpe_se3_mul(ptr(A), ptr(B), ptr(out), A.numel() // 7, _DT[A.dtype], stream_ptr()), 'rpe_se3_mul')
+    return out
+
+
+def se3_act(T, pts):
+    """T (n,7) or (n,1,7) acting on pts (n,m,3)."""
+    pts = _dev(pts, None, 'pts')
+    n, m = pts.shape[0], pts.shape[1]
+    T = _dev(T.reshape(n, 7), pts.dtype, 'T')
+    out = torch.empty_like(pts)
+    check(lib().rpe_se3_act(ptr(T), ptr(pts), ptr(out), n, m, _DT[pts.dtype], stream_ptr()), 'rpe_se3_act')
+    return out
+
+
+def se3_chain(rel, scale=1.0, init=None):
+    rel = _dev(rel.reshape(-1, 7), None, 'rel')
+    init = _dev(init.reshape(7), rel.dtype, 'init') if init is not None else None
+    out = torch.empty_like(rel)
+    check(lib().rpe_se3_chain(ptr(rel), ptr(init), ptr(out), rel.shape[0], float(scale), _DT[rel.dtype], stream_ptr()),
+          'rpe_se3_chain')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- pose layer
+def _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight):
+    f32 = torch.float32
+    flow = _dev(flow, f32, 'flow')
+    n, _, h, w = flow.shape
+    pcl1, pcl2 = _dev(pcl1, f32, 'pcl1'), _dev(pcl2, f32, 'pcl2')
+    w1, w2 = _dev(w1, f32, 'w1'), _dev(w2, f32, 'w2')
+    mask1, mask2 = _mask(mask1, 'mask1'), _mask(mask2, 'mask2')
+    K = _dev(K, f32, 'K')
+    lw = _dev(loss_weight, f32, 'loss_weight')
+    for t, c in ((pcl1, 3), (pcl2, 3), (w1, 1), (w2, 1), (mask1, 1), (mask2, 1)):
+        if tuple(t.shape) != (n, c, h, w):
+            raise _lib.RpeError(f'pose layer: shape {tuple(t.shape)} != {(n, c, h, w)}')
+    if tuple(K.shape) != (n, 3, 3) or tuple(lw.shape) != (n, 2):
+        raise _lib.RpeError('pose layer: K must be (n,3,3) and loss_weight (n,2)')
+    return (flow, pcl1, pcl2, w1, w2, mask1, mask2, K, lw), n, h, w
+
+
+def _workspace(n, h, w, device):
+    return torch.empty(lib().rpe_pose_workspace_bytes(n, h, w), dtype=torch.uint8, device=device)
+
+
+def pose_reduce(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, T, need_hessian=False):
+    """One objective evaluation at T (n,7) f64 -> dict(loss2d, loss3d, f, g (n,6), H (n,6,6))."""
+    args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
+    T = _dev(T.reshape(n, 7), torch.float64, 'T')
+    out = torch.empty(n, 32, dtype=torch.float64, device=T.device)
+    ws = _workspace(n, h, w, T.device)
+    check(lib().rpe_pose_reduce(*[ptr(a) for a in args], ptr(T), n, h, w, int(bool(need_hessian)), ptr(out), ptr(ws),
+                                stream_ptr()), 'rpe_pose_reduce')
+    res = dict(loss2d=out[:, 0], loss3d=out[:, 1], f=out[:, 2], g=out[:, 3:9])
+    if need_hessian:
+        iu = torch.triu_indices(6, 6, device=T.device)
+        H = torch.zeros(n, 6, 6, dtype=torch.float64, device=T.device)
+        H[:, iu[0], iu[1]] = out[:, 9:30]
+        H = H + H.transpose(1, 2) - torch.diag_embed(torch.diagonal(H, dim1=1, dim2=2))
+        res['H'] = H
+    return res
+
+
+def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mode=SOLVER_LBFGS):
+    """Device-resident solve.  Returns (T f64 (n,7), vec7 f32 (n,7), log6 f32 (n,6), info int32 (n,4))."""
+    args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
+    dev = args[0].device
+    T = torch.empty(n, 7, dtype=torch.float64, device=dev)
+    vec7 = torch.empty(n, 7, dtype=torch.float32, device=dev)
+    log6 = torch.empty(n, 6, dtype=torch.float32, device=dev)
+    info = torch.empty(n, 4, dtype=torch.int32, device=dev)
+    ws = _workspace(n, h, w, dev)
+    check(lib().rpe_pose_solve(*[ptr(a) for a in args], n, h, w, int(mode), int(iters), ptr(T), ptr(vec7), ptr(log6),
+                               ptr(info), ptr(ws), stream_ptr()), 'rpe_pose_solve')
+    return T, vec7, log6, info
+
+
+# ------------------------------------------------------------------------------------------------- geometry
+def depth_backproject_warp(stereo_flow2, time_flow, baseline, K, depth1, image1l, image2l, stereo_flow1, mask2,
+                           want_pcl2=False):
+    f32 = torch.float32
+    sf2 = _dev(stereo_flow2, f32, 'stereo_flow2')
+    n, _, h, w = sf2.shape
+    tf, b, K = _dev(time_flow, f32, 'time_flow'), _dev(baseline, f32, 'baseline'), _dev(K, f32, 'K')
+    d1, i1, i2 = _dev(depth1, f32, 'depth1'), _dev(image1l, f32, 'image1l'), _dev(image2l, f32, 'image2l')
+    sf1, m2 = _dev(stereo_flow1, f32, 'stereo_flow1'), _mask(mask2, 'mask2')
+    dev = sf2.device
+    e = lambda *s, dt=f32: torch.empty(*s, dtype=dt, device=dev)
+    depth2, pcl1, pcl2w = e(n, 1, h, w), e(n, 3, h, w), e(n, 3, h, w)
+    m2v, m2w = e(n, 1, h, w, dt=torch.uint8), e(n, 1, h, w, dt=torch.uint8)
+    inp1, inp2 = e(n, 8, h // 8, w // 8), e(n, 8, h // 8, w // 8)
+    pcl2 = e(n, 3, h, w) if want_pcl2 else None
+    check(lib().rpe_depth_backproject_warp(ptr(sf2), ptr(tf), ptr(b), ptr(K), ptr(d1), ptr(i1), ptr(i2), ptr(sf1), ptr(m2),
+                                           n, h, w, ptr(depth2), ptr(m2v), ptr(pcl1), ptr(pcl2w), ptr(m2w), ptr(inp1),
+                                           ptr(inp2), ptr(pcl2), stream_ptr()), 'rpe_depth_backproject_warp')
+    return dict(depth2=depth2, mask2=m2v.view(torch.bool), pcl1=pcl1, pcl2w=pcl2w, mask2w=m2w.view(torch.bool),
+                inp1=inp1, inp2=inp2, pcl2=pcl2)
+
+
+def flow2depth(stereo_flow, baseline):
+    sf = _dev(stereo_flow, torch.float32, 'stereo_flow')
+    n, _, h, w = sf.shape
+    b = _dev(baseline, torch.float32, 'baseline')
+    depth = torch.empty(n, 1, h, w, dtype=torch.float32, device=sf.device)
+    valid = torch.empty(n, 1, h, w, dtype=torch.uint8, device=sf.device)
+    check(lib().rpe_flow2depth(ptr(sf), ptr(b), n, h, w, ptr(depth), ptr(valid), stream_ptr()), 'rpe_flow2depth')
+    return depth, valid.view(torch.bool)
+
+
+def warp_taps(flow):
+    fl = _dev(flow, torch.float32, 'flow')
+    n, _, h, w = fl.shape
+    outs = [torch.empty(n, h, w, dtype=torch.int32, device=fl.device) for _ in range(4)]
+    check(lib().rpe_warp_taps(ptr(fl), n, h, w, *[ptr(o) for o in outs], stream_ptr()), 'rpe_warp_taps')
+    return dict(x0=outs[0], y0=outs[1], xn=outs[2], yn=outs[3])
+
+
+# ------------------------------------------------------------------------------------------------- correlation
+class CorrPyramid:
+    """Opaque device buffer holding the 4-level correlation pyramid of a batch of pairs."""
+
+    def __init__(self, b, h8, w8, levels=4, radius=4, device='cuda'):
+        self.b, self.h8, self.w8, self.levels, self.radius = b, h8, w8, levels, radius
+        nbytes = lib().rpe_corr_pyramid_bytes(b, h8, w8, levels)
+        if nbytes == 0:
+            raise _lib.RpeError('rpe_corr_pyramid_bytes: unsupported geometry')
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def build(self, fmap1, fmap2):
+        f1, f2 = _dev(fmap1, torch.float32, 'fmap1'), _dev(fmap2, torch.float32, 'fmap2')
+        b, c, h8, w8 = f1.shape
+        if (b, h8, w8) != (self.b, self.h8, self.w8) or f2.shape != f1.shape:
+            raise _lib.RpeError('corr build: shape mismatch')
+        check(lib().rpe_corr_build(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, ptr(self.buf), stream_ptr()), 'rpe_corr_build')
+        return self
+
+    def lookup(self, coords, out=None):
+        co = _dev(coords, torch.float32, 'coords')
+        if tuple(co.shape) != (self.b, 2, self.h8, self.w8):
+            raise _lib.RpeError('corr lookup: coords shape mismatch')
+        ch = self.levels * (2 * self.radius + 1) ** 2
+        if out is None:
+            out = torch.empty(self.b, ch, self.h8, self.w8, dtype=torch.float32, device=co.device)
+        check(lib().rpe_corr_lookup(ptr(self.buf), ptr(co), self.b, self.h8, self.w8, self.levels, self.radius, ptr(out),
+                                    stream_ptr()), 'rpe_corr_lookup')
+        return out
+
+    def taps(self, coords):
+        co = _dev(coords, torch.float32, 'coords')
+        win = 2 * self.radius + 1
+        x0 = torch.empty(self.b, self.levels, win, self.h8 * self.w8, dtype=torch.int32, device=co.device)
+        y0 = torch.empty_like(x0)
+        check(lib().rpe_corr_lookup_taps(ptr(co), self.b, self.h8, self.w8, self.levels, ptr(x0), ptr(y0), stream_ptr()),
+              'rpe_corr_lookup_taps')
+        return x0, y0
+
+    def export_level(self, level):
+        h, w = self.h8 >> level, self.w8 >> level
+        dense = torch.empty(self.b * self.h8 * self.w8, h, w, dtype=torch.float32, device=self.buf.device)
+        check(lib().rpe_corr_export_level(ptr(self.buf), self.b, self.h8, self.w8, self.levels, level, ptr(dense),
+                                          stream_ptr()), 'rpe_corr_export_level')
+        return dense
+
+
+# ------------------------------------------------------------------------------------------------- RAFT update
+def gru_gates_zr(zr_pre, h_buf, c, z_out, rh_buf):
+    """z_out = sigmoid(zr_pre[:, :c]); rh_buf[:, :c] = sigmoid(zr_pre[:, c:]) * h_buf[:, :c]."""
+    b, c2, hh, ww = zr_pre.shape
+    hw = hh * ww
+    check(lib().rpe_gru_gates_zr(ptr(zr_pre), ptr(h_buf), h_buf.shape[1], b, c, hw, ptr(z_out), ptr(rh_buf),
+                                 rh_buf.shape[1], stream_ptr()), 'rpe_gru_gates_zr')
+
+
+def gru_gates_h(z, q_pre, h_buf, c, h_out):
+    """h_out[:, :c] = (1 - z) * h_buf[:, :c] + z * tanh(q_pre)."""
+    b, _, hh, ww = q_pre.shape
+    check(lib().rpe_gru_gates_h(ptr(z), ptr(q_pre), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(h_out), h_out.shape[1],
+                                stream_ptr()), 'rpe_gru_gates_h')
+
+
+def upsample_convex(flow, mask):
+    fl, mk = _dev(flow, torch.float32, 'flow'), _dev(mask, torch.float32, 'mask')
+    b, _, h8, w8 = fl.shape
+    if tuple(mk.shape) != (b, 576, h8, w8):
+        raise _lib.RpeError('upsample_convex: mask must be (b,576,h/8,w/8)')
+    out = torch.empty(b, 2, 8 * h8, 8 * w8, dtype=torch.float32, device=fl.device)
+    check(lib().rpe_upsample_convex(ptr(fl), ptr(mk), b, h8, w8, ptr(out), stream_ptr()), 'rpe_upsample_convex')
+    return out

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    return {k: (torch.from_numpy(g[k]) if g[k].ndim > 0 else g[k]) for k in g.files}
+
+
+SOLVER_KEYS = ['flow', 'pcl1', 'pcl2', 'w1', 'w2', 'mask1', 'mask2', 'K', 'loss_weight']
+
+
+@pytest.fixture(scope='session')
+def rpe():
+    import rpe_amd
+    from rpe_amd import ops  # noqa: F401
+    return rpe_amd

@@ -1,0 +1,117 @@
+"""GPU: correlation pyramid build + lookup, GRU gate kernels and convex up-sampling against the oracle's
+RAFT restatement (torch CPU).  Float tolerance 2e-5 relative to the correlation scale (f32 dot products of
+length 256 accumulated in a different order); integer taps bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import raft as oraft
+
+pytestmark = pytest.mark.gpu
+
+
+def fmaps(seed, b, h8, w8, c=256):
+    rng = np.random.default_rng(seed)
+    f1 = torch.from_numpy(rng.normal(size=(b, c, h8, w8)).astype(np.float32))
+    f2 = torch.from_numpy(rng.normal(size=(b, c, h8, w8)).astype(np.float32))
+    return f1, f2
+
+
+def coords_for(seed, b, h8, w8, spread):
+    rng = np.random.default_rng(seed)
+    c0 = oraft.coords_grid(b, h8, w8)
+    fl = torch.from_numpy(rng.normal(0, spread, size=(b, 2, h8, w8)).astype(np.float32))
+    fl[:, :, : h8 // 3] = torch.round(fl[:, :, : h8 // 3] * 4) / 4          # exact quarter positions
+    fl[:, :, -2:] = 0.0                                                      # exact integers (iteration 0 case)
+    return c0 + fl
+
+
+@pytest.mark.parametrize('b,h8,w8', [(2, 32, 40), (1, 64, 80), (2, 17, 23)])
+def test_pyramid_and_lookup_match_oracle(rpe, b, h8, w8):
+    from rpe_amd import ops
+    f1, f2 = fmaps(b + h8, b, h8, w8)
+    ref = oraft.CorrBlock(f1, f2, num_levels=4, radius=4)
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda())
+    scale = float(ref.corr_pyramid[0].abs().max())
+    for l in range(4):
+        dense = pyr.export_level(l).cpu()
+        r = ref.corr_pyramid[l][:, 0]
+        assert dense.shape == r.shape, (l, dense.shape, r.shape)
+        assert float((dense - r).abs().max()) <= 2e-5 * scale, l
+    for spread in (0.0, 2.0, 30.0):                                          # 30: many windows leave the map
+        coords = coords_for(7, b, h8, w8, spread)
+        out = pyr.lookup(coords.cuda()).cpu()
+        expect = ref(coords)
+        assert out.shape == expect.shape
+        assert float((out - expect).abs().max()) <= 4e-5 * scale, spread
+
+
+def test_lookup_taps_bit_exact(rpe):
+    """Floor indices of every window tap == floor of torch's grid_sample position, computed explicitly."""
+    from rpe_amd import ops
+    b, h8, w8 = 2, 32, 40
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda')
+    coords = coords_for(11, b, h8, w8, 3.0)
+    x0, y0 = pyr.taps(coords.cuda())
+    x0, y0 = x0.cpu().numpy(), y0.cpu().numpy()
+    c = coords.numpy().reshape(b, 2, -1)
+    one, two = np.float32(1), np.float32(2)
+    for l in range(4):
+        wl, hl = w8 >> l, h8 >> l
+        for i in range(9):
+            d = np.float32(i - 4)
+            for axis, size, got in ((0, wl, x0), (1, hl, y0)):
+                v = c[:, axis] / np.float32(2 ** l) + d
+                g = two * v / np.float32(size - 1) - one
+                pos = ((g + one) / two) * np.float32(size - 1)
+                assert np.array_equal(got[:, l, i], np.floor(pos).astype(np.int32)), (l, i, axis)
+
+
+def test_lookup_handles_nonfinite_and_far_coords(rpe):
+    from rpe_amd import ops
+    b, h8, w8 = 1, 16, 24
+    f1, f2 = fmaps(3, b, h8, w8)
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda())
+    coords = oraft.coords_grid(b, h8, w8)
+    coords[0, 0, 0, 0] = float('nan')
+    coords[0, 1, 0, 1] = float('inf')
+    coords[0, 0, 0, 2] = 1e12
+    coords[0, 0, 0, 3] = -3000.0
+    out = pyr.lookup(coords.cuda()).cpu()
+    assert bool(torch.isfinite(out).all())
+    assert float(out[0, :, 0, :4].abs().max()) == 0.0                       # all taps outside -> zero padding
+    ref = oraft.CorrBlock(f1, f2)(oraft.coords_grid(b, h8, w8))
+    assert float((out[0, :, 1:] - ref[0, :, 1:]).abs().max()) <= 4e-5 * float(ref.abs().max())
+
+
+def test_gru_gates(rpe):
+    from rpe_amd import ops
+    torch.manual_seed(0)
+    b, c, h, w = 2, 128, 16, 20
+    zr = torch.randn(b, 2 * c, h, w) * 3
+    hx = torch.randn(b, 384, h, w)
+    q = torch.randn(b, c, h, w) * 3
+    z_out = torch.empty(b, c, h, w, device='cuda')
+    rhx = hx.clone().cuda()
+    ops.gru_gates_zr(zr.cuda(), hx.cuda(), c, z_out, rhx)
+    z_ref = torch.sigmoid(zr[:, :c])
+    rh_ref = torch.sigmoid(zr[:, c:]) * hx[:, :c]
+    assert torch.allclose(z_out.cpu(), z_ref, atol=1e-6)
+    assert torch.allclose(rhx[:, :c].cpu(), rh_ref, atol=1e-6)
+    assert torch.equal(rhx[:, c:].cpu(), hx[:, c:])                         # x part untouched
+    hx_d = hx.clone().cuda()
+    ops.gru_gates_h(z_out, q.cuda(), hx_d, c, hx_d)                         # in place
+    h_ref = (1 - z_ref) * hx[:, :c] + z_ref * torch.tanh(q)
+    assert torch.allclose(hx_d[:, :c].cpu(), h_ref, atol=2e-6)
+    assert torch.equal(hx_d[:, c:].cpu(), hx[:, c:])
+
+
+def test_convex_upsample(rpe):
+    from rpe_amd import ops
+    torch.manual_seed(1)
+    b, h8, w8 = 2, 12, 20
+    flow = torch.randn(b, 2, h8, w8) * 4
+    mask = torch.randn(b, 576, h8, w8) * 2
+    out = ops.upsample_convex(flow.cuda(), mask.cuda()).cpu()
+    assert torch.allclose(out, oraft.upsample_flow(flow, mask), atol=2e-5)

@@ -1,0 +1,132 @@
+"""CPU: the oracle restatement against the golden vectors produced from the reference's own files
+(oracle/gen_golden.py).  These pin the checker before it is used to judge the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SOLVER_KEYS, load_golden
+from oracle import metrics, pose_head, se3, synth, warp
+
+
+@pytest.mark.parametrize('name', ['solver_a', 'solver_b', 'solver_c', 'solver_d'])
+def test_objective_and_gradient(name):
+    g = load_golden(name + '.npz')
+    P = pose_head._prep(*[g[k] for k in SOLVER_KEYS])
+    for tag in ('id', 'rnd'):
+        ev = pose_head.evaluate(P, g['T_' + tag])
+        scale = max(1.0, float(g['graw_' + tag].abs().max()))
+        assert torch.allclose(ev['f'], g['f_' + tag], rtol=1e-13, atol=0)
+        assert float((ev['g'] - g['graw_' + tag]).abs().max()) <= 1e-13 * scale
+        clipped = pose_head._clip(ev['g'])          # reference clips over the whole batch gradient
+        assert float((clipped - g['gclip_' + tag]).abs().max()) <= 1e-12
+
+
+@pytest.mark.parametrize('name,ks', [('solver_a', (1, 2, 3, 8, 20, 100)), ('solver_b', (1, 2, 3, 8, 20)),
+                                     ('solver_c', (1, 2, 3, 8, 20, 100)), ('solver_d', (1,))])
+def test_lbfgs_iterates_match_reference(name, ks):
+    g = load_golden(name + '.npz')
+    args = [g[k] for k in SOLVER_KEYS]
+    for k in ks:
+        T, info = pose_head.lbfgs_solve(*args, iters=k, coupled=True)
+        assert float((T - g['T_k%d' % k]).abs().max()) < 1e-11, (name, k)
+        v7, l6 = pose_head.declarative_forward(T)
+        assert torch.allclose(v7, g['vec7_k%d' % k], atol=1e-7) and torch.allclose(l6, g['log6_k%d' % k], atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['solver_b', 'solver_c'])
+def test_independent_rows_match_per_frame_reference(name):
+    g = load_golden(name + '.npz')
+    args = [g[k] for k in SOLVER_KEYS]
+    for k in (3, 8, 20):
+        T, _ = pose_head.lbfgs_solve(*args, iters=k, coupled=False)
+        assert float((T - g['Tind_k%d' % k]).abs().max()) < 1e-8
+
+
+def test_nan_input_gives_nan_pose_like_reference():
+    g = load_golden('solver_nan.npz')
+    args = [g[k] for k in SOLVER_KEYS]
+    P = pose_head._prep(*args)
+    T_id = torch.zeros(1, 7, dtype=torch.float64)
+    T_id[:, 6] = 1
+    ev = pose_head.evaluate(P, T_id)
+    assert torch.allclose(ev['f'], g['f_id'], rtol=1e-13)            # NaN residual is zeroed in the loss ...
+    assert bool(torch.isnan(ev['g']).all()) and bool(torch.isnan(g['graw_id']).all())   # ... but poisons the gradient
+    T, _ = pose_head.lbfgs_solve(*args, iters=3)
+    assert bool(torch.isnan(T).all()) and bool(torch.isnan(g['T_k3']).all())
+
+
+def test_gn_hessian_is_consistent_with_gradient():
+    g = load_golden('solver_c.npz')
+    P = pose_head._prep(*[g[k] for k in SOLVER_KEYS])
+    T = se3.se3_exp(g['xi_gt'])       # noise-free case: residuals vanish at the true pose, so GN's H is the Hessian
+    ev = pose_head.evaluate(P, T, need_hessian=True)
+    # g(exp(d) T) ~ g + H d
+    d = torch.tensor([[1e-6, -2e-6, 1.5e-6, 2e-6, -1e-6, 1e-6]] * P['n'], dtype=torch.float64)
+    T2 = se3.se3_mul(se3.se3_exp(d), T)
+    g2 = pose_head.evaluate(P, T2)['g']
+    pred = ev['g'] + torch.einsum('nij,nj->ni', ev['H'], d)
+    assert float((g2 - pred).abs().max()) < 2e-2 * float((g2 - ev['g']).abs().max())
+    assert torch.allclose(ev['H'], ev['H'].transpose(1, 2))
+
+
+def test_reference_known_answer_test():
+    """tests/unit_test_pose_head.py:38-50 of the reference, on the oracle (same thresholds)."""
+    ref = load_golden('solver_kat.npz')
+    c = synth.solver_case(12345, 5, 180, 180, sigma_t=0.01, sigma_r=0.01, noise=0.0, unit_weights=True,
+                          full_masks=True, outliers=False)
+    c['loss_weight'] = torch.tensor([[0.001, 1.0]]).repeat(5, 1)
+    args = synth.solver_args(c)
+    Tgt = se3.se3_exp(c['xi_gt'])
+    assert float(pose_head.objective(*args, Tgt).max()) <= 1e-5
+    T, _ = pose_head.lbfgs_solve(*args, iters=100, coupled=True)
+    assert float(pose_head.objective(*args, T).max()) <= 1e-5
+    sup = (se3.se3_log(T) - se3.se3_log(Tgt)).abs().sum() / 5
+    assert float(sup) <= 0.05
+    assert float((T - ref['T_k100']).abs().max()) < 1e-6          # same answer the reference computed here
+
+
+def test_warps_match_reference_and_explicit_indices():
+    g = load_golden('warp.npz')
+    xb, vb = warp.remap_from_flow(g['x'], g['flow'])
+    assert torch.equal(xb, g['bilinear']) and torch.equal(vb, g['bilinear_valid'])
+    mn, vn = warp.remap_from_flow_nearest(g['mask'], g['flow'])
+    assert torch.equal(mn, g['nearest']) and torch.equal(vn, g['nearest_valid'])
+    assert torch.equal(warp.remap_explicit(g['mask'].float(), g['flow'], nearest=True), g['nearest'])
+    assert torch.allclose(warp.remap_explicit(g['x'], g['flow']), g['bilinear'], atol=1e-6)
+    assert torch.allclose(se3.hat(g['skew_in']), g['skew_out'])
+
+
+def test_geometry_matches_reference():
+    g = load_golden('geometry.npz')
+    assert torch.equal(pose_head.img_coords(12, 20), g['coords'])
+    bp = warp.backproject(g['depth'], g['K']).reshape(2, 3, -1)
+    assert torch.equal(bp, g['reproject'][:, :3])
+
+
+def test_metrics_match_reference():
+    g = load_golden('metrics.npz')
+    G = se3.se3_matrix(g['gt']).numpy()
+    P = se3.se3_matrix(g['pred']).numpy()
+    ate, terr = metrics.absolute_trajectory_error(G, P)
+    assert abs(ate - float(g['ate'])) < 1e-12 and np.allclose(terr, g['trans_err'].numpy(), atol=1e-12)
+    ate_na, _ = metrics.absolute_trajectory_error(G, P, prealign=False)
+    assert abs(ate_na - float(g['ate_noalign'])) < 1e-12
+    t, r = metrics.relative_pose_error(G, P)
+    assert np.allclose(t, g['rpe_trans'].numpy(), atol=1e-12) and np.allclose(r, g['rpe_rot'].numpy(), atol=1e-12)
+
+
+def test_se3_reference_tolerances():
+    """tests/unit_test_pinhole_transforms.py:24-33: inverse round trip and matrix form, rtol 1e-3 / atol 1e-6."""
+    torch.manual_seed(0)
+    pcl = torch.clamp(torch.rand(20, 3, 900), 0.0001, 1)
+    T = se3.se3_exp(torch.randn(20, 1, 6))
+    fwd = se3.se3_act(T, pcl.permute(0, 2, 1))
+    back = se3.se3_act(se3.se3_inv(T), fwd)
+    assert torch.allclose(back.permute(0, 2, 1), pcl, rtol=1e-3, atol=1e-6)
+    M = se3.se3_matrix(T[:, 0])
+    hom = torch.cat((pcl, torch.ones(20, 1, 900)), dim=1)
+    assert torch.allclose(torch.bmm(M, hom)[:, :3], fwd.permute(0, 2, 1), rtol=1e-3, atol=1e-6)
+    xi = torch.randn(50, 6, dtype=torch.float64) * 0.5
+    assert torch.allclose(se3.se3_log(se3.se3_exp(xi)), xi, atol=1e-10)
+    tiny = torch.randn(50, 6, dtype=torch.float64) * 1e-5                # Taylor branches
+    assert torch.allclose(se3.se3_log(se3.se3_exp(tiny)), tiny, atol=1e-14)
