@@ -1,0 +1,118 @@
+"""Frame-to-frame tracker host mirror: ``PoseEstimator(config, intrinsics, baseline, checkpoint, img_shape)``
+called once per stereo frame, as scripts/infer_trajectory.py:50-51,71-77 of the reference does.
+
+Follows core/pose/pose_estimator.py:26-48 (checkpoint + config overrides, 1/depth_clipping scale),
+:50-96 (forward: failure gate ``isnan | |log| > 0.1`` -> identity, de-normalise, chain
+``last_pose <- last_pose * rel^-1``) and :98-125 (get_pose_f2f), and core/utils/frame_class.py:5-50 (Frame).
+Frame-to-model tracking (``frame2frame: False``, SurfelMap) is out of scope.
+"""
+import warnings
+from collections import OrderedDict
+
+import torch
+
+from .pose_net import PoseNet
+from .se3 import SE3
+
+
+class Frame:
+    """Carrier of img / rimg / depth / mask / confidence / flow between consecutive calls (frame_class.py)."""
+
+    def __init__(self, img, rimg=None, depth=None, mask=None, confidence=None, flow=None):
+        assert img.ndim == 4
+        self.img = img.contiguous()
+        self.rimg = img.contiguous() if rimg is None else rimg.contiguous()
+        shape, dev = self.img.shape[-2:], self.img.device
+        n = self.img.shape[0]
+        self.mask = (torch.ones((n, 1, *shape), dtype=torch.bool, device=dev) if mask is None else mask).bool()
+        self.depth = torch.ones((n, 1, *shape), device=dev) if depth is None else depth.contiguous()
+        self.confidence = torch.ones((n, 1, *shape), device=dev) if confidence is None else confidence.contiguous()
+        self.flow = torch.zeros((n, 2, *shape), device=dev) if flow is None else flow.contiguous()
+        assert self.rimg.shape == self.img.shape
+        for t in (self.depth, self.mask, self.confidence, self.flow):
+            assert t.shape[-2:] == shape
+
+    @property
+    def shape(self):
+        return self.img.shape[-2:]
+
+    @property
+    def device(self):
+        return self.img.device
+
+    def to(self, d):
+        for k in ('img', 'rimg', 'depth', 'mask', 'confidence'):
+            setattr(self, k, getattr(self, k).to(d))
+        return self
+
+
+class PoseEstimator(torch.nn.Module):
+    def __init__(self, config, intrinsics, baseline, checkpoint, img_shape, init_pose=None):
+        """config: the ``slam`` section of the inference YAML (configuration/infer_f2f.yaml:1-11);
+        img_shape = (W, H) as in the reference; checkpoint: path, ``{'state_dict','config'}`` dict or a PoseNet."""
+        super().__init__()
+        if not config.get('frame2frame', True):
+            raise NotImplementedError('frame-to-model tracking (SurfelMap) is out of scope')
+        if isinstance(checkpoint, PoseNet):
+            model = checkpoint
+        else:
+            ckp = torch.load(checkpoint, map_location='cpu') if isinstance(checkpoint, str) else checkpoint
+            mcfg = dict(ckp['config']['model'])
+            mcfg['image_shape'] = (img_shape[1], img_shape[0])          # pose_estimator.py:28
+            mcfg['lbgfs_iters'] = config['lbgfs_iters']
+            mcfg['use_weights'] = config['conf_weighing']
+            if 'solver' in config:
+                mcfg['solver'] = config['solver']
+            model = PoseNet(mcfg)
+            state = OrderedDict((k.replace('module.', ''), v) for k, v in ckp['state_dict'].items())
+            model.load_state_dict(state)
+        model.eval()
+        self.model = model
+        self.config = config
+        self.register_buffer('intrinsics', intrinsics.unsqueeze(0).float(), persistent=False)
+        self.register_buffer('scale', torch.tensor(1 / config['depth_clipping'][1]), persistent=False)
+        self.register_buffer('baseline', torch.tensor(baseline).unsqueeze(0).float(), persistent=False)
+        self.last_pose = SE3.Identity(1) if init_pose is None else init_pose.float()
+        self.frame = None
+        self.last_frame = None
+
+    @property
+    def device(self):
+        return self.intrinsics.device
+
+    @torch.no_grad()
+    def forward(self, limg, rimg, mask):
+        """limg, rimg: (1,3,h,w) 0..255; mask: (1,1,h,w) True = valid.  Returns (absolute pose SE3, None, flow, weights)."""
+        self.last_pose = self.last_pose.to(limg.device)
+        self.last_frame = self.frame
+        self.frame = Frame(limg, rimg, mask=mask)
+        rel_pose, ret_frame, flow, weights = self.get_pose_f2f()
+        rel_log = rel_pose.log()
+        if bool(torch.isnan(rel_pose.vec()).any()) or bool((torch.abs(rel_log) > 1.0e-1).any()):     # :81
+            warnings.warn('pose estimation not converged, skip.', RuntimeWarning)
+            rel_pose = SE3.IdentityLike(self.last_pose)
+            self.success = False
+        else:
+            self.success = True
+        self.last_rel_pose = rel_pose
+        self.last_frame = ret_frame
+        rel_pose = rel_pose.scale(1 / self.scale)                        # :90 de-normalise the depth scaling
+        self.last_pose = self.last_pose * rel_pose.inv()                 # :91 chain transforms
+        return self.last_pose, None, flow, weights
+
+    def get_pose_f2f(self):
+        flow = None
+        if self.last_frame is None:
+            rel = SE3.IdentityLike(self.last_pose)
+            depth, stereo_flow, valid = self.model.flow2depth(self.frame.img, self.frame.rimg, self.baseline * self.scale)
+            self.frame.depth = depth / self.scale
+            self.frame.flow = stereo_flow
+            return rel, None, None, None
+        rel, depth1, depth2, weights, flow, stereo_flow = self.model.infer(
+            self.last_frame.img, self.frame.img, self.intrinsics, self.baseline * self.scale,
+            depth1=self.last_frame.depth * self.scale, image2r=self.frame.rimg, mask1=self.last_frame.mask,
+            mask2=self.frame.mask, stereo_flow1=self.last_frame.flow, ret_details=True)
+        rel = SE3(rel.data.reshape(1, 7))
+        self.frame.depth = depth2 / self.scale
+        self.frame.flow = stereo_flow
+        return rel, self.last_frame, flow, weights

@@ -1,0 +1,87 @@
+"""PoseNet host mirror (boundary B3): ``PoseNet(config).infer(image1l, image2l, intrinsics, baseline, depth1,
+image2r, mask1, mask2, stereo_flow1, ret_details)`` and ``.flow2depth(imagel, imager, baseline)`` with the
+reference's argument meaning (core/pose/pose_net.py:14-27,60-85,102-135) and parameter names (checkpoints load
+unchanged: ``flow.*``, ``weight_head_2d.0.*``, ``weight_head_3d.0.*``, ``loss_weight``).
+
+Per call: one batch-2n RAFT pass (HIP correlation / gates / up-sampling), one fused HIP pass for
+depth + back-projection + the four warps + both 1/8 stacks, the two TinyUNet heads on PyTorch-ROCm, and the
+device-resident SE(3) solve.  ``infer`` is generalised from the reference's hard-coded single frame
+(``flow_predictions[-1][0]`` / ``[1]``, :66-67) to n frames by splitting the RAFT batch in halves.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .pose_head import DeclarativeLayerLie, DPoseSE3Head, create_img_coords_t
+from .raft import RAFT
+from .se3 import SE3
+from .unet import TinyUNet
+
+
+class PoseNet(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.loss_weight = nn.Parameter(torch.tensor([1.0, 1.0]))
+        H, W = config['image_shape']
+        self.register_buffer('img_coords', create_img_coords_t(y=H, x=W), persistent=False)
+        self.use_weights = config.get('use_weights', True)
+        self.flow = RAFT(config)
+        self.flow.freeze_bn()
+        self.pose_head = DeclarativeLayerLie(DPoseSE3Head(self.img_coords, config.get('lbgfs_iters', 100),
+                                                          solver=config.get('solver', 'lbfgs')))
+        self.weight_head_2d = nn.Sequential(TinyUNet(in_channels=128 + 128 + 8, output_size=(H, W)), nn.Sigmoid())
+        self.weight_head_3d = nn.Sequential(TinyUNet(in_channels=128 + 128 + 8 + 8, output_size=(H, W)), nn.Sigmoid())
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.flow.eval()
+        return self
+
+    @torch.no_grad()
+    def flow2depth(self, imagel, imager, baseline, upsample=True):
+        """pose_net.py:127-135 -> (depth (n,1,h,w), stereo flow (n,2,h,w), valid (n,1,h,w) bool)."""
+        if not upsample:
+            raise NotImplementedError('upsample=False is not on the inference path')
+        flow = self.flow(imagel, imager, upsample=True)[0][-1]
+        depth, valid = ops.flow2depth(flow, baseline)
+        return depth, flow, valid
+
+    @torch.no_grad()
+    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1):
+        n = image1l.shape[0]
+        ref_imgs = torch.cat((image1l, image2l), dim=0)
+        trg_imgs = torch.cat((image2l, image2r), dim=0)
+        flow_predictions, hidden, context = self.flow(ref_imgs, trg_imgs, upsample=True)
+        time_flow = flow_predictions[-1][:n].contiguous()
+        stereo_flow2 = flow_predictions[-1][n:].contiguous()
+        hidden, context = hidden[:n], context[:n]
+        g = ops.depth_backproject_warp(stereo_flow2, time_flow, baseline, intrinsics, depth1, image1l, image2l,
+                                       stereo_flow1, mask2)
+        if self.use_weights:
+            w2d = self.weight_head_2d(torch.cat((g['inp1'], hidden, context), dim=1))
+            w3d = self.weight_head_3d(torch.cat((g['inp1'], g['inp2'], hidden, context), dim=1))
+        else:
+            w2d = torch.ones_like(g['depth2'])
+            w3d = torch.ones_like(g['depth2'])
+        g.update(time_flow=time_flow, stereo_flow2=stereo_flow2, hidden=hidden, context=context, w2d=w2d, w3d=w3d)
+        return g
+
+    @torch.no_grad()
+    def infer(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1,
+              ret_details=False):
+        s = self.stages(image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1)
+        mask2.copy_(s['mask2'])                               # `mask2 &= valid` mutates the caller's tensor (:77)
+        n = image1l.shape[0]
+        lw = self.loss_weight.detach()[None, :].repeat(n, 1)
+        vec7, _ = self.pose_head(s['time_flow'], s['pcl1'], s['pcl2w'], s['w2d'], s['w3d'], mask1.bool(), s['mask2w'],
+                                 intrinsics, lw)
+        pose = SE3(vec7[:, 0]) if n > 1 else SE3(vec7)[0]     # reference returns SE3(pose_se3)[0] for its n == 1
+        if ret_details:
+            return pose, depth1, s['depth2'], (s['w2d'], s['w3d']), s['time_flow'], s['stereo_flow2']
+        return pose
+
+    def init_from_raft(self, raft_ckp):
+        state = torch.load(raft_ckp, map_location='cpu')
+        self.flow.load_state_dict({k.replace('module.', ''): v for k, v in state.items()})
+        return self

@@ -1,0 +1,252 @@
+"""RAFT host mirror: same constructor / forward contract as the reference's RAFT fork
+(``RAFT(config)(img1, img2, upsample=True) -> (flow_predictions, hidden, context)``, call sites
+core/pose/pose_net.py:21-22,47,65,129) and the upstream parameter names, so ``raft-things.pth`` /
+``poseNet_*.pth`` state dicts load unchanged.
+
+What runs where (MI355X-first split):
+  * encoders and the update block's convolutions: dense contractions -> PyTorch-ROCm (MIOpen / MFMA)
+  * all-pairs correlation + pyramid, the per-iteration window lookup, the GRU gate arithmetic and the convex
+    up-sampling: hand-written HIP (csrc/corr.hip, csrc/raft_ops.hip) through the C ABI
+Exact re-associations used (results identical up to float rounding of the conv library):
+  * convz/convr of each GRU half share their input, so their weights are stacked into one 256-channel conv
+  * the (h | x) concatenations live in two persistent buffers; the gate kernels write r*h and the new h in place
+  * the mask head + convex up-sampling only run for the predictions that are returned (``all_flows=False``
+    returns just the final one, which is all the reference's PoseNet reads: ``[0][-1]``)
+The RAFT architecture itself is restated from princeton-vl/RAFT (the reference's submodule is empty);
+see oracle/raft.py for the CPU restatement these kernels are tested against.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _norm(kind, ch):
+    if kind == 'batch':
+        return nn.BatchNorm2d(ch)
+    if kind == 'instance':
+        return nn.InstanceNorm2d(ch)
+    if kind == 'none':
+        return nn.Sequential()
+    raise ValueError(kind)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn='batch', stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1 = _norm(norm_fn, planes)
+        self.norm2 = _norm(norm_fn, planes)
+        if stride == 1:
+            self.downsample = None
+        else:
+            self.norm3 = _norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class BasicEncoder(nn.Module):
+    def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.norm1 = _norm(norm_fn, 64)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = 64
+        self.layer1 = self._make_layer(64, stride=1)
+        self.layer2 = self._make_layer(96, stride=2)
+        self.layer3 = self._make_layer(128, stride=2)
+        self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, dim, stride=1):
+        l1 = ResidualBlock(self.in_planes, dim, self.norm_fn, stride=stride)
+        l2 = ResidualBlock(dim, dim, self.norm_fn, stride=1)
+        self.in_planes = dim
+        return nn.Sequential(l1, l2)
+
+    def forward(self, x):
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        return self.conv2(x)
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.conv2(self.relu(self.conv1(x)))
+
+
+class SepConvGRU(nn.Module):
+    """Parameters as upstream; the forward lives in BasicUpdateBlock.step (fused with the HIP gate kernels)."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        c = hidden_dim + input_dim
+        self.convz1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, corr_levels=4, corr_radius=4):
+        super().__init__()
+        cor_planes = corr_levels * (2 * corr_radius + 1) ** 2
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+    def forward(self, flow, corr):
+        cor = F.relu(self.convc1(corr))
+        cor = F.relu(self.convc2(cor))
+        flo = F.relu(self.convf1(flow))
+        flo = F.relu(self.convf2(flo))
+        return F.relu(self.conv(torch.cat([cor, flo], dim=1)))          # (b,126,h,w); caller appends flow
+
+
+class BasicUpdateBlock(nn.Module):
+    def __init__(self, corr_levels=4, corr_radius=4, hidden_dim=128):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.encoder = BasicMotionEncoder(corr_levels, corr_radius)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self._stacked = None
+
+    def stacked_gate_weights(self):
+        """convz|convr stacked on the output-channel axis (they read the same input)."""
+        g = self.gru
+        key = tuple(p._version for p in g.parameters()) + tuple(p.data_ptr() for p in g.parameters())
+        if self._stacked is None or self._stacked[0] != key:
+            w1 = torch.cat((g.convz1.weight, g.convr1.weight), 0).detach().contiguous()
+            b1 = torch.cat((g.convz1.bias, g.convr1.bias), 0).detach().contiguous()
+            w2 = torch.cat((g.convz2.weight, g.convr2.weight), 0).detach().contiguous()
+            b2 = torch.cat((g.convz2.bias, g.convr2.bias), 0).detach().contiguous()
+            self._stacked = (key, (w1, b1, w2, b2))
+        return self._stacked[1]
+
+    def step(self, hx, rhx, z_buf, corr, flow):
+        """One update.  hx = (h | inp | motion | flow) buffer, rhx = (r*h | same x) buffer; both (b,384,h,w).
+        Returns delta_flow; the new hidden state is left in hx[:, :128]."""
+        c = self.hidden_dim
+        g = self.gru
+        mot = self.encoder(flow, corr)
+        for buf in (hx, rhx):
+            buf[:, 2 * c:3 * c - 2].copy_(mot)
+            buf[:, 3 * c - 2:].copy_(flow)
+        w1, b1, w2, b2 = self.stacked_gate_weights()
+        # horizontal half: z = s(convz1 hx), r = s(convr1 hx), q = tanh(convq1 [r*h, x]), h = (1-z) h + z q
+        zr = F.conv2d(hx, w1, b1, padding=(0, 2))
+        ops.gru_gates_zr(zr, hx, c, z_buf, rhx)
+        q = g.convq1(rhx)
+        ops.gru_gates_h(z_buf, q, hx, c, hx)
+        # vertical half
+        zr = F.conv2d(hx, w2, b2, padding=(2, 0))
+        ops.gru_gates_zr(zr, hx, c, z_buf, rhx)
+        q = g.convq2(rhx)
+        ops.gru_gates_h(z_buf, q, hx, c, hx)
+        return self.flow_head(hx[:, :c])
+
+    def up_mask(self, net):
+        return .25 * self.mask(net)                                      # scale mask to balance gradients (upstream)
+
+
+def coords_grid(batch, ht, wd, device):
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing='ij')
+    return torch.stack((xs, ys), dim=0).float()[None].repeat(batch, 1, 1, 1)
+
+
+class RAFT(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.get('small', False):
+            raise NotImplementedError("RAFT-small is not on the reference's inference path (train.yaml:5 small: False)")
+        self.config = config
+        self.iters = int(config.get('iters', 12))
+        self.hidden_dim = self.context_dim = 128
+        self.corr_levels, self.corr_radius = 4, 4
+        drop = config.get('dropout', 0.0)
+        self.fnet = BasicEncoder(output_dim=256, norm_fn='instance', dropout=drop)
+        self.cnet = BasicEncoder(output_dim=256, norm_fn='batch', dropout=drop)
+        self.update_block = BasicUpdateBlock(self.corr_levels, self.corr_radius, hidden_dim=128)
+        self._pyr = None
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def _pyramid(self, b, h8, w8, device):
+        p = self._pyr
+        if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device:
+            self._pyr = ops.CorrPyramid(b, h8, w8, self.corr_levels, self.corr_radius, device=device)
+        return self._pyr
+
+    @torch.no_grad()
+    def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None):
+        """image1, image2: (N,3,H,W) in 0..255.  Inference only (the reference freezes RAFT, train.yaml:51)."""
+        iters = self.iters if iters is None else iters
+        N, _, H, W = image1.shape
+        h8, w8 = H // 8, W // 8
+        dev = image1.device
+        image1 = 2 * (image1 / 255.0) - 1.0
+        image2 = 2 * (image2 / 255.0) - 1.0
+        if fmaps is None:
+            f = self.fnet(torch.cat((image1, image2), dim=0))
+            fmap1, fmap2 = f[:N], f[N:]
+        else:
+            fmap1, fmap2 = fmaps
+        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float())
+        cnet = self.cnet(image1)
+        c = self.hidden_dim
+        hx = torch.empty(N, 3 * c, h8, w8, device=dev)
+        rhx = torch.empty_like(hx)
+        z_buf = torch.empty(N, c, h8, w8, device=dev)
+        torch.tanh(cnet[:, :c], out=hx[:, :c])
+        inp = torch.relu(cnet[:, c:])
+        hx[:, c:2 * c].copy_(inp)
+        rhx[:, c:2 * c].copy_(inp)
+        coords0 = coords_grid(N, h8, w8, dev)
+        coords1 = coords0.clone()
+        corr = torch.empty(N, self.corr_levels * (2 * self.corr_radius + 1) ** 2, h8, w8, device=dev)
+        flow_predictions = []
+        for itr in range(iters):
+            pyr.lookup(coords1, out=corr)
+            flow = coords1 - coords0
+            delta = self.update_block.step(hx, rhx, z_buf, corr, flow)
+            coords1 = coords1 + delta
+            if all_flows or itr == iters - 1:
+                lowres = coords1 - coords0
+                if upsample:
+                    flow_predictions.append(ops.upsample_convex(lowres, self.update_block.up_mask(hx[:, :c])))
+                else:
+                    flow_predictions.append(lowres)
+        return flow_predictions, hx[:, :c].contiguous(), inp
