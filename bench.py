@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--raft-iters', type=int, default=12)
     ap.add_argument('--solver', default='lbfgs', choices=['lbfgs', 'gn'])
     ap.add_argument('--solver-iters', type=int, default=8)
-    ap.add_argument('--cpu-frames', type=int, default=2, help='frames timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=4, help='frames timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -154,17 +154,30 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Host threads this process may really use: scheduler affinity capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants 16; 256 threads on 16 CPUs is ~100x slower than 16 threads)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(cfg, model, frames, n_frames, gpu_pose):
     """The CPU oracle (PyTorch-CPU port of the reference path, oracle/pose_net.py) on the first frames of the
     same batch with the same weights, all host threads.  Frames are processed one at a time, as the reference
     does (scripts/infer_trajectory.py:57 batch_size=1)."""
     from oracle import pose_net as opn
     from rpe_amd import synth
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
     om = opn.PoseNet(cfg)
     om.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})

@@ -45,7 +45,8 @@ def test_raft_matches_oracle(models):
     i1 = torch.cat((fr['image1l'], fr['image2l']))
     i2 = torch.cat((fr['image2l'], fr['image2r']))
     flows, hid, ctx = model.flow(i1.cuda(), i2.cuda(), all_flows=True)
-    oflows, ohid, octx = om.flow(i1, i2)
+    with torch.no_grad():
+        oflows, ohid, octx = om.flow(i1, i2)
     assert len(flows) == len(oflows) == 12
     d0 = float((flows[0].cpu() - oflows[0]).abs().max())
     d11 = float((flows[-1].cpu() - oflows[-1]).abs().max())
@@ -53,9 +54,11 @@ def test_raft_matches_oracle(models):
     assert d0 < 2e-3 and d11 < 2e-2
     assert float((hid.cpu() - ohid).abs().max()) < 5e-3 and float((ctx.cpu() - octx).abs().max()) < 1e-3
     last_only, _, _ = model.flow(i1.cuda(), i2.cuda())
-    assert len(last_only) == 1 and torch.equal(last_only[0], flows[-1])
+    # (MIOpen may pick different conv algorithms call to call, so repeated runs agree to round-off, not bitwise)
+    assert len(last_only) == 1 and float((last_only[0] - flows[-1]).abs().max()) < 1e-3
     low, _, _ = model.flow(i1.cuda(), i2.cuda(), upsample=False)
-    olow, _, _ = om.flow(i1, i2, upsample=False)
+    with torch.no_grad():
+        olow, _, _ = om.flow(i1, i2, upsample=False)
     assert low[-1].shape == (2, 2, H // 8, W // 8) and float((low[-1].cpu() - olow[-1]).abs().max()) < 5e-3
 
 
