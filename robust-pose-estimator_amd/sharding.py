@@ -1,0 +1,107 @@
+"""One-process-per-GPU sharding of a stereo sequence.
+
+In frame-to-frame mode the relative pose t-1 -> t depends only on the two stereo pairs
+(core/pose/pose_estimator.py:98-125); the only cross-frame state is the chained absolute pose (:91), an
+associative SE(3) product.  So a sequence of F frames is cut into contiguous blocks of relative poses, one
+block per rank, each with a one-frame halo (the predecessor of its first pair, whose stereo depth it needs).
+There is NO collective on the data path; the single exchange is one all-gather of the (frames, 7) float32
+relative poses + success flags (RCCL over xGMI with backend "nccl", gloo in the CPU tests), after which the
+failure gate (:81-87) and the prefix product (:90-91) run where the trajectory is wanted.
+
+Everything here is host logic on torch.distributed; the per-pair solve is injected, so the CPU tests can drive
+it with the oracle while the GPU path drives it with PoseEstimator / the HIP kernels.
+"""
+import torch
+import torch.distributed as dist
+
+
+def block_partition(n_items, world):
+    """Contiguous, near-equal blocks: returns [(start, end)] * world covering range(n_items)."""
+    base, rem = divmod(n_items, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def gather_relative_poses(rel_local, ok_local, sizes, group=None):
+    """all_gather of variable-length blocks: pad to the longest block, gather, strip the padding.
+    rel_local (m_r,7) float32, ok_local (m_r,) bool.  Returns (rel (sum m,7), ok (sum m,)) on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return rel_local, ok_local
+    mmax = max(sizes)
+    dev = rel_local.device
+    pad = torch.zeros(mmax, 8, dtype=torch.float32, device=dev)
+    m = rel_local.shape[0]
+    if m:
+        pad[:m, :7] = rel_local.float()
+        pad[:m, 7] = ok_local.float()
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    rel = torch.cat([b[:sz, :7] for b, sz in zip(bufs, sizes)])
+    ok = torch.cat([b[:sz, 7] > 0.5 for b, sz in zip(bufs, sizes)])
+    return rel, ok
+
+
+def failure_gate(rel, log, thr=1.0e-1):
+    """pose_estimator.py:81-87: NaN pose or any |log| > 0.1 -> failed, substitute identity."""
+    bad = torch.isnan(rel).any(dim=-1) | (log.abs() > thr).any(dim=-1)
+    ident = torch.zeros_like(rel)
+    ident[..., 6] = 1.0
+    return torch.where(bad[..., None], ident, rel), ~bad
+
+
+def track_sharded(n_frames, run_block, chain_fn, rank=0, world=1, group=None, scale=250.0):
+    """Sharded tracking of frames 0..n_frames-1.
+
+    run_block(first_pair, last_pair) -> (rel (m,7) f32, ok (m,) bool) computes the GATED relative poses of
+    pairs first_pair..last_pair-1, pair t being (frame t, frame t+1); it is responsible for the halo frame.
+    chain_fn(rel (M,7), scale) -> (M,7) absolute poses: the prefix product P_k = P_{k-1} * inv(scale(rel_k)).
+    Returns absolute poses (n_frames,7): identity for frame 0 followed by the chained poses.
+    """
+    blocks = block_partition(max(n_frames - 1, 0), world)
+    s, e = blocks[rank]
+    rel_local, ok_local = run_block(s, e)
+    rel, ok = gather_relative_poses(rel_local, ok_local, [b[1] - b[0] for b in blocks], group)
+    ident = torch.zeros(1, 7, dtype=rel.dtype, device=rel.device)
+    ident[0, 6] = 1.0
+    if rel.shape[0] == 0:
+        return ident, rel, ok
+    return torch.cat((ident, chain_fn(rel, scale))), rel, ok
+
+
+class SequenceTracker:
+    """GPU driver of track_sharded on top of PoseEstimator: every rank walks its block of frames one at a time
+    (the reference's per-frame semantics, batch 1), starting from the halo frame."""
+
+    def __init__(self, make_estimator, get_frame):
+        """make_estimator() -> a fresh PoseEstimator on this rank's GPU; get_frame(t) -> (limg, rimg, mask)."""
+        self.make_estimator, self.get_frame = make_estimator, get_frame
+
+    def run_block(self, first_pair, last_pair):
+        from . import ops
+        est = self.make_estimator()
+        rels, oks = [], []
+        if last_pair <= first_pair:
+            dev = est.device
+            return torch.zeros(0, 7, device=dev), torch.zeros(0, dtype=torch.bool, device=dev)
+        l, r, m = self.get_frame(first_pair)
+        est(l, r, m)                                   # halo / first frame: stereo depth only
+        if first_pair > 0:
+            # in the serial run this frame was the "current" frame of pair first_pair-1, whose infer() ANDed its
+            # mask with the stereo validity (pose_net.py:77); reproduce that for the halo frame
+            _, valid = ops.flow2depth(est.frame.flow, est.baseline * est.scale)
+            est.frame.mask &= valid
+        for t in range(first_pair, last_pair):
+            l, r, m = self.get_frame(t + 1)
+            est(l, r, m)
+            rels.append(est.last_rel_pose.data.reshape(1, 7).float())
+            oks.append(torch.tensor([est.success], device=rels[-1].device))
+        return torch.cat(rels), torch.cat(oks)
+
+    def track(self, n_frames, rank=0, world=1, group=None, scale=250.0):
+        from . import ops
+        return track_sharded(n_frames, self.run_block, lambda rel, s: ops.se3_chain(rel, scale=s), rank, world, group, scale)

@@ -127,3 +127,21 @@ def test_tracker_matches_oracle(models):
         print(f'frame {i}: abs pose diff {d:.2e}, success {est.success} / {oest.success[-1]}')
         assert est.success == oest.success[-1]
         assert d < 0.5                                       # translation in mm after the x250 de-normalisation
+
+
+def test_sharded_blocks_reproduce_serial_tracker(models):
+    """Two blocks with a one-frame halo (what two ranks would run) give the serial run's relative poses."""
+    model, om, synth = models
+    from rpe_amd import ops, pose_estimator, sharding
+    fr = synth.stereo_frames(8, 5, H, W)
+    K = fr['K'][0]
+    cfg = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=8, conf_weighing=True)
+    make = lambda: pose_estimator.PoseEstimator(cfg, K, 7.2 * 250.0, model, (W, H)).cuda()
+    get = lambda t: (fr['image2l'][t:t + 1].cuda(), fr['image2r'][t:t + 1].cuda(), fr['mask2'][t:t + 1].clone().cuda())
+    tr = sharding.SequenceTracker(make, get)
+    poses, rel, ok = tr.track(5)                                  # world = 1: the serial trajectory
+    r0, ok0 = tr.run_block(0, 2)
+    r1, ok1 = tr.run_block(2, 4)
+    assert torch.equal(torch.cat((ok0, ok1)), ok)
+    assert float((torch.cat((r0, r1)) - rel).abs().max()) < 1e-5
+    assert poses.shape == (5, 7) and float((poses[1:] - ops.se3_chain(rel, scale=250.0)).abs().max()) == 0.0
