@@ -247,21 +247,40 @@ __device__ __forceinline__ float bfi(unsigned m, float a, float b) {
 #define ROW_E(e) ((e) < 4 ? f0[(e) & 3] : (e) < 8 ? f1[(e) & 3] : (e) < 12 ? f2[(e) & 3] : f3[(e) & 3])
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
-                                                     float* __restrict__ out, PyrGeom G) {
+// LDS staging geometry: per wave, 64 queries x (4 footprint rows x 64 B) with the query stride padded to 272 B
+// so that ds_read_b128 by lane = query is bank-conflict free (4*lane mod 64 distinct within each 16-lane group).
+#define LK_WAVES 4
+#define LK_QSTRIDE 68                          // floats per query slot: 4 rows x 16 floats + 4 pad
+#define LK_WAVE_FLOATS (64 * LK_QSTRIDE)
+#define LK_PASSES 3                            // footprint rows 0-3, 4-7, 8-10
+
+// One workgroup = 4 waves = 256 consecutive queries of one (batch item, level).
+// Loader role (per pass, 16 instructions): instruction i serves queries 4i..4i+3 of the wave; lane L fetches the
+//   16-B piece (row (L>>2)&3, micro-tile L&3) of query 4i + (L>>4): 16 lanes cover one query's 4 rows x 64 B, the
+//   four pieces of a row sit in four neighbouring micro-tiles = one or two 128-B lines, and every line of the
+//   footprint is requested exactly once per wave (the first version re-fetched each line ~3x: 13.9 M line requests
+//   per launch at batch 32 against ~5 M distinct lines -- profiles/r01_lookup_pmc.txt).
+// Consumer role: lane = query; reads its rows back from LDS, aligns them in registers and emits the 81 taps with
+//   coalesced stores (64 consecutive queries per channel).
+__global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                             float* __restrict__ out, PyrGeom G) {
+    __shared__ __attribute__((aligned(16))) float stage[LK_WAVES * LK_WAVE_FLOATS];
     const int l = blockIdx.y, bz = blockIdx.z;
     const int nq = G.h8 * G.w8;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
+    const bool qok = q < nq;
+    const int qc = qok ? q : nq - 1;
     const int hl = G.h[l], wl = G.w[l], txc = G.txc[l];
     const float inv = 1.0f / (float)(1 << l);
-    const float cx = coords[((size_t)bz * 2 + 0) * nq + q] * inv;        // coords / 2**i  (exact)
-    const float cy = coords[((size_t)bz * 2 + 1) * nq + q] * inv;
+    const float cx = coords[((size_t)bz * 2 + 0) * nq + qc] * inv;       // coords / 2**i  (exact)
+    const float cy = coords[((size_t)bz * 2 + 1) * nq + qc] * inv;
     TapAxis X, Y;
     make_taps(cx, wl, X);
     make_taps(cy, hl, Y);
-    const float* map = pyr + G.base[l] + ((size_t)bz * nq + q) * G.S[l];
-    float* o = out + ((size_t)bz * G.levels * WIN * WIN + (size_t)l * WIN * WIN) * nq + q;
+    const size_t S = (size_t)G.S[l];
+    const float* lvl = pyr + G.base[l] + (size_t)bz * nq * S;
+    float* o = out + ((size_t)bz * G.levels * WIN * WIN + (size_t)l * WIN * WIN) * nq + qc;
 
     const int xb = (X.lo >> 2) << 2;          // aligned start column of the 16-wide register row
     const int s = X.lo - xb;                  // 0..3
@@ -269,43 +288,75 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ p
     // lane masks for the two register-shift stages; blended with v_bfi (kept as bit ops on purpose: written
     // as selects the optimiser turns the shift into a dynamically indexed private array)
     const unsigned m1 = 0u - (unsigned)(s & 1), m2 = 0u - (unsigned)((s >> 1) & 1);
+    // what the loader lanes need to know about a query: first row, first micro-tile column, whether the
+    // fourth micro-tile is used (columns s..s+10 reach it only for s >= 2)
+    // (packed into one word -> one ds_bpermute per loader instruction; far-outside values are clamped, they only
+    // have to stay outside the map)
+    const int cl_ylo = Y.lo < -30000 ? -30000 : (Y.lo > 30000 ? 30000 : Y.lo);
+    const int cl_tx0 = tx0 < -8000 ? -8000 : (tx0 > 8000 ? 8000 : tx0);
+    const int my_packed = ((cl_ylo + 32768) << 16) | ((cl_tx0 + 16384) << 1) | ((s >= 2) ? 1 : 0);
+
+    float* wstage = stage + wv * LK_WAVE_FLOATS;
+    const int ld_row = (lane >> 2) & 3, ld_piece = lane & 3, ld_sub = lane >> 4;      // loader role of this lane
+    const int q_wave0 = blockIdx.x * blockDim.x + wv * 64;                           // first query of this wave
 
     float hm2[WIN], hm1[WIN], hc[WIN];        // horizontally interpolated rows r-2, r-1, r
 #pragma unroll
     for (int i = 0; i < WIN; ++i) { hm2[i] = 0.0f; hm1[i] = 0.0f; }
+
 #pragma unroll
-    for (int r = 0; r < WIN + 2; ++r) {
-        // ---- footprint row r: four aligned 16-B loads, zero outside the (zero-padded) map
-        const int yy = Y.lo + r;
-        const bool row_ok = yy >= 0 && yy < hl;
-        const int yc = row_ok ? yy : 0;
-        const float* rowp = map + ((size_t)(yc >> 2) * txc << 4) + ((yc & 3) << 2);
-        const bool ok0 = row_ok && tx0 >= 0 && tx0 < txc, ok1 = row_ok && tx0 + 1 >= 0 && tx0 + 1 < txc;
-        const bool ok2 = row_ok && tx0 + 2 >= 0 && tx0 + 2 < txc, ok3 = row_ok && tx0 + 3 >= 0 && tx0 + 3 < txc;
-        f32x4 f0 = *(const f32x4*)(rowp + ((size_t)(ok0 ? tx0 : 0) << 4));
-        f32x4 f1 = *(const f32x4*)(rowp + ((size_t)(ok1 ? tx0 + 1 : 0) << 4));
-        f32x4 f2 = *(const f32x4*)(rowp + ((size_t)(ok2 ? tx0 + 2 : 0) << 4));
-        f32x4 f3 = *(const f32x4*)(rowp + ((size_t)(ok3 ? tx0 + 3 : 0) << 4));
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        f0 = ok0 ? f0 : zero; f1 = ok1 ? f1 : zero; f2 = ok2 ? f2 : zero; f3 = ok3 ? f3 : zero;
-        // ---- align in registers: A[k] = row[k + s], two select stages (s&1, s&2)
-        float Bt[13], A[11];
+    for (int pass = 0; pass < LK_PASSES; ++pass) {
+        // ---- loader: 16 coalesced 16-B loads per lane-group of 16
+        f32x4 v[16];
 #pragma unroll
-        for (int k = 0; k < 13; ++k) { const float u = ROW_E(k), v = ROW_E(k + 1); Bt[k] = bfi(m1, v, u); }
-#pragma unroll
-        for (int k = 0; k < 11; ++k) A[k] = bfi(m2, Bt[k + 2], Bt[k]);
-        // ---- horizontal interpolation of this row for the 9 x-taps
-#pragma unroll
-        for (int i = 0; i < WIN; ++i) hc[i] = A[i] * X.a0[i] + A[i + 1] * X.a1[i] + A[i + 2] * X.a2[i];
-        // ---- rows (r-2, r-1, r) finish window row j = r-2
-        if (r >= 2) {
-            const int j = r - 2;
-#pragma unroll
-            for (int i = 0; i < WIN; ++i)                               // channel i*9+j: x offset i-r, y offset j-r
-                o[(size_t)(i * WIN + j) * nq] = hm2[i] * Y.a0[j] + hm1[i] * Y.a1[j] + hc[i] * Y.a2[j];
+        for (int i = 0; i < 16; ++i) {
+            const int src = 4 * i + ld_sub;                                          // query (within the wave) served
+            const int pk = __shfl(my_packed, src, 64);
+            const int ylo_s = (int)((unsigned)pk >> 16) - 32768, tx0_s = ((pk >> 1) & 0x7fff) - 16384, need4_s = pk & 1;
+            const int qs = q_wave0 + src;
+            const int yy = ylo_s + 4 * pass + ld_row;
+            const int tx = tx0_s + ld_piece;
+            const bool ok = qs < nq && (4 * pass + ld_row) < WIN + 2 && yy >= 0 && yy < hl && tx >= 0 && tx < txc &&
+                            (ld_piece < 3 || need4_s);
+            const float* p = lvl + (size_t)(ok ? qs : 0) * S + (ok ? ((((yy >> 2) * txc + tx) << 4) + ((yy & 3) << 2)) : 0);
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            v[i] = *(const f32x4*)p;
+            v[i] = ok ? v[i] : zero;
         }
+        __syncthreads();                                                             // previous pass fully consumed
 #pragma unroll
-        for (int i = 0; i < WIN; ++i) { hm2[i] = hm1[i]; hm1[i] = hc[i]; }
+        for (int i = 0; i < 16; ++i)
+            *(f32x4*)(wstage + (4 * i + ld_sub) * LK_QSTRIDE + ld_row * 16 + ld_piece * 4) = v[i];
+        __syncthreads();
+        // ---- consumer: lane = query
+        const float* mine = wstage + lane * LK_QSTRIDE;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * pass + rr;
+            if (r >= WIN + 2) break;
+            const f32x4 f0 = *(const f32x4*)(mine + rr * 16 + 0), f1 = *(const f32x4*)(mine + rr * 16 + 4);
+            const f32x4 f2 = *(const f32x4*)(mine + rr * 16 + 8), f3 = *(const f32x4*)(mine + rr * 16 + 12);
+            // align in registers: A[k] = row[k + s], two blend stages (s&1, s&2)
+            float Bt[13], A[11];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) { const float u = ROW_E(k), w = ROW_E(k + 1); Bt[k] = bfi(m1, w, u); }
+#pragma unroll
+            for (int k = 0; k < 11; ++k) A[k] = bfi(m2, Bt[k + 2], Bt[k]);
+            // horizontal interpolation of this row for the 9 x-taps
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) hc[i] = A[i] * X.a0[i] + A[i + 1] * X.a1[i] + A[i + 2] * X.a2[i];
+            // rows (r-2, r-1, r) finish window row j = r-2
+            if (r >= 2) {
+                const int j = r - 2;
+                if (qok) {
+#pragma unroll
+                    for (int i = 0; i < WIN; ++i)                       // channel i*9+j: x offset i-r, y offset j-r
+                        o[(size_t)(i * WIN + j) * nq] = hm2[i] * Y.a0[j] + hm1[i] * Y.a1[j] + hc[i] * Y.a2[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) { hm2[i] = hm1[i]; hm1[i] = hc[i]; }
+        }
     }
 }
 
