@@ -294,7 +294,11 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
     // have to stay outside the map)
     const int cl_ylo = Y.lo < -30000 ? -30000 : (Y.lo > 30000 ? 30000 : Y.lo);
     const int cl_tx0 = tx0 < -8000 ? -8000 : (tx0 > 8000 ? 8000 : tx0);
-    const int my_packed = ((cl_ylo + 32768) << 16) | ((cl_tx0 + 16384) << 1) | ((s >= 2) ? 1 : 0);
+    // the 4th micro-tile is touched only if columns s..s+9 (+1 when some x-tap deviates) reach it; the 11th row
+    // only if some y-tap deviates
+    const int need4 = (s + 9 + (X.dev ? 1 : 0)) >= 12 ? 1 : 0;
+    const int need_r10 = Y.dev ? 1 : 0;
+    const int my_packed = ((cl_ylo + 32768) << 16) | ((cl_tx0 + 8192) << 2) | (need_r10 << 1) | need4;
 
     float* wstage = stage + wv * LK_WAVE_FLOATS;
     const int ld_row = (lane >> 2) & 3, ld_piece = lane & 3, ld_sub = lane >> 4;      // loader role of this lane
@@ -312,11 +316,12 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
         for (int i = 0; i < 16; ++i) {
             const int src = 4 * i + ld_sub;                                          // query (within the wave) served
             const int pk = __shfl(my_packed, src, 64);
-            const int ylo_s = (int)((unsigned)pk >> 16) - 32768, tx0_s = ((pk >> 1) & 0x7fff) - 16384, need4_s = pk & 1;
+            const int ylo_s = (int)((unsigned)pk >> 16) - 32768, tx0_s = ((pk >> 2) & 0x3fff) - 8192, need4_s = pk & 1;
+            const int last_row = (pk & 2) ? WIN + 1 : WIN;                           // highest footprint row index needed
             const int qs = q_wave0 + src;
             const int yy = ylo_s + 4 * pass + ld_row;
             const int tx = tx0_s + ld_piece;
-            const bool ok = qs < nq && (4 * pass + ld_row) < WIN + 2 && yy >= 0 && yy < hl && tx >= 0 && tx < txc &&
+            const bool ok = qs < nq && (4 * pass + ld_row) <= last_row && yy >= 0 && yy < hl && tx >= 0 && tx < txc &&
                             (ld_piece < 3 || need4_s);
             const float* p = lvl + (size_t)(ok ? qs : 0) * S + (ok ? ((((yy >> 2) * txc + tx) << 4) + ((yy & 3) << 2)) : 0);
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};

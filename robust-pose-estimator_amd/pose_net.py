@@ -50,9 +50,15 @@ class PoseNet(nn.Module):
     @torch.no_grad()
     def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1):
         n = image1l.shape[0]
+        intrinsics = intrinsics.expand(n, 3, 3).contiguous()
+        baseline = baseline.expand(n).contiguous()
         ref_imgs = torch.cat((image1l, image2l), dim=0)
         trg_imgs = torch.cat((image2l, image2r), dim=0)
-        flow_predictions, hidden, context = self.flow(ref_imgs, trg_imgs, upsample=True)
+        # image2l sits in both halves of the reference's batch-2 RAFT call (pose_net.py:63-64); the feature
+        # encoder uses per-sample instance norm, so it is encoded once and reused (3n encoder passes, not 4n)
+        f = self.flow.encode_features(torch.cat((image1l, image2l, image2r), dim=0))
+        fmaps = (f[:2 * n], torch.cat((f[n:2 * n], f[2 * n:]), dim=0))
+        flow_predictions, hidden, context = self.flow(ref_imgs, trg_imgs, upsample=True, fmaps=fmaps)
         time_flow = flow_predictions[-1][:n].contiguous()
         stereo_flow2 = flow_predictions[-1][n:].contiguous()
         hidden, context = hidden[:n], context[:n]
@@ -64,7 +70,8 @@ class PoseNet(nn.Module):
         else:
             w2d = torch.ones_like(g['depth2'])
             w3d = torch.ones_like(g['depth2'])
-        g.update(time_flow=time_flow, stereo_flow2=stereo_flow2, hidden=hidden, context=context, w2d=w2d, w3d=w3d)
+        g.update(time_flow=time_flow, stereo_flow2=stereo_flow2, hidden=hidden, context=context, w2d=w2d, w3d=w3d,
+                 intrinsics=intrinsics)
         return g
 
     @torch.no_grad()
@@ -75,7 +82,7 @@ class PoseNet(nn.Module):
         n = image1l.shape[0]
         lw = self.loss_weight.detach()[None, :].repeat(n, 1)
         vec7, _ = self.pose_head(s['time_flow'], s['pcl1'], s['pcl2w'], s['w2d'], s['w3d'], mask1.bool(), s['mask2w'],
-                                 intrinsics, lw)
+                                 s['intrinsics'], lw)
         pose = SE3(vec7[:, 0]) if n > 1 else SE3(vec7)[0]     # reference returns SE3(pose_se3)[0] for its n == 1
         if ret_details:
             return pose, depth1, s['depth2'], (s['w2d'], s['w3d']), s['time_flow'], s['stereo_flow2']

@@ -211,6 +211,11 @@ class RAFT(nn.Module):
         return self._pyr
 
     @torch.no_grad()
+    def encode_features(self, images):
+        """fnet on raw 0..255 images (normalised like forward does)."""
+        return self.fnet(2 * (images / 255.0) - 1.0).float()
+
+    @torch.no_grad()
     def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None):
         """image1, image2: (N,3,H,W) in 0..255.  Inference only (the reference freezes RAFT, train.yaml:51)."""
         iters = self.iters if iters is None else iters
@@ -218,12 +223,12 @@ class RAFT(nn.Module):
         h8, w8 = H // 8, W // 8
         dev = image1.device
         image1 = 2 * (image1 / 255.0) - 1.0
-        image2 = 2 * (image2 / 255.0) - 1.0
         if fmaps is None:
+            image2 = 2 * (image2 / 255.0) - 1.0
             f = self.fnet(torch.cat((image1, image2), dim=0))
             fmap1, fmap2 = f[:N], f[N:]
         else:
-            fmap1, fmap2 = fmaps
+            fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
         pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float())
         cnet = self.cnet(image1)
         c = self.hidden_dim
