@@ -129,6 +129,13 @@ def main():
         lk_avg_s = sum(lk_ms) / max(1, len(lk_ms)) / 1e3
         alg = lookup_algorithmic_bytes(2 * B, H // 8, W // 8)
         achieved = alg / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
+        traffic = None                              # HBM bytes per launch from separate rocprofv3 --pmc passes
+        try:                                        # (profiles/pmc_traffic.json), valid for the default workload only
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['k_corr_lookup']
+            if (B, H, W) == (16, 512, 640):
+                traffic = pmc['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             'metric': 'stereo-pair pose solves/sec (640x512, 8 solver iters)',
             'value': world * B * args.steps / elapsed,
@@ -143,7 +150,7 @@ def main():
                        'frames_per_gpu': B, 'height': H, 'width': W, 'raft_iters': args.raft_iters,
                        'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
             'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': alg,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
                          'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
             'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
             'valid_fraction': float(gpu_in['mask2'].float().mean()),

@@ -149,7 +149,7 @@ __device__ __forceinline__ void pixel_terms(double* acc, double px, double py, d
 }
 
 template <bool HESS, int VEC>
-__global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 4) void k_pose_reduce(PoseArgs A, const RowUniform* __restrict__ uni,
+__global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseArgs A, const RowUniform* __restrict__ uni,
                                                              const RowState* __restrict__ states,
                                                              double* __restrict__ partials) {
     constexpr int NACC = HESS ? 29 : 8;
