@@ -236,6 +236,37 @@ def main():
     gen_warp(R)
     gen_geometry(R)
     gen_metrics(R)
+    gen_tartanair(R)
+
+
+def gen_tartanair(R):
+    """Realistic known-answer input from the reference's own (orphan) fixture tests/test_data/tartan_air/*:
+    GT optical flow + GT depths of frames 0/1 + GT camera poses (pose_left.txt rows 0-1).  A 192x256 crop is
+    stored (flow, depth0, the flow-warped cloud of frame 1 computed by the reference's remap_from_flow on the
+    full frame, occlusion mask) with the GT relative pose.  Assumptions (not stated in the reference repo, verified
+    here by the 3-D consistency |R p + t - q| median 4e-4 at depth ~2): TartanAir intrinsics fx=fy=320, cx=320,
+    cy=240; pose_left is camera-to-world in NED (x fwd, y right, z down)."""
+    from oracle import se3, warp
+    fu = R['fu']
+    d = os.path.join(REF, 'tests', 'test_data', 'tartan_air')
+    flow = torch.from_numpy(np.load(os.path.join(d, '000000_000001_flow.npy'))).permute(2, 0, 1)[None].float()
+    occ = torch.from_numpy(np.load(os.path.join(d, '000000_000001_mask.npy')))[None, None]
+    d0 = torch.from_numpy(np.load(os.path.join(d, '000000_left_depth.npy')))[None, None].float()
+    d1 = torch.from_numpy(np.load(os.path.join(d, '000001_left_depth.npy')))[None, None].float()
+    poses = np.loadtxt(os.path.join(d, 'pose_left.txt'))[:2]
+    K = torch.tensor([[320.0, 0, 320], [0, 320.0, 240], [0, 0, 1]])
+    M = torch.tensor([[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 0, 1.0]], dtype=torch.float64)
+    Tw = [M @ se3.se3_matrix(torch.tensor(p, dtype=torch.float64)[None])[0] @ torch.linalg.inv(M) for p in poses]
+    rel = torch.linalg.inv(Tw[1]) @ Tw[0]                       # cam-0 coordinates -> cam-1 coordinates
+    pcl2 = warp.backproject(d1, K[None])
+    pcl2w, _ = fu.remap_from_flow(pcl2, flow)                   # the reference's own warp, on the full frame
+    y0, x0, h, w = 144, 192, 192, 256
+    sl = (slice(None), slice(None), slice(y0, y0 + h), slice(x0, x0 + w))
+    Kc = K.clone()
+    Kc[0, 2] -= x0
+    Kc[1, 2] -= y0
+    save('tartanair_crop.npz', flow=flow[sl], depth0=d0[sl], pcl2w=pcl2w[sl], valid=(occ[sl] == 0), K=Kc[None],
+         rel_matrix=rel)
 
 
 if __name__ == '__main__':

@@ -182,3 +182,18 @@ def test_chain_matches_tracker_recurrence(rpe):
     rel = se3.se3_exp(torch.randn(300, 6, dtype=torch.float64) * 0.01)
     out = ops.se3_chain(rel.cuda(), scale=250.0).cpu()
     assert torch.allclose(out, tracker.chain(rel, 250.0), atol=1e-9)
+
+
+def test_tartanair_ground_truth_pose_recovered_on_hip(rpe):
+    """Real data with ground truth (the reference's TartanAir fixture): HIP solve == oracle solve, both == GT pose."""
+    from rpe_amd import ops
+    from oracle import warp
+    g = load_golden('tartanair_crop.npz')
+    pcl1 = warp.backproject(g['depth0'], g['K'])
+    ones = torch.ones_like(g['depth0'])
+    args = (g['flow'], pcl1, g['pcl2w'], ones, ones, g['valid'], torch.ones_like(g['valid']), g['K'], torch.ones(1, 2))
+    for mode, solve in ((ops.SOLVER_LBFGS, pose_head.lbfgs_solve), (ops.SOLVER_GN, pose_head.gn_solve)):
+        T, _, _, info = ops.pose_solve(*dev(args), iters=20, mode=mode)
+        To, _ = solve(*args, iters=20)
+        assert float((T.cpu() - To).abs().max()) < 1e-8
+        assert float((se3.se3_matrix(T.cpu())[0] - g['rel_matrix']).abs().max()) < 2e-3

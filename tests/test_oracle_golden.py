@@ -130,3 +130,14 @@ def test_se3_reference_tolerances():
     assert torch.allclose(se3.se3_log(se3.se3_exp(xi)), xi, atol=1e-10)
     tiny = torch.randn(50, 6, dtype=torch.float64) * 1e-5                # Taylor branches
     assert torch.allclose(se3.se3_log(se3.se3_exp(tiny)), tiny, atol=1e-14)
+
+
+def test_tartanair_ground_truth_pose_recovered():
+    """The reference's own TartanAir fixture (GT flow + depth + camera poses): the solve recovers the GT
+    relative pose (tests/golden/tartanair_crop.npz, produced by oracle/gen_golden.py:gen_tartanair)."""
+    g = load_golden('tartanair_crop.npz')
+    pcl1 = warp.backproject(g['depth0'], g['K'])
+    ones = torch.ones_like(g['depth0'])
+    T, info = pose_head.lbfgs_solve(g['flow'], pcl1, g['pcl2w'], ones, ones, g['valid'], torch.ones_like(g['valid']),
+                                    g['K'], torch.ones(1, 2), iters=20)
+    assert float((se3.se3_matrix(T)[0] - g['rel_matrix']).abs().max()) < 2e-3
