@@ -115,3 +115,18 @@ def test_convex_upsample(rpe):
     mask = torch.randn(b, 576, h8, w8) * 2
     out = ops.upsample_convex(flow.cuda(), mask.cuda()).cpu()
     assert torch.allclose(out, oraft.upsample_flow(flow, mask), atol=2e-5)
+
+
+def test_high_resolution_geometry_1280x1024(rpe):
+    """BASELINE config 5 geometry (1/8 grid 128x160, 20 480 queries): pyramid + lookup vs the oracle."""
+    from rpe_amd import ops
+    b, h8, w8 = 1, 128, 160
+    f1, f2 = fmaps(99, b, h8, w8)
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda())
+    ref = oraft.CorrBlock(f1, f2, num_levels=4, radius=4)
+    scale = float(ref.corr_pyramid[0].abs().max())
+    coords = coords_for(13, b, h8, w8, 4.0)
+    out = pyr.lookup(coords.cuda()).cpu()
+    assert float((out - ref(coords)).abs().max()) <= 4e-5 * scale
+    l3 = pyr.export_level(3).cpu()
+    assert float((l3 - ref.corr_pyramid[3][:, 0]).abs().max()) <= 2e-5 * scale

@@ -145,3 +145,22 @@ def test_sharded_blocks_reproduce_serial_tracker(models):
     assert torch.equal(torch.cat((ok0, ok1)), ok)
     assert float((torch.cat((r0, r1)) - rel).abs().max()) < 1e-5
     assert poses.shape == (5, 7) and float((poses[1:] - ops.se3_chain(rel, scale=250.0)).abs().max()) == 0.0
+
+
+def test_small_frames_without_weight_heads(rpe):
+    """BASELINE config 0 geometry (320x256, 3 solver iterations).  The TinyUNet heads need a 1/8 grid of at least
+    44x44 (valid convolutions), so this size only runs with conf_weighing off (configuration/infer_f2f_nw.yaml:9)."""
+    from rpe_amd import pose_net, synth
+    h, w = 256, 320
+    cfg = synth.model_config(h, w, iters=12, lbgfs_iters=3, use_weights=False)
+    model = synth.init_synthetic_weights(pose_net.PoseNet(cfg)).eval().cuda()
+    om = opn.PoseNet(cfg)
+    om.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    om.eval()
+    a = synth.infer_args(synth.stereo_frames(11, 2, h, w))
+    pose = model.infer(**{k: v.cuda() for k, v in a.items()})
+    opose = om.infer(**{k: v.clone() for k, v in a.items()})
+    assert pose.data.shape == (2, 7)
+    assert float((pose.data.cpu() - opose).abs().max()) < 1e-4
+    info = model.pose_head.problem.last_info.cpu()
+    assert info[:, 0].tolist() == [2, 2] and info[:, 2].tolist() == [4, 4]      # max_iter 3 -> max_eval 3 -> 2 iterations
