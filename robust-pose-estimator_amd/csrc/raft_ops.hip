@@ -11,11 +11,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // zr_pre (b,2c,hw) ; h (b, h_ch, hw) channels [0,c) ; z_out (b,c,hw) ; rh_out (b, rh_ch, hw) channels [0,c)
 template <int VEC>
-__global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, const float* __restrict__ h, int c, int hw,
+__global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, const float* __restrict__ bias,
+                                                  const float* __restrict__ h, int c, int hw,
                                                   int h_ch, float* __restrict__ z_out, float* __restrict__ rh, int rh_ch) {
     const int bz = blockIdx.y;
     const size_t per = (size_t)c * hw;
     for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        const int ch = (int)(e / hw);                       // hw % VEC == 0: all VEC elements share the channel
+        const float bzv = bias ? bias[ch] : 0.0f, brv = bias ? bias[c + ch] : 0.0f;
         const float* zp = zr + (size_t)bz * 2 * per + e;
         const float* rp = zp + per;
         const float* hp = h + (size_t)bz * h_ch * hw + e;
@@ -23,22 +26,25 @@ __global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, 
         float* ro = rh + (size_t)bz * rh_ch * hw + e;
         if (VEC == 4) {
             float4 zv = *(const float4*)zp, rv = *(const float4*)rp, hv = *(const float4*)hp;
-            float4 zz = make_float4(sigmoidf_(zv.x), sigmoidf_(zv.y), sigmoidf_(zv.z), sigmoidf_(zv.w));
-            float4 rr = make_float4(sigmoidf_(rv.x) * hv.x, sigmoidf_(rv.y) * hv.y, sigmoidf_(rv.z) * hv.z, sigmoidf_(rv.w) * hv.w);
+            float4 zz = make_float4(sigmoidf_(zv.x + bzv), sigmoidf_(zv.y + bzv), sigmoidf_(zv.z + bzv), sigmoidf_(zv.w + bzv));
+            float4 rr = make_float4(sigmoidf_(rv.x + brv) * hv.x, sigmoidf_(rv.y + brv) * hv.y, sigmoidf_(rv.z + brv) * hv.z,
+                                    sigmoidf_(rv.w + brv) * hv.w);
             *(float4*)zo = zz; *(float4*)ro = rr;
         } else {
-            zo[0] = sigmoidf_(zp[0]); ro[0] = sigmoidf_(rp[0]) * hp[0];
+            zo[0] = sigmoidf_(zp[0] + bzv); ro[0] = sigmoidf_(rp[0] + brv) * hp[0];
         }
     }
 }
 
 // h_out = (1 - z) * h + z * tanh(q_pre)
 template <int VEC>
-__global__ __launch_bounds__(256) void k_gates_h(const float* __restrict__ z, const float* __restrict__ q, const float* h, int c,
+__global__ __launch_bounds__(256) void k_gates_h(const float* __restrict__ z, const float* __restrict__ q,
+                                                 const float* __restrict__ bias, const float* h, int c,
                                                  int hw, int h_ch, float* h_out, int ho_ch) {
     const int bz = blockIdx.y;
     const size_t per = (size_t)c * hw;
     for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        const float bq = bias ? bias[(int)(e / hw)] : 0.0f;
         const float* zp = z + (size_t)bz * per + e;
         const float* qp = q + (size_t)bz * per + e;
         const float* hp = h + (size_t)bz * h_ch * hw + e;
@@ -46,11 +52,34 @@ __global__ __launch_bounds__(256) void k_gates_h(const float* __restrict__ z, co
         if (VEC == 4) {
             float4 zv = *(const float4*)zp, qv = *(const float4*)qp, hv = *(const float4*)hp;
             float4 o;
-            o.x = (1.0f - zv.x) * hv.x + zv.x * tanhf(qv.x); o.y = (1.0f - zv.y) * hv.y + zv.y * tanhf(qv.y);
-            o.z = (1.0f - zv.z) * hv.z + zv.z * tanhf(qv.z); o.w = (1.0f - zv.w) * hv.w + zv.w * tanhf(qv.w);
+            o.x = (1.0f - zv.x) * hv.x + zv.x * tanhf(qv.x + bq); o.y = (1.0f - zv.y) * hv.y + zv.y * tanhf(qv.y + bq);
+            o.z = (1.0f - zv.z) * hv.z + zv.z * tanhf(qv.z + bq); o.w = (1.0f - zv.w) * hv.w + zv.w * tanhf(qv.w + bq);
             *(float4*)ho = o;
         } else {
-            ho[0] = (1.0f - zp[0]) * hp[0] + zp[0] * tanhf(qp[0]);
+            ho[0] = (1.0f - zp[0]) * hp[0] + zp[0] * tanhf(qp[0] + bq);
+        }
+    }
+}
+
+// y = act(x + bias[c]) written into channels [off, off+c) of one or two (b, C_total, hw) buffers: the conv
+// library's separate bias-add and ReLU passes and the torch.cat / copy_ that follow them, in one pass.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bias_act(const float* x, const float* __restrict__ bias, int c, int hw, int relu,
+                                                  float* o1, int o1_ch, int o1_off, float* o2, int o2_ch, int o2_off) {
+    const int bz = blockIdx.y;
+    const size_t per = (size_t)c * hw;
+    for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        const float bv = bias ? bias[(int)(e / hw)] : 0.0f;
+        const float* xp = x + (size_t)bz * per + e;
+        float v[VEC];
+        if (VEC == 4) *(float4*)v = *(const float4*)xp; else v[0] = xp[0];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { v[k] += bv; if (relu) v[k] = v[k] < 0.0f ? 0.0f : v[k]; }   // (NaN stays NaN, like torch.relu) 
+        float* p1 = o1 + ((size_t)bz * o1_ch + o1_off) * hw + e;
+        if (VEC == 4) *(float4*)p1 = *(float4*)v; else p1[0] = v[0];
+        if (o2) {
+            float* p2 = o2 + ((size_t)bz * o2_ch + o2_off) * hw + e;
+            if (VEC == 4) *(float4*)p2 = *(float4*)v; else p2[0] = v[0];
         }
     }
 }
@@ -95,25 +124,37 @@ __global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict
 
 static bool vec_ok(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
-extern "C" int rpe_gru_gates_zr(const float* zr_pre, const float* h, int h_channels, int b, int c, int hw, float* z_out,
-                                float* rh_out, int rh_channels, void* stream) {
+extern "C" int rpe_bias_act(const float* x, const float* bias, int b, int c, int hw, int relu, float* out1, int out1_channels,
+                            int out1_offset, float* out2, int out2_channels, int out2_offset, void* stream) {
+    if (!x || !out1 || b <= 0 || c <= 0 || hw <= 0 || out1_offset < 0 || out1_offset + c > out1_channels) return RPE_E_BADARG;
+    if (out2 && (out2_offset < 0 || out2_offset + c > out2_channels)) return RPE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t per = (size_t)c * hw;
+    bool v4 = hw % 4 == 0 && vec_ok(x) && vec_ok(out1) && (!out2 || vec_ok(out2));
+    if (v4) hipLaunchKernelGGL(k_bias_act<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, x, bias, c, hw, relu, out1, out1_channels, out1_offset, out2, out2_channels, out2_offset);
+    else hipLaunchKernelGGL(k_bias_act<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, x, bias, c, hw, relu, out1, out1_channels, out1_offset, out2, out2_channels, out2_offset);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_gru_gates_zr(const float* zr_pre, const float* zr_bias, const float* h, int h_channels, int b, int c, int hw,
+                                float* z_out, float* rh_out, int rh_channels, void* stream) {
     if (!zr_pre || !h || !z_out || !rh_out || b <= 0 || c <= 0 || hw <= 0 || h_channels < c || rh_channels < c) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     size_t per = (size_t)c * hw;
     bool v4 = hw % 4 == 0 && vec_ok(zr_pre) && vec_ok(h) && vec_ok(z_out) && vec_ok(rh_out);
-    if (v4) hipLaunchKernelGGL(k_gates_zr<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, zr_pre, h, c, hw, h_channels, z_out, rh_out, rh_channels);
-    else hipLaunchKernelGGL(k_gates_zr<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, zr_pre, h, c, hw, h_channels, z_out, rh_out, rh_channels);
+    if (v4) hipLaunchKernelGGL(k_gates_zr<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, zr_pre, zr_bias, h, c, hw, h_channels, z_out, rh_out, rh_channels);
+    else hipLaunchKernelGGL(k_gates_zr<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, zr_pre, zr_bias, h, c, hw, h_channels, z_out, rh_out, rh_channels);
     return rpe_check_launch();
 }
 
-extern "C" int rpe_gru_gates_h(const float* z, const float* q_pre, const float* h, int h_channels, int b, int c, int hw,
-                               float* h_out, int hout_channels, void* stream) {
+extern "C" int rpe_gru_gates_h(const float* z, const float* q_pre, const float* q_bias, const float* h, int h_channels, int b,
+                               int c, int hw, float* h_out, int hout_channels, void* stream) {
     if (!z || !q_pre || !h || !h_out || b <= 0 || c <= 0 || hw <= 0 || h_channels < c || hout_channels < c) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     size_t per = (size_t)c * hw;
     bool v4 = hw % 4 == 0 && vec_ok(z) && vec_ok(q_pre) && vec_ok(h) && vec_ok(h_out);
-    if (v4) hipLaunchKernelGGL(k_gates_h<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, z, q_pre, h, c, hw, h_channels, h_out, hout_channels);
-    else hipLaunchKernelGGL(k_gates_h<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, z, q_pre, h, c, hw, h_channels, h_out, hout_channels);
+    if (v4) hipLaunchKernelGGL(k_gates_h<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, z, q_pre, q_bias, h, c, hw, h_channels, h_out, hout_channels);
+    else hipLaunchKernelGGL(k_gates_h<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, z, q_pre, q_bias, h, c, hw, h_channels, h_out, hout_channels);
     return rpe_check_launch();
 }
 

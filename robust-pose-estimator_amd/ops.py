@@ -220,19 +220,39 @@ class CorrPyramid:
 
 
 # ------------------------------------------------------------------------------------------------- RAFT update
-def gru_gates_zr(zr_pre, h_buf, c, z_out, rh_buf):
-    """z_out = sigmoid(zr_pre[:, :c]); rh_buf[:, :c] = sigmoid(zr_pre[:, c:]) * h_buf[:, :c]."""
+def _nchw(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _lib.RpeError(f'{name}: expected a contiguous float32 NCHW tensor on the GPU')
+    return t
+
+
+def gru_gates_zr(zr_pre, h_buf, c, z_out, rh_buf, bias=None):
+    """z_out = sigmoid(zr_pre[:, :c] + bias[:c]); rh_buf[:, :c] = sigmoid(zr_pre[:, c:] + bias[c:]) * h_buf[:, :c]."""
+    _nchw(zr_pre, 'zr_pre'); _nchw(h_buf, 'h_buf'); _nchw(z_out, 'z_out'); _nchw(rh_buf, 'rh_buf')
     b, c2, hh, ww = zr_pre.shape
-    hw = hh * ww
-    check(lib().rpe_gru_gates_zr(ptr(zr_pre), ptr(h_buf), h_buf.shape[1], b, c, hw, ptr(z_out), ptr(rh_buf),
+    check(lib().rpe_gru_gates_zr(ptr(zr_pre), ptr(bias), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(z_out), ptr(rh_buf),
                                  rh_buf.shape[1], stream_ptr()), 'rpe_gru_gates_zr')
 
 
-def gru_gates_h(z, q_pre, h_buf, c, h_out):
-    """h_out[:, :c] = (1 - z) * h_buf[:, :c] + z * tanh(q_pre)."""
+def gru_gates_h(z, q_pre, h_buf, c, h_out, bias=None):
+    """h_out[:, :c] = (1 - z) * h_buf[:, :c] + z * tanh(q_pre + bias)."""
+    _nchw(z, 'z'); _nchw(q_pre, 'q_pre'); _nchw(h_buf, 'h_buf'); _nchw(h_out, 'h_out')
     b, _, hh, ww = q_pre.shape
-    check(lib().rpe_gru_gates_h(ptr(z), ptr(q_pre), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(h_out), h_out.shape[1],
-                                stream_ptr()), 'rpe_gru_gates_h')
+    check(lib().rpe_gru_gates_h(ptr(z), ptr(q_pre), ptr(bias), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(h_out),
+                                h_out.shape[1], stream_ptr()), 'rpe_gru_gates_h')
+
+
+def bias_act(x, bias, relu=True, out=None, out_offset=0, out2=None, out2_offset=0):
+    """act(x + bias[c]) -> channels [out_offset, out_offset + c) of ``out`` (default: in place on x) and optionally
+    the same into ``out2``."""
+    _nchw(x, 'x')
+    b, c, hh, ww = x.shape
+    out = x if out is None else _nchw(out, 'out')
+    if out2 is not None:
+        _nchw(out2, 'out2')
+    check(lib().rpe_bias_act(ptr(x), ptr(bias), b, c, hh * ww, int(bool(relu)), ptr(out), out.shape[1], out_offset,
+                             ptr(out2), out2.shape[1] if out2 is not None else 0, out2_offset, stream_ptr()), 'rpe_bias_act')
+    return out
 
 
 def upsample_convex(flow, mask):

@@ -122,12 +122,17 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr):
-        cor = F.relu(self.convc1(corr))
-        cor = F.relu(self.convc2(cor))
-        flo = F.relu(self.convf1(flow))
-        flo = F.relu(self.convf2(flo))
-        return F.relu(self.conv(torch.cat([cor, flo], dim=1)))          # (b,126,h,w); caller appends flow
+    def forward(self, flow, corr, cat_buf, hx, rhx):
+        """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [256,384) of hx and rhx.
+        Convolutions run without bias; bias + ReLU (+ the cat / copies) are one HIP pass each (rpe_bias_act)."""
+        def cv(m, x):
+            return F.conv2d(x, m.weight, None, m.stride, m.padding)
+        cor = ops.bias_act(cv(self.convc1, corr), self.convc1.bias)
+        ops.bias_act(cv(self.convc2, cor), self.convc2.bias, out=cat_buf, out_offset=0)
+        flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)
+        ops.bias_act(cv(self.convf2, flo), self.convf2.bias, out=cat_buf, out_offset=192)
+        ops.bias_act(cv(self.conv, cat_buf), self.conv.bias, out=hx, out_offset=256, out2=rhx, out2_offset=256)
+        ops.bias_act(flow, None, relu=False, out=hx, out_offset=382, out2=rhx, out2_offset=382)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -153,27 +158,27 @@ class BasicUpdateBlock(nn.Module):
             self._stacked = (key, (w1, b1, w2, b2))
         return self._stacked[1]
 
-    def step(self, hx, rhx, z_buf, corr, flow):
+    def step(self, hx, rhx, z_buf, cat_buf, h_buf, corr, flow):
         """One update.  hx = (h | inp | motion | flow) buffer, rhx = (r*h | same x) buffer; both (b,384,h,w).
-        Returns delta_flow; the new hidden state is left in hx[:, :128]."""
+        Returns delta_flow; the new hidden state is left in hx[:, :128] (and, contiguous, in h_buf)."""
         c = self.hidden_dim
         g = self.gru
-        mot = self.encoder(flow, corr)
-        for buf in (hx, rhx):
-            buf[:, 2 * c:3 * c - 2].copy_(mot)
-            buf[:, 3 * c - 2:].copy_(flow)
+        self.encoder(flow, corr, cat_buf, hx, rhx)
         w1, b1, w2, b2 = self.stacked_gate_weights()
         # horizontal half: z = s(convz1 hx), r = s(convr1 hx), q = tanh(convq1 [r*h, x]), h = (1-z) h + z q
-        zr = F.conv2d(hx, w1, b1, padding=(0, 2))
-        ops.gru_gates_zr(zr, hx, c, z_buf, rhx)
-        q = g.convq1(rhx)
-        ops.gru_gates_h(z_buf, q, hx, c, hx)
+        zr = F.conv2d(hx, w1, None, padding=(0, 2))
+        ops.gru_gates_zr(zr, hx, c, z_buf, rhx, bias=b1)
+        q = F.conv2d(rhx, g.convq1.weight, None, padding=(0, 2))
+        ops.gru_gates_h(z_buf, q, hx, c, hx, bias=g.convq1.bias)
         # vertical half
-        zr = F.conv2d(hx, w2, b2, padding=(2, 0))
-        ops.gru_gates_zr(zr, hx, c, z_buf, rhx)
-        q = g.convq2(rhx)
-        ops.gru_gates_h(z_buf, q, hx, c, hx)
-        return self.flow_head(hx[:, :c])
+        zr = F.conv2d(hx, w2, None, padding=(2, 0))
+        ops.gru_gates_zr(zr, hx, c, z_buf, rhx, bias=b2)
+        q = F.conv2d(rhx, g.convq2.weight, None, padding=(2, 0))
+        ops.gru_gates_h(z_buf, q, hx, c, hx, bias=g.convq2.bias)
+        h_buf.copy_(hx[:, :c])                                            # contiguous h for the heads
+        fh = self.flow_head
+        t = ops.bias_act(F.conv2d(h_buf, fh.conv1.weight, None, padding=1), fh.conv1.bias)
+        return fh.conv2(t)
 
     def up_mask(self, net):
         return .25 * self.mask(net)                                      # scale mask to balance gradients (upstream)
@@ -235,6 +240,8 @@ class RAFT(nn.Module):
         hx = torch.empty(N, 3 * c, h8, w8, device=dev)
         rhx = torch.empty_like(hx)
         z_buf = torch.empty(N, c, h8, w8, device=dev)
+        h_buf = torch.empty(N, c, h8, w8, device=dev)
+        cat_buf = torch.empty(N, 2 * c, h8, w8, device=dev)
         torch.tanh(cnet[:, :c], out=hx[:, :c])
         inp = torch.relu(cnet[:, c:])
         hx[:, c:2 * c].copy_(inp)
@@ -246,12 +253,12 @@ class RAFT(nn.Module):
         for itr in range(iters):
             pyr.lookup(coords1, out=corr)
             flow = coords1 - coords0
-            delta = self.update_block.step(hx, rhx, z_buf, corr, flow)
+            delta = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, corr, flow)
             coords1 = coords1 + delta
             if all_flows or itr == iters - 1:
                 lowres = coords1 - coords0
                 if upsample:
-                    flow_predictions.append(ops.upsample_convex(lowres, self.update_block.up_mask(hx[:, :c])))
+                    flow_predictions.append(ops.upsample_convex(lowres, self.update_block.up_mask(h_buf)))
                 else:
                     flow_predictions.append(lowres)
-        return flow_predictions, hx[:, :c].contiguous(), inp
+        return flow_predictions, h_buf, inp

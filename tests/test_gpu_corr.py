@@ -94,17 +94,40 @@ def test_gru_gates(rpe):
     q = torch.randn(b, c, h, w) * 3
     z_out = torch.empty(b, c, h, w, device='cuda')
     rhx = hx.clone().cuda()
-    ops.gru_gates_zr(zr.cuda(), hx.cuda(), c, z_out, rhx)
-    z_ref = torch.sigmoid(zr[:, :c])
-    rh_ref = torch.sigmoid(zr[:, c:]) * hx[:, :c]
+    bzr = torch.randn(2 * c)
+    ops.gru_gates_zr(zr.cuda(), hx.cuda(), c, z_out, rhx, bias=bzr.cuda())
+    z_ref = torch.sigmoid(zr[:, :c] + bzr[:c, None, None])
+    rh_ref = torch.sigmoid(zr[:, c:] + bzr[c:, None, None]) * hx[:, :c]
     assert torch.allclose(z_out.cpu(), z_ref, atol=1e-6)
     assert torch.allclose(rhx[:, :c].cpu(), rh_ref, atol=1e-6)
     assert torch.equal(rhx[:, c:].cpu(), hx[:, c:])                         # x part untouched
     hx_d = hx.clone().cuda()
-    ops.gru_gates_h(z_out, q.cuda(), hx_d, c, hx_d)                         # in place
-    h_ref = (1 - z_ref) * hx[:, :c] + z_ref * torch.tanh(q)
+    bq = torch.randn(c)
+    ops.gru_gates_h(z_out, q.cuda(), hx_d, c, hx_d, bias=bq.cuda())         # in place
+    h_ref = (1 - z_ref) * hx[:, :c] + z_ref * torch.tanh(q + bq[:, None, None])
     assert torch.allclose(hx_d[:, :c].cpu(), h_ref, atol=2e-6)
     assert torch.equal(hx_d[:, c:].cpu(), hx[:, c:])
+
+
+def test_bias_act(rpe):
+    from rpe_amd import ops
+    torch.manual_seed(2)
+    x = torch.randn(2, 126, 16, 20)
+    x[0, 0, 0, 0] = float('nan')
+    bias = torch.randn(126)
+    hx = torch.zeros(2, 384, 16, 20, device='cuda')
+    rhx = torch.ones(2, 384, 16, 20, device='cuda')
+    ops.bias_act(x.cuda(), bias.cuda(), relu=True, out=hx, out_offset=256, out2=rhx, out2_offset=256)
+    ref = torch.relu(x + bias[:, None, None])
+    for buf, other in ((hx, 0.0), (rhx, 1.0)):
+        got = buf[:, 256:382].cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(ref))
+        assert bool((buf[:, :256] == other).all()) and bool((buf[:, 382:] == other).all())
+    y = x.clone().cuda()
+    ops.bias_act(y, None, relu=False)                                        # identity, in place
+    assert torch.equal(torch.nan_to_num(y.cpu()), torch.nan_to_num(x))
+    odd = torch.randn(1, 3, 5, 7)                                            # hw % 4 != 0 -> scalar path
+    assert torch.equal(ops.bias_act(odd.cuda(), bias[:3].cuda()).cpu(), torch.relu(odd + bias[:3, None, None]))
 
 
 def test_convex_upsample(rpe):

@@ -48,6 +48,7 @@ def main():
         mark('corr_build')
         c = 128
         hx = torch.empty(N, 3 * c, h8, w8, device=dev); rhx = torch.empty_like(hx); z = torch.empty(N, c, h8, w8, device=dev)
+        hb = torch.empty(N, c, h8, w8, device=dev); catb = torch.empty(N, 2 * c, h8, w8, device=dev); F = torch.nn.functional
         torch.tanh(cnet[:, :c], out=hx[:, :c]); inp = torch.relu(cnet[:, c:]); hx[:, c:2*c].copy_(inp); rhx[:, c:2*c].copy_(inp)
         c0 = raft_mod.coords_grid(N, h8, w8, dev); c1 = c0.clone()
         corr = torch.empty(N, 324, h8, w8, device=dev)
@@ -56,20 +57,19 @@ def main():
         for it in range(12):
             pyr.lookup(c1, out=corr); mark('lookup')
             flow = c1 - c0
-            mot = ub.encoder(flow, corr); mark('motion_enc')
-            for buf in (hx, rhx):
-                buf[:, 2*c:3*c-2].copy_(mot); buf[:, 3*c-2:].copy_(flow)
+            ub.encoder(flow, corr, catb, hx, rhx); mark('motion_enc')
             w1, b1, w2, b2 = ub.stacked_gate_weights()
-            zr = torch.nn.functional.conv2d(hx, w1, b1, padding=(0, 2)); ops.gru_gates_zr(zr, hx, c, z, rhx)
-            q = ub.gru.convq1(rhx); ops.gru_gates_h(z, q, hx, c, hx)
-            zr = torch.nn.functional.conv2d(hx, w2, b2, padding=(2, 0)); ops.gru_gates_zr(zr, hx, c, z, rhx)
-            q = ub.gru.convq2(rhx); ops.gru_gates_h(z, q, hx, c, hx); mark('gru')
-            d = ub.flow_head(hx[:, :c]); c1 = c1 + d; mark('flow_head')
-        up = ops.upsample_convex(c1 - c0, ub.up_mask(hx[:, :c])); mark('mask+upsample')
+            zr = F.conv2d(hx, w1, None, padding=(0, 2)); ops.gru_gates_zr(zr, hx, c, z, rhx, bias=b1)
+            q = F.conv2d(rhx, ub.gru.convq1.weight, None, padding=(0, 2)); ops.gru_gates_h(z, q, hx, c, hx, bias=ub.gru.convq1.bias)
+            zr = F.conv2d(hx, w2, None, padding=(2, 0)); ops.gru_gates_zr(zr, hx, c, z, rhx, bias=b2)
+            q = F.conv2d(rhx, ub.gru.convq2.weight, None, padding=(2, 0)); ops.gru_gates_h(z, q, hx, c, hx, bias=ub.gru.convq2.bias); mark('gru')
+            hb.copy_(hx[:, :c]); fh = ub.flow_head
+            d = fh.conv2(ops.bias_act(F.conv2d(hb, fh.conv1.weight, None, padding=1), fh.conv1.bias)); c1 = c1 + d; mark('flow_head')
+        up = ops.upsample_convex(c1 - c0, ub.up_mask(hb)); mark('mask+upsample')
         tfl = up[:n].contiguous(); sf2 = up[n:].contiguous()
         gg = ops.depth_backproject_warp(sf2, tfl, g['baseline'], g['intrinsics'], g['depth1'], g['image1l'], g['image2l'], g['stereo_flow1'], g['mask2'])
         mark('geometry')
-        hid = hx[:n, :c]; ctx = inp[:n]
+        hid = hb[:n]; ctx = inp[:n]
         w2d = model.weight_head_2d(torch.cat((gg['inp1'], hid, ctx), 1)); w3d = model.weight_head_3d(torch.cat((gg['inp1'], gg['inp2'], hid, ctx), 1))
         mark('weight_heads')
         lw = model.loss_weight.detach()[None].repeat(n, 1)
