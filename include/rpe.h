@@ -170,6 +170,15 @@ int rpe_gru_gates_h(const float *z, const float *q_pre, const float *q_bias, con
  * bias may be NULL; out1 may alias x when out1_channels == c. */
 int rpe_bias_act(const float *x, const float *bias, int b, int c, int hw, int relu, float *out1, int out1_channels,
                  int out1_offset, float *out2, int out2_channels, int out2_offset, void *stream);
+/* Encoder epilogues (core/RAFT/core/extractor.py ResidualBlock.forward / BasicEncoder.forward): for x (b,c,hw)
+ *   y = norm(x + bias[c]);  if (relu) y = max(y,0);  if (residual != NULL) y = max(residual + y, 0)
+ * rpe_instnorm_act: per-(b,c) instance norm, biased variance, eps inside the root (torch.nn.InstanceNorm2d, fnet).
+ * rpe_affine_act:   y = x*scale[c] + shift[c], i.e. an eval-mode BatchNorm2d folded with the conv bias (cnet).
+ * out may alias x.  bias / residual may be NULL. */
+int rpe_instnorm_act(const float *x, const float *bias, int b, int c, int hw, float eps, int relu,
+                     const float *residual, float *out, void *stream);
+int rpe_affine_act(const float *x, const float *scale, const float *shift, int b, int c, int hw, int relu,
+                   const float *residual, float *out, void *stream);
 /* flow (b,2,h8,w8), mask (b,576,h8,w8) raw logits already scaled by .25 -> out (b,2,8*h8,8*w8). */
 int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int w8, float *out, void *stream);
 

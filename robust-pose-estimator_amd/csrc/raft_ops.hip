@@ -84,6 +84,82 @@ __global__ __launch_bounds__(256) void k_bias_act(const float* x, const float* _
     }
 }
 
+// ---- encoder epilogues (core/RAFT/core/extractor.py ResidualBlock / BasicEncoder): the normalisation, ReLU and
+// residual add that follow every encoder convolution, fused so each activation plane crosses HBM once in and once out
+// (torch runs statistics, normalise, bias add, ReLU and the residual add as 4-5 separate passes).
+//   y = norm(x + bias[c]);  if (relu) y = max(y, 0);  if (residual) y = max(residual + y, 0)
+// Instance norm (fnet): one workgroup per (b, c) plane, mean and biased variance by two passes over the plane (the
+// re-reads hit L2: a plane is <= 328 KB), eps inside the square root as torch.nn.InstanceNorm2d does.
+__global__ __launch_bounds__(512) void k_instnorm_act(const float* __restrict__ x, const float* __restrict__ bias, int c, int hw,
+                                                      float eps, int relu, const float* __restrict__ residual, float* __restrict__ out) {
+    const int plane = blockIdx.x;                      // b * c + ch
+    const float bv = bias ? bias[plane % c] : 0.0f;
+    const float* xp = x + (size_t)plane * hw;
+    const float* rp = residual ? residual + (size_t)plane * hw : nullptr;
+    float* op = out + (size_t)plane * hw;
+    __shared__ float red[8];
+    __shared__ float bc;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const bool v4 = (hw & 3) == 0;
+    const int n4 = hw >> 2;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wv] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) { float t = 0.0f; for (int i = 0; i < nw; ++i) t += red[i]; bc = t; }
+        __syncthreads();
+        return bc;
+    };
+    float acc = 0.0f;
+    if (v4) for (int i = threadIdx.x; i < n4; i += blockDim.x) { float4 v = ((const float4*)xp)[i]; acc += (v.x + bv) + (v.y + bv) + (v.z + bv) + (v.w + bv); }
+    else for (int i = threadIdx.x; i < hw; i += blockDim.x) acc += xp[i] + bv;
+    const float mean = block_sum(acc) / (float)hw;
+    acc = 0.0f;
+    if (v4) for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        float4 v = ((const float4*)xp)[i];
+        float a = v.x + bv - mean, b = v.y + bv - mean, cc = v.z + bv - mean, d = v.w + bv - mean;
+        acc += a * a + b * b + cc * cc + d * d;
+    } else for (int i = threadIdx.x; i < hw; i += blockDim.x) { float a = xp[i] + bv - mean; acc += a * a; }
+    const float invstd = 1.0f / sqrtf(block_sum(acc) / (float)hw + eps);
+    auto fin = [&](float v, float r) -> float {
+        float y = (v + bv - mean) * invstd;
+        if (relu) y = y < 0.0f ? 0.0f : y;
+        if (rp) { y = r + y; y = y < 0.0f ? 0.0f : y; }
+        return y;
+    };
+    if (v4) for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        float4 v = ((const float4*)xp)[i];
+        float4 r = rp ? ((const float4*)rp)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ((float4*)op)[i] = make_float4(fin(v.x, r.x), fin(v.y, r.y), fin(v.z, r.z), fin(v.w, r.w));
+    } else for (int i = threadIdx.x; i < hw; i += blockDim.x) op[i] = fin(xp[i], rp ? rp[i] : 0.0f);
+}
+
+// Frozen batch norm (cnet, eval mode) folded to a per-channel affine map y = x * scale[c] + shift[c].
+template <int VEC>
+__global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ x, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int c, int hw, int relu,
+                                                    const float* __restrict__ residual, float* __restrict__ out) {
+    const int bz = blockIdx.y;
+    const size_t per = (size_t)c * hw;
+    for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        const int ch = (int)(e / hw);
+        const float sc = scale[ch], sh = shift[ch];
+        const size_t o = (size_t)bz * per + e;
+        float v[VEC], r[VEC];
+        if (VEC == 4) { *(float4*)v = *(const float4*)(x + o); if (residual) *(float4*)r = *(const float4*)(residual + o); }
+        else { v[0] = x[o]; if (residual) r[0] = residual[o]; }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float y = v[k] * sc + sh;
+            if (relu) y = y < 0.0f ? 0.0f : y;
+            if (residual) { y = r[k] + y; y = y < 0.0f ? 0.0f : y; }
+            v[k] = y;
+        }
+        if (VEC == 4) *(float4*)(out + o) = *(float4*)v; else out[o] = v[0];
+    }
+}
+
 // One thread per 1/8-resolution cell; loops over the 64 sub-pixels.  Mask channel = k*64 + i*8 + j.
 __global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict__ flow, const float* __restrict__ mask, int h8,
                                                          int w8, float* __restrict__ out) {
@@ -123,6 +199,27 @@ __global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict
 }
 
 static bool vec_ok(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+extern "C" int rpe_instnorm_act(const float* x, const float* bias, int b, int c, int hw, float eps, int relu,
+                                const float* residual, float* out, void* stream) {
+    if (!x || !out || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    bool v4 = vec_ok(x) && vec_ok(out) && (!residual || vec_ok(residual));
+    if (!v4 && (hw & 3) == 0) return RPE_E_BADARG;     // planes of 16-B-aligned tensors with hw % 4 == 0 stay aligned
+    hipLaunchKernelGGL(k_instnorm_act, dim3(b * c), dim3(hw >= 16384 ? 512 : 256), 0, (hipStream_t)stream, x, bias, c, hw, eps, relu,
+                       residual, out);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_affine_act(const float* x, const float* scale, const float* shift, int b, int c, int hw, int relu,
+                              const float* residual, float* out, void* stream) {
+    if (!x || !scale || !shift || !out || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    size_t per = (size_t)c * hw;
+    bool v4 = hw % 4 == 0 && vec_ok(x) && vec_ok(out) && (!residual || vec_ok(residual));
+    if (v4) hipLaunchKernelGGL(k_affine_act<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, x, scale, shift, c, hw, relu, residual, out);
+    else hipLaunchKernelGGL(k_affine_act<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, x, scale, shift, c, hw, relu, residual, out);
+    return rpe_check_launch();
+}
 
 extern "C" int rpe_bias_act(const float* x, const float* bias, int b, int c, int hw, int relu, float* out1, int out1_channels,
                             int out1_offset, float* out2, int out2_channels, int out2_offset, void* stream) {

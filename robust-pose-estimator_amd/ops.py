@@ -255,6 +255,30 @@ def bias_act(x, bias, relu=True, out=None, out_offset=0, out2=None, out2_offset=
     return out
 
 
+def instnorm_act(x, bias, eps=1e-5, relu=True, residual=None, out=None):
+    """relu?(InstanceNorm(x + bias)), then optionally relu(residual + .) -- one pass per plane."""
+    _nchw(x, 'x')
+    if residual is not None:
+        _nchw(residual, 'residual')
+    b, c, hh, ww = x.shape
+    out = x if out is None else _nchw(out, 'out')
+    check(lib().rpe_instnorm_act(ptr(x), ptr(bias), b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
+                                 stream_ptr()), 'rpe_instnorm_act')
+    return out
+
+
+def affine_act(x, scale, shift, relu=True, residual=None, out=None):
+    """relu?(x * scale[c] + shift[c]), then optionally relu(residual + .)."""
+    _nchw(x, 'x')
+    if residual is not None:
+        _nchw(residual, 'residual')
+    b, c, hh, ww = x.shape
+    out = x if out is None else _nchw(out, 'out')
+    check(lib().rpe_affine_act(ptr(x), ptr(scale), ptr(shift), b, c, hh * ww, int(bool(relu)), ptr(residual), ptr(out),
+                               stream_ptr()), 'rpe_affine_act')
+    return out
+
+
 def upsample_convex(flow, mask):
     fl, mk = _dev(flow, torch.float32, 'flow'), _dev(mask, torch.float32, 'mask')
     b, _, h8, w8 = fl.shape

@@ -47,11 +47,35 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        """relu(x' + relu(norm2(conv2(relu(norm1(conv1 x)))))), x' = x or norm3(conv1x1 x); convolutions without
+        bias on MIOpen, every (bias, norm, ReLU, residual) epilogue one fused HIP pass (ops.conv_norm_act)."""
+        y = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         if self.downsample is not None:
-            x = self.downsample(x)
-        return self.relu(x + y)
+            x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
+        return conv_norm_act(self.conv2, self.norm2, y, relu=True, residual=x)
+
+
+def _bn_affine(conv, norm):
+    """Eval-mode BatchNorm2d folded with the conv bias: y = conv_nobias(x) * scale + shift (cached per module)."""
+    key = tuple(t._version for t in (conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var)) + (norm.weight.data_ptr(),)
+    cached = getattr(norm, '_rpe_affine', None)
+    if cached is None or cached[0] != key:
+        scale = (norm.weight / torch.sqrt(norm.running_var + norm.eps)).detach().float().contiguous()
+        shift = ((conv.bias - norm.running_mean) * scale + norm.bias).detach().float().contiguous()
+        norm._rpe_affine = cached = (key, scale, shift)
+    return cached[1], cached[2]
+
+
+def conv_norm_act(conv, norm, x, relu, residual=None):
+    pre = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    if isinstance(norm, nn.InstanceNorm2d):
+        return ops.instnorm_act(pre, conv.bias, eps=norm.eps, relu=relu, residual=residual)
+    if isinstance(norm, nn.BatchNorm2d):
+        if norm.training:
+            raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')
+        scale, shift = _bn_affine(conv, norm)
+        return ops.affine_act(pre, scale, shift, relu=relu, residual=residual)
+    raise NotImplementedError(type(norm))
 
 
 class BasicEncoder(nn.Module):
@@ -82,7 +106,7 @@ class BasicEncoder(nn.Module):
         return nn.Sequential(l1, l2)
 
     def forward(self, x):
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = conv_norm_act(self.conv1, self.norm1, x.contiguous(), relu=True)
         x = self.layer3(self.layer2(self.layer1(x)))
         return self.conv2(x)
 

@@ -153,3 +153,49 @@ def test_high_resolution_geometry_1280x1024(rpe):
     assert float((out - ref(coords)).abs().max()) <= 4e-5 * scale
     l3 = pyr.export_level(3).cpu()
     assert float((l3 - ref.corr_pyramid[3][:, 0]).abs().max()) <= 2e-5 * scale
+
+
+def test_encoder_epilogues(rpe):
+    """rpe_instnorm_act / rpe_affine_act vs torch's InstanceNorm2d / eval BatchNorm2d + ReLU + residual."""
+    from rpe_amd import ops
+    torch.manual_seed(3)
+    for shape in ((2, 64, 32, 40), (1, 96, 17, 23)):                        # second: hw % 4 != 0
+        x = torch.randn(*shape) * 3 + 1
+        bias = torch.randn(shape[1])
+        res = torch.randn(*shape)
+        pre = x + bias[None, :, None, None]
+        ref = torch.relu(F.instance_norm(pre, eps=1e-5))
+        got = ops.instnorm_act(x.clone().cuda(), bias.cuda(), eps=1e-5, relu=True).cpu()
+        assert torch.allclose(got, ref, atol=2e-5)
+        ref2 = torch.relu(res + ref)
+        got2 = ops.instnorm_act(x.clone().cuda(), bias.cuda(), relu=True, residual=res.cuda()).cpu()
+        assert torch.allclose(got2, ref2, atol=2e-5)
+        ref3 = F.instance_norm(pre, eps=1e-5)
+        got3 = ops.instnorm_act(x.clone().cuda(), bias.cuda(), relu=False).cpu()
+        assert torch.allclose(got3, ref3, atol=2e-5)
+        bn = torch.nn.BatchNorm2d(shape[1]).eval()
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(); bn.bias.data.normal_()
+        with torch.no_grad():
+            refb = torch.relu(res + torch.relu(bn(pre)))
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = (bias - bn.running_mean) * scale + bn.bias
+        gotb = ops.affine_act(x.clone().cuda(), scale.cuda(), shift.cuda(), relu=True, residual=res.cuda()).cpu()
+        assert torch.allclose(gotb, refb, atol=2e-5)
+
+
+def test_encoders_match_oracle(rpe):
+    from rpe_amd import raft as praft
+    torch.manual_seed(4)
+    img = torch.rand(2, 3, 96, 128) * 2 - 1
+    for norm in ('instance', 'batch'):
+        enc = praft.BasicEncoder(256, norm).eval()
+        oenc = oraft.BasicEncoder(256, norm).eval()
+        if norm == 'batch':
+            for m in enc.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+        oenc.load_state_dict(enc.state_dict())
+        with torch.no_grad():
+            ref = oenc(img)
+            got = enc.cuda()(img.cuda()).cpu()
+        assert float((got - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), norm
