@@ -64,7 +64,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import rpe_amd  # noqa: F401  (raises if librpe_hip.so is missing: no fallback)
-    from rpe_amd import pose_net, synth
+    from rpe_amd import pose_head, pose_net, synth  # noqa: F401
 
     H, W, B = args.height, args.width, args.batch
     cfg = synth.model_config(H, W, iters=args.raft_iters, lbgfs_iters=args.solver_iters, solver=args.solver)
@@ -92,6 +92,22 @@ def main():
         return r
 
     rpe_amd.ops.CorrPyramid.lookup = timed_lookup
+
+    solve_events = []
+    real_solve = rpe_amd.ops.pose_solve
+
+    def timed_solve(*a, **k):
+        if not timing['on']:
+            return real_solve(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real_solve(*a, **k)
+        e1.record()
+        solve_events.append((e0, e1))
+        return r
+
+    rpe_amd.ops.pose_solve = timed_solve
+    rpe_amd.pose_head.ops.pose_solve = timed_solve
 
     def step():
         gpu_in['mask2'].copy_(mask2_init)          # infer() mutates mask2 in place, as the reference does
@@ -152,15 +168,27 @@ def main():
             'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
                          'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
+            'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
             'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
             'valid_fraction': float(gpu_in['mask2'].float().mean()),
         }
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:        # CPU baseline on rank 0 at N = 1 only
             res['cpu_baseline'] = cpu_baseline(cfg, model, frames, args.cpu_frames, pose)
         print(json.dumps(res))
     barrier()
     if distributed:
         dist.destroy_process_group()
+
+
+def pose_roofline(events, frames, h, w, iters):
+    """Second HBM-bound kernel family: the whole device-resident solve (N x (k_pose_reduce + k_pose_update)), HIP-event
+    timed in the timed region; algorithmic bytes = 42 B/pixel per evaluation."""
+    if not events:
+        return None
+    t = sum(a.elapsed_time(b) for a, b in events) / len(events) / 1e3
+    alg = frames * h * w * 42 * iters
+    return {'kernels': 'k_pose_reduce + k_pose_update x%d' % iters, 'bound': 'hbm', 'achieved': alg / t / 1e9, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': alg / t / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_solve': alg, 'avg_solve_us': t * 1e6}
 
 
 def usable_cores():
