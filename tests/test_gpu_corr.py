@@ -199,3 +199,27 @@ def test_encoders_match_oracle(rpe):
             ref = oenc(img)
             got = enc.cuda()(img.cuda()).cpu()
         assert float((got - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), norm
+
+
+def test_full_size_lookup_properties(rpe):
+    """BASELINE geometry (64x80 queries), properties that need no CPU reference:
+    (a) scaling fmap1 by 2 scales every lookup output by exactly 2 (bit for bit: GEMM, pooling and bilinear taps are
+        all linear and a power-of-two factor is exact);
+    (b) a permutation of the batch permutes the outputs bit for bit (pairs are independent);
+    (c) at integer coordinates the centre tap of level 0 is the correlation of the query with its own target pixel."""
+    from rpe_amd import ops
+    b, h8, w8 = 4, 64, 80
+    f1, f2 = fmaps(21, b, h8, w8)
+    f1, f2 = f1.cuda(), f2.cuda()
+    coords = coords_for(5, b, h8, w8, 3.0).cuda()
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda')
+    out = pyr.build(f1, f2).lookup(coords).clone()
+    out2 = pyr.build(2.0 * f1, f2).lookup(coords).clone()
+    assert torch.equal(out2, 2.0 * out)
+    perm = [2, 0, 3, 1]
+    outp = pyr.build(f1[perm].contiguous(), f2[perm].contiguous()).lookup(coords[perm].contiguous())
+    assert torch.equal(outp, out[perm])
+    c0 = oraft.coords_grid(b, h8, w8).cuda()
+    centre = pyr.build(f1, f2).lookup(c0)[:, 40]                              # level 0, window index (4,4)
+    diag = (f1 * f2).sum(1) / 16.0                                           # <f1[:,q], f2[:,q]> / sqrt(256)
+    assert float((centre - diag).abs().max()) <= 4e-5 * float(diag.abs().max())
