@@ -75,6 +75,10 @@ class PoseEstimator(torch.nn.Module):
         self.last_pose = SE3.Identity(1) if init_pose is None else init_pose.float()
         self.frame = None
         self.last_frame = None
+        # streaming: encoder outputs of the current left image, reused as image1l's on the next call (exact: both
+        # encoders normalise per sample); set reuse_features=False to re-encode like the reference does
+        self.reuse_features = config.get('reuse_features', True)
+        self._enc_cache = None
 
     @property
     def device(self):
@@ -104,14 +108,18 @@ class PoseEstimator(torch.nn.Module):
         flow = None
         if self.last_frame is None:
             rel = SE3.IdentityLike(self.last_pose)
-            depth, stereo_flow, valid = self.model.flow2depth(self.frame.img, self.frame.rimg, self.baseline * self.scale)
+            depth, stereo_flow, valid, cache = self.model.flow2depth(self.frame.img, self.frame.rimg,
+                                                                     self.baseline * self.scale, ret_cache=True)
+            self._enc_cache = cache if self.reuse_features else None
             self.frame.depth = depth / self.scale
             self.frame.flow = stereo_flow
             return rel, None, None, None
-        rel, depth1, depth2, weights, flow, stereo_flow = self.model.infer(
+        rel, depth1, depth2, weights, flow, stereo_flow, cache = self.model.infer(
             self.last_frame.img, self.frame.img, self.intrinsics, self.baseline * self.scale,
             depth1=self.last_frame.depth * self.scale, image2r=self.frame.rimg, mask1=self.last_frame.mask,
-            mask2=self.frame.mask, stereo_flow1=self.last_frame.flow, ret_details=True)
+            mask2=self.frame.mask, stereo_flow1=self.last_frame.flow, ret_details=True,
+            cache1=self._enc_cache, ret_cache=True)
+        self._enc_cache = cache if self.reuse_features else None
         rel = SE3(rel.data.reshape(1, 7))
         self.frame.depth = depth2 / self.scale
         self.frame.flow = stereo_flow

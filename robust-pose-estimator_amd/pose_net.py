@@ -39,16 +39,24 @@ class PoseNet(nn.Module):
         return self
 
     @torch.no_grad()
-    def flow2depth(self, imagel, imager, baseline, upsample=True):
-        """pose_net.py:127-135 -> (depth (n,1,h,w), stereo flow (n,2,h,w), valid (n,1,h,w) bool)."""
+    def flow2depth(self, imagel, imager, baseline, upsample=True, ret_cache=False):
+        """pose_net.py:127-135 -> (depth (n,1,h,w), stereo flow (n,2,h,w), valid (n,1,h,w) bool).
+        ``ret_cache`` additionally returns the encoder outputs of ``imagel`` for reuse by the next ``infer``."""
         if not upsample:
             raise NotImplementedError('upsample=False is not on the inference path')
-        flow = self.flow(imagel, imager, upsample=True)[0][-1]
+        n = imagel.shape[0]
+        f = self.flow.encode_features(torch.cat((imagel, imager), dim=0))
+        cn = self.flow.encode_context(imagel)
+        flow = self.flow(imagel, imager, upsample=True, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
         depth, valid = ops.flow2depth(flow, baseline)
+        if ret_cache:
+            return depth, flow, valid, dict(fmap=f[:n], cnet=cn)
         return depth, flow, valid
 
     @torch.no_grad()
-    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1):
+    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None):
+        """Every stage of infer() before the solve.  ``cache1`` = {'fmap','cnet'} of image1l from the previous call
+        (streaming: frame t's image2l is frame t+1's image1l), so only the two new images are encoded."""
         n = image1l.shape[0]
         intrinsics = intrinsics.expand(n, 3, 3).contiguous()
         baseline = baseline.expand(n).contiguous()
@@ -56,9 +64,18 @@ class PoseNet(nn.Module):
         trg_imgs = torch.cat((image2l, image2r), dim=0)
         # image2l sits in both halves of the reference's batch-2 RAFT call (pose_net.py:63-64); the feature
         # encoder uses per-sample instance norm, so it is encoded once and reused (3n encoder passes, not 4n)
-        f = self.flow.encode_features(torch.cat((image1l, image2l, image2r), dim=0))
-        fmaps = (f[:2 * n], torch.cat((f[n:2 * n], f[2 * n:]), dim=0))
-        flow_predictions, hidden, context = self.flow(ref_imgs, trg_imgs, upsample=True, fmaps=fmaps)
+        if cache1 is None:
+            f = self.flow.encode_features(torch.cat((image1l, image2l, image2r), dim=0))
+            f1l, f2l, f2r = f[:n], f[n:2 * n], f[2 * n:]
+            cn = self.flow.encode_context(ref_imgs)
+            c2l = cn[n:]
+        else:
+            f = self.flow.encode_features(torch.cat((image2l, image2r), dim=0))
+            f1l, f2l, f2r = cache1['fmap'], f[:n], f[n:]
+            c2l = self.flow.encode_context(image2l)
+            cn = torch.cat((cache1['cnet'], c2l), dim=0)
+        fmaps = (torch.cat((f1l, f2l), dim=0), torch.cat((f2l, f2r), dim=0))
+        flow_predictions, hidden, context = self.flow(ref_imgs, trg_imgs, upsample=True, fmaps=fmaps, cnet=cn)
         time_flow = flow_predictions[-1][:n].contiguous()
         stereo_flow2 = flow_predictions[-1][n:].contiguous()
         hidden, context = hidden[:n], context[:n]
@@ -71,22 +88,23 @@ class PoseNet(nn.Module):
             w2d = torch.ones_like(g['depth2'])
             w3d = torch.ones_like(g['depth2'])
         g.update(time_flow=time_flow, stereo_flow2=stereo_flow2, hidden=hidden, context=context, w2d=w2d, w3d=w3d,
-                 intrinsics=intrinsics)
+                 intrinsics=intrinsics, cache2=dict(fmap=f2l, cnet=c2l))
         return g
 
     @torch.no_grad()
     def infer(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1,
-              ret_details=False):
-        s = self.stages(image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1)
+              ret_details=False, cache1=None, ret_cache=False):
+        s = self.stages(image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1)
         mask2.copy_(s['mask2'])                               # `mask2 &= valid` mutates the caller's tensor (:77)
         n = image1l.shape[0]
         lw = self.loss_weight.detach()[None, :].repeat(n, 1)
         vec7, _ = self.pose_head(s['time_flow'], s['pcl1'], s['pcl2w'], s['w2d'], s['w3d'], mask1.bool(), s['mask2w'],
                                  s['intrinsics'], lw)
         pose = SE3(vec7[:, 0]) if n > 1 else SE3(vec7)[0]     # reference returns SE3(pose_se3)[0] for its n == 1
-        if ret_details:
-            return pose, depth1, s['depth2'], (s['w2d'], s['w3d']), s['time_flow'], s['stereo_flow2']
-        return pose
+        out = (pose, depth1, s['depth2'], (s['w2d'], s['w3d']), s['time_flow'], s['stereo_flow2']) if ret_details else pose
+        if ret_cache:
+            return (*out, s['cache2']) if ret_details else (out, s['cache2'])
+        return out
 
     def init_from_raft(self, raft_ckp):
         state = torch.load(raft_ckp, map_location='cpu')

@@ -245,21 +245,27 @@ class RAFT(nn.Module):
         return self.fnet(2 * (images / 255.0) - 1.0).float()
 
     @torch.no_grad()
-    def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None):
-        """image1, image2: (N,3,H,W) in 0..255.  Inference only (the reference freezes RAFT, train.yaml:51)."""
+    def encode_context(self, images):
+        """cnet on raw 0..255 images: (N,256,H/8,W/8) = (hidden | context) pre-activations."""
+        return self.cnet(2 * (images / 255.0) - 1.0)
+
+    @torch.no_grad()
+    def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None, cnet=None):
+        """image1, image2: (N,3,H,W) in 0..255.  Inference only (the reference freezes RAFT, train.yaml:51).
+        ``fmaps`` / ``cnet`` accept encoder outputs computed elsewhere (both encoders normalise per sample -- instance
+        norm / frozen batch norm -- so a caller may encode every distinct image once and reuse it)."""
         iters = self.iters if iters is None else iters
         N, _, H, W = image1.shape
         h8, w8 = H // 8, W // 8
         dev = image1.device
-        image1 = 2 * (image1 / 255.0) - 1.0
         if fmaps is None:
-            image2 = 2 * (image2 / 255.0) - 1.0
-            f = self.fnet(torch.cat((image1, image2), dim=0))
+            f = self.encode_features(torch.cat((image1, image2), dim=0))
             fmap1, fmap2 = f[:N], f[N:]
         else:
             fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
         pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float())
-        cnet = self.cnet(image1)
+        if cnet is None:
+            cnet = self.encode_context(image1)
         c = self.hidden_dim
         hx = torch.empty(N, 3 * c, h8, w8, device=dev)
         rhx = torch.empty_like(hx)

@@ -164,3 +164,21 @@ def test_small_frames_without_weight_heads(rpe):
     assert float((pose.data.cpu() - opose).abs().max()) < 1e-4
     info = model.pose_head.problem.last_info.cpu()
     assert info[:, 0].tolist() == [2, 2] and info[:, 2].tolist() == [4, 4]      # max_iter 3 -> max_eval 3 -> 2 iterations
+
+
+def test_streaming_feature_reuse_is_exact(models):
+    """Re-using the encoder outputs of frame t's left image as frame t+1's image1l changes nothing but round-off."""
+    model, om, synth = models
+    from rpe_amd import pose_estimator
+    fr = synth.stereo_frames(9, 4, H, W)
+    K = fr['K'][0]
+    out = {}
+    for reuse in (True, False):
+        cfg = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=8, conf_weighing=True, reuse_features=reuse)
+        est = pose_estimator.PoseEstimator(cfg, K, 7.2 * 250.0, model, (W, H)).cuda()
+        poses = []
+        for i in range(4):
+            P, _, _, _ = est(fr['image2l'][i:i + 1].cuda(), fr['image2r'][i:i + 1].cuda(), fr['mask2'][i:i + 1].clone().cuda())
+            poses.append(P.data.reshape(7).cpu())
+        out[reuse] = torch.stack(poses)
+    assert float((out[True] - out[False]).abs().max()) < 1e-4          # mm scale after x250
