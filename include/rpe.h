@@ -92,6 +92,15 @@ int rpe_pose_solve(const float *flow, const float *pcl1, const float *pcl2, cons
                    int n, int h, int w, int mode, int iters, double *T_out, float *vec7, float *log6,
                    int32_t *info, void *workspace, void *stream);
 
+/* Same with torch.optim.LBFGS's remaining constructor arguments exposed (rpe_pose_solve uses its defaults
+ * tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, which is how pose_head.py:70 builds the optimiser).
+ * 1 <= history_size <= 100.  The tolerances also drive the Gauss-Newton step test. */
+int rpe_pose_solve_opts(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
+                        const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
+                        int n, int h, int w, int mode, int iters, double tolerance_grad, double tolerance_change,
+                        int history_size, double *T_out, float *vec7, float *log6, int32_t *info, void *workspace,
+                        void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Stereo depth, back-projection, flow warps and the 1/8 stacks of the weight heads -- replaces
  * core/pose/pose_net.py:73-79 (depth from disparity, validity, proj), :104-108 (remap_from_flow x3,

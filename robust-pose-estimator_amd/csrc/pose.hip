@@ -277,8 +277,10 @@ __device__ __forceinline__ double sum_partials(const double* partials, int row, 
     return s;
 }
 
+struct SolveOpts { double tol_grad, tol_change; int history; };
+
 __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform* uni, const double* partials, int nblk,
-                                                    const float* lw, int h, int w, int mode, int max_iter) {
+                                                    const float* lw, int h, int w, int mode, int max_iter, SolveOpts opt) {
     const int row = blockIdx.x, lane = threadIdx.x;
     RowState& S = states[row];
     if (S.stop != 0) return;
@@ -293,7 +295,8 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
     const double loss = (double)lw[row * 2 + 1] * loss2d + (double)lw[row * 2 + 0] * loss3d;
     double g[6];
     for (int i = 0; i < 6; ++i) g[i] = vals[2 + i];
-    const double tol_grad = 1e-7, tol_change = 1e-9, lr = 1.0;
+    const double tol_grad = opt.tol_grad, tol_change = opt.tol_change, lr = 1.0;
+    const int hist = opt.history;
 
     if (mode == RPE_SOLVER_GN) {
         S.n_iter += 1; S.evals += 1; S.loss = loss;
@@ -355,12 +358,12 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
         for (int i = 0; i < 6; ++i) { yk[i] = g[i] - S.prev_g[i]; sk[i] = S.d[i] * S.t; }
         double ys = dot6(yk, sk);
         if (ys > 1e-10) {
-            if (S.num_old == HIST) {
-                for (int k = 1; k < HIST; ++k) {
+            if (S.num_old == hist) {
+                for (int k = 1; k < hist; ++k) {
                     for (int i = 0; i < 6; ++i) { S.old_dirs[k - 1][i] = S.old_dirs[k][i]; S.old_stps[k - 1][i] = S.old_stps[k][i]; }
                     S.ro[k - 1] = S.ro[k];
                 }
-                S.num_old = HIST - 1;
+                S.num_old = hist - 1;
             }
             for (int i = 0; i < 6; ++i) { S.old_dirs[S.num_old][i] = yk[i]; S.old_stps[S.num_old][i] = sk[i]; }
             S.ro[S.num_old] = 1.0 / ys;
@@ -490,10 +493,28 @@ extern "C" int rpe_pose_reduce(const float* flow, const float* pcl1, const float
     return rpe_check_launch();
 }
 
+extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
+                                   const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
+                                   int n, int h, int w, int mode, int iters, double tolerance_grad, double tolerance_change,
+                                   int history_size, double* T_out, float* vec7, float* log6, int32_t* info,
+                                   void* workspace, void* stream);
+
 extern "C" int rpe_pose_solve(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
                               const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
                               int n, int h, int w, int mode, int iters, double* T_out, float* vec7, float* log6,
                               int32_t* info, void* workspace, void* stream) {
+    // torch.optim.LBFGS defaults, as DPoseSE3Head.solve constructs it (pose_head.py:70)
+    return rpe_pose_solve_opts(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w, mode, iters, 1e-7, 1e-9, HIST,
+                               T_out, vec7, log6, info, workspace, stream);
+}
+
+extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
+                                   const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
+                                   int n, int h, int w, int mode, int iters, double tolerance_grad, double tolerance_change,
+                                   int history_size, double* T_out, float* vec7, float* log6, int32_t* info,
+                                   void* workspace, void* stream) {
+    if (history_size < 1 || history_size > HIST || !(tolerance_grad >= 0.0) || !(tolerance_change >= 0.0)) return RPE_E_BADARG;
+    const SolveOpts opt{tolerance_grad, tolerance_change, history_size};
     if (!flow || !pcl1 || !pcl2 || !w1 || !w2 || !mask1 || !mask2 || !K || !loss_weight || !T_out || n <= 0 || h <= 0 || w <= 0 || iters < 0)
         return RPE_E_BADARG;
     if (mode != RPE_SOLVER_LBFGS && mode != RPE_SOLVER_GN) return RPE_E_BADARG;
@@ -508,7 +529,7 @@ extern "C" int rpe_pose_solve(const float* flow, const float* pcl1, const float*
     int evals = mode == RPE_SOLVER_LBFGS && iters == 0 ? 1 : iters;
     for (int it = 0; it < evals; ++it) {
         launch_reduce(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s);
-        hipLaunchKernelGGL(k_pose_update, dim3(n), dim3(64), 0, s, st, uni, (const double*)partials, nblk, loss_weight, h, w, mode, iters);
+        hipLaunchKernelGGL(k_pose_update, dim3(n), dim3(64), 0, s, st, uni, (const double*)partials, nblk, loss_weight, h, w, mode, iters, opt);
     }
     hipLaunchKernelGGL(k_pose_finalize, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, n, T_out, vec7, log6, info);
     return rpe_check_launch();

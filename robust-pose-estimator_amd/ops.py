@@ -118,7 +118,8 @@ def pose_reduce(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, T, need_
     return res
 
 
-def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mode=SOLVER_LBFGS):
+def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mode=SOLVER_LBFGS,
+               tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
     """Device-resident solve.  Returns (T f64 (n,7), vec7 f32 (n,7), log6 f32 (n,6), info int32 (n,4))."""
     args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
     dev = args[0].device
@@ -127,8 +128,9 @@ def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mo
     log6 = torch.empty(n, 6, dtype=torch.float32, device=dev)
     info = torch.empty(n, 4, dtype=torch.int32, device=dev)
     ws = _workspace(n, h, w, dev)
-    check(lib().rpe_pose_solve(*[ptr(a) for a in args], n, h, w, int(mode), int(iters), ptr(T), ptr(vec7), ptr(log6),
-                               ptr(info), ptr(ws), stream_ptr()), 'rpe_pose_solve')
+    check(lib().rpe_pose_solve_opts(*[ptr(a) for a in args], n, h, w, int(mode), int(iters), float(tolerance_grad),
+                                    float(tolerance_change), int(history_size), ptr(T), ptr(vec7), ptr(log6), ptr(info), ptr(ws),
+                                    stream_ptr()), 'rpe_pose_solve_opts')
     return T, vec7, log6, info
 
 

@@ -197,3 +197,20 @@ def test_tartanair_ground_truth_pose_recovered_on_hip(rpe):
         To, _ = solve(*args, iters=20)
         assert float((T.cpu() - To).abs().max()) < 1e-8
         assert float((se3.se3_matrix(T.cpu())[0] - g['rel_matrix']).abs().max()) < 2e-3
+
+
+def test_history_shift_and_tolerances(rpe):
+    """torch.optim.LBFGS keeps at most history_size (y, s) pairs and drops the oldest; with the stopping tests
+    disabled (tolerances 0) and a short history the shift runs many times.  Also the default-tolerance run."""
+    from rpe_amd import ops
+    c = synth.solver_case(31, 2, 24, 32, noise=0.3, sigma_t=0.05, sigma_r=0.05)
+    args = synth.solver_args(c)
+    for hist in (3, 100):
+        To, io = pose_head.lbfgs_solve(*args, iters=30, tolerance_change=0.0, tolerance_grad=0.0, history_size=hist)
+        T, _, _, info = ops.pose_solve(*dev(args), iters=30, tolerance_change=0.0, tolerance_grad=0.0, history_size=hist)
+        assert info[:, 0].cpu().tolist() == io['n_iter'].tolist() == [30, 30]
+        assert float((T.cpu() - To).abs().max()) < 1e-6, hist
+    Td, iod = pose_head.lbfgs_solve(*args, iters=140)
+    T, _, _, info = ops.pose_solve(*dev(args), iters=140)
+    assert info[:, 0].cpu().tolist() == iod['n_iter'].tolist() and info[:, 2].cpu().tolist() == iod['stop'].tolist()
+    assert float((T.cpu() - Td).abs().max()) < 1e-7
