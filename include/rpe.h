@@ -162,17 +162,19 @@ int rpe_corr_export_level(const void *pyramid, int b, int h8, int w8, int levels
  * RAFT update block, element-wise halves of SepConvGRU (core/RAFT/core/update.py) fused around the
  * convolutions, and the convex 8x up-sampling of RAFT.upsample_flow (core/RAFT/core/raft.py).
  * --------------------------------------------------------------------------------------------------------- */
-/* zr_pre (b,2c,hw): pre-activations (WITHOUT bias; zr_bias (2c) is added here, may be NULL) of the z and r
- * convolutions stacked on the channel axis; h is read from
+/* zr_pre (b,2c,hw): pre-activations (WITHOUT bias; zr_bias (2c) and the tensor zr_add (b,2c,hw) are added here, either
+ * may be NULL) of the z and r convolutions stacked on the channel axis.  zr_add carries the loop-invariant part of
+ * the convolution: the context features `inp` are the same in all GRU iterations, so conv(inp-channels) is computed
+ * once per RAFT pass and added here instead of being recomputed 12 times.  h is read from
  * channels [0,c) of a (b,h_channels,hw) buffer.  Writes z = sigmoid(zr_pre[:, :c]) to z_out (b,c,hw) and
  * r*h = sigmoid(zr_pre[:, c:]) * h into channels [0,c) of rh_out (b,rh_channels,hw), so rh_out can be the
  * (r*h | x) buffer the q convolution reads. */
-int rpe_gru_gates_zr(const float *zr_pre, const float *zr_bias, const float *h, int h_channels, int b, int c, int hw,
-                     float *z_out, float *rh_out, int rh_channels, void *stream);
-/* h_out = (1 - z) * h + z * tanh(q_pre + q_bias[c]) (q_bias may be NULL); h_out may alias h.  h / h_out are channels [0,c) of buffers with
+int rpe_gru_gates_zr(const float *zr_pre, const float *zr_bias, const float *zr_add, const float *h, int h_channels,
+                     int b, int c, int hw, float *z_out, float *rh_out, int rh_channels, void *stream);
+/* h_out = (1 - z) * h + z * tanh(q_pre + q_add + q_bias[c]) (q_bias (c), q_add (b,c,hw) may be NULL); h_out may alias h.  h / h_out are channels [0,c) of buffers with
  * h_channels / hout_channels channels per batch row, so the new state lands straight in the (h|x) buffer. */
-int rpe_gru_gates_h(const float *z, const float *q_pre, const float *q_bias, const float *h, int h_channels, int b, int c,
-                    int hw, float *h_out, int hout_channels, void *stream);
+int rpe_gru_gates_h(const float *z, const float *q_pre, const float *q_bias, const float *q_add, const float *h,
+                    int h_channels, int b, int c, int hw, float *h_out, int hout_channels, void *stream);
 /* y = act(x + bias[c]) for x (b,c,hw): the bias add, ReLU (relu != 0) and the torch.cat / copy_ that follow a
  * convolution of the update block (core/RAFT/core/update.py BasicMotionEncoder / FlowHead), in one pass.  The result
  * goes to channels [out1_offset, out1_offset+c) of out1 (b,out1_channels,hw) and, if out2 != NULL, also to out2.

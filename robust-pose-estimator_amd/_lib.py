@@ -39,8 +39,8 @@ SIGNATURES = {
     'rpe_corr_lookup': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup_taps': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_corr_export_level': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'rpe_gru_gates_zr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
-    'rpe_gru_gates_h': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'rpe_gru_gates_zr': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'rpe_gru_gates_h': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'rpe_bias_act': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     'rpe_instnorm_act': (_i, [_vp, _vp, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
     'rpe_affine_act': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

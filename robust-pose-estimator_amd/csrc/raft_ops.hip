@@ -12,7 +12,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // zr_pre (b,2c,hw) ; h (b, h_ch, hw) channels [0,c) ; z_out (b,c,hw) ; rh_out (b, rh_ch, hw) channels [0,c)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, const float* __restrict__ bias,
-                                                  const float* __restrict__ h, int c, int hw,
+                                                  const float* __restrict__ add, const float* __restrict__ h, int c, int hw,
                                                   int h_ch, float* __restrict__ z_out, float* __restrict__ rh, int rh_ch) {
     const int bz = blockIdx.y;
     const size_t per = (size_t)c * hw;
@@ -26,12 +26,17 @@ __global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, 
         float* ro = rh + (size_t)bz * rh_ch * hw + e;
         if (VEC == 4) {
             float4 zv = *(const float4*)zp, rv = *(const float4*)rp, hv = *(const float4*)hp;
+            if (add) {
+                const float4 az = *(const float4*)(add + (size_t)bz * 2 * per + e), ar = *(const float4*)(add + (size_t)bz * 2 * per + per + e);
+                zv.x += az.x; zv.y += az.y; zv.z += az.z; zv.w += az.w; rv.x += ar.x; rv.y += ar.y; rv.z += ar.z; rv.w += ar.w;
+            }
             float4 zz = make_float4(sigmoidf_(zv.x + bzv), sigmoidf_(zv.y + bzv), sigmoidf_(zv.z + bzv), sigmoidf_(zv.w + bzv));
             float4 rr = make_float4(sigmoidf_(rv.x + brv) * hv.x, sigmoidf_(rv.y + brv) * hv.y, sigmoidf_(rv.z + brv) * hv.z,
                                     sigmoidf_(rv.w + brv) * hv.w);
             *(float4*)zo = zz; *(float4*)ro = rr;
         } else {
-            zo[0] = sigmoidf_(zp[0] + bzv); ro[0] = sigmoidf_(rp[0] + brv) * hp[0];
+            const float az = add ? add[(size_t)bz * 2 * per + e] : 0.0f, ar = add ? add[(size_t)bz * 2 * per + per + e] : 0.0f;
+            zo[0] = sigmoidf_(zp[0] + az + bzv); ro[0] = sigmoidf_(rp[0] + ar + brv) * hp[0];
         }
     }
 }
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void k_gates_zr(const float* __restrict__ zr, 
 // h_out = (1 - z) * h + z * tanh(q_pre)
 template <int VEC>
 __global__ __launch_bounds__(256) void k_gates_h(const float* __restrict__ z, const float* __restrict__ q,
-                                                 const float* __restrict__ bias, const float* h, int c,
+                                                 const float* __restrict__ bias, const float* __restrict__ add, const float* h, int c,
                                                  int hw, int h_ch, float* h_out, int ho_ch) {
     const int bz = blockIdx.y;
     const size_t per = (size_t)c * hw;
@@ -51,12 +56,13 @@ __global__ __launch_bounds__(256) void k_gates_h(const float* __restrict__ z, co
         float* ho = h_out + (size_t)bz * ho_ch * hw + e;
         if (VEC == 4) {
             float4 zv = *(const float4*)zp, qv = *(const float4*)qp, hv = *(const float4*)hp;
+            if (add) { const float4 aq = *(const float4*)(add + (size_t)bz * per + e); qv.x += aq.x; qv.y += aq.y; qv.z += aq.z; qv.w += aq.w; }
             float4 o;
             o.x = (1.0f - zv.x) * hv.x + zv.x * tanhf(qv.x + bq); o.y = (1.0f - zv.y) * hv.y + zv.y * tanhf(qv.y + bq);
             o.z = (1.0f - zv.z) * hv.z + zv.z * tanhf(qv.z + bq); o.w = (1.0f - zv.w) * hv.w + zv.w * tanhf(qv.w + bq);
             *(float4*)ho = o;
         } else {
-            ho[0] = (1.0f - zp[0]) * hp[0] + zp[0] * tanhf(qp[0] + bq);
+            ho[0] = (1.0f - zp[0]) * hp[0] + zp[0] * tanhf(qp[0] + (add ? add[(size_t)bz * per + e] : 0.0f) + bq);
         }
     }
 }
@@ -233,25 +239,25 @@ extern "C" int rpe_bias_act(const float* x, const float* bias, int b, int c, int
     return rpe_check_launch();
 }
 
-extern "C" int rpe_gru_gates_zr(const float* zr_pre, const float* zr_bias, const float* h, int h_channels, int b, int c, int hw,
-                                float* z_out, float* rh_out, int rh_channels, void* stream) {
+extern "C" int rpe_gru_gates_zr(const float* zr_pre, const float* zr_bias, const float* zr_add, const float* h, int h_channels,
+                                int b, int c, int hw, float* z_out, float* rh_out, int rh_channels, void* stream) {
     if (!zr_pre || !h || !z_out || !rh_out || b <= 0 || c <= 0 || hw <= 0 || h_channels < c || rh_channels < c) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     size_t per = (size_t)c * hw;
-    bool v4 = hw % 4 == 0 && vec_ok(zr_pre) && vec_ok(h) && vec_ok(z_out) && vec_ok(rh_out);
-    if (v4) hipLaunchKernelGGL(k_gates_zr<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, zr_pre, zr_bias, h, c, hw, h_channels, z_out, rh_out, rh_channels);
-    else hipLaunchKernelGGL(k_gates_zr<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, zr_pre, zr_bias, h, c, hw, h_channels, z_out, rh_out, rh_channels);
+    bool v4 = hw % 4 == 0 && vec_ok(zr_pre) && vec_ok(h) && vec_ok(z_out) && vec_ok(rh_out) && (!zr_add || vec_ok(zr_add));
+    if (v4) hipLaunchKernelGGL(k_gates_zr<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, zr_pre, zr_bias, zr_add, h, c, hw, h_channels, z_out, rh_out, rh_channels);
+    else hipLaunchKernelGGL(k_gates_zr<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, zr_pre, zr_bias, zr_add, h, c, hw, h_channels, z_out, rh_out, rh_channels);
     return rpe_check_launch();
 }
 
-extern "C" int rpe_gru_gates_h(const float* z, const float* q_pre, const float* q_bias, const float* h, int h_channels, int b,
-                               int c, int hw, float* h_out, int hout_channels, void* stream) {
+extern "C" int rpe_gru_gates_h(const float* z, const float* q_pre, const float* q_bias, const float* q_add, const float* h,
+                               int h_channels, int b, int c, int hw, float* h_out, int hout_channels, void* stream) {
     if (!z || !q_pre || !h || !h_out || b <= 0 || c <= 0 || hw <= 0 || h_channels < c || hout_channels < c) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     size_t per = (size_t)c * hw;
-    bool v4 = hw % 4 == 0 && vec_ok(z) && vec_ok(q_pre) && vec_ok(h) && vec_ok(h_out);
-    if (v4) hipLaunchKernelGGL(k_gates_h<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, z, q_pre, q_bias, h, c, hw, h_channels, h_out, hout_channels);
-    else hipLaunchKernelGGL(k_gates_h<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, z, q_pre, q_bias, h, c, hw, h_channels, h_out, hout_channels);
+    bool v4 = hw % 4 == 0 && vec_ok(z) && vec_ok(q_pre) && vec_ok(h) && vec_ok(h_out) && (!q_add || vec_ok(q_add));
+    if (v4) hipLaunchKernelGGL(k_gates_h<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, z, q_pre, q_bias, q_add, h, c, hw, h_channels, h_out, hout_channels);
+    else hipLaunchKernelGGL(k_gates_h<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, z, q_pre, q_bias, q_add, h, c, hw, h_channels, h_out, hout_channels);
     return rpe_check_launch();
 }
 

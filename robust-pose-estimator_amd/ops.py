@@ -228,19 +228,23 @@ def _nchw(t, name):
     return t
 
 
-def gru_gates_zr(zr_pre, h_buf, c, z_out, rh_buf, bias=None):
-    """z_out = sigmoid(zr_pre[:, :c] + bias[:c]); rh_buf[:, :c] = sigmoid(zr_pre[:, c:] + bias[c:]) * h_buf[:, :c]."""
+def gru_gates_zr(zr_pre, h_buf, c, z_out, rh_buf, bias=None, add=None):
+    """z_out = sigmoid(zr_pre[:, :c] + add[:, :c] + bias[:c]); rh_buf[:, :c] = sigmoid(zr_pre[:, c:] + ...) * h_buf[:, :c]."""
     _nchw(zr_pre, 'zr_pre'); _nchw(h_buf, 'h_buf'); _nchw(z_out, 'z_out'); _nchw(rh_buf, 'rh_buf')
+    if add is not None and _nchw(add, 'add').shape != zr_pre.shape:
+        raise _lib.RpeError('gru_gates_zr: add must have the shape of zr_pre')
     b, c2, hh, ww = zr_pre.shape
-    check(lib().rpe_gru_gates_zr(ptr(zr_pre), ptr(bias), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(z_out), ptr(rh_buf),
-                                 rh_buf.shape[1], stream_ptr()), 'rpe_gru_gates_zr')
+    check(lib().rpe_gru_gates_zr(ptr(zr_pre), ptr(bias), ptr(add), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(z_out),
+                                 ptr(rh_buf), rh_buf.shape[1], stream_ptr()), 'rpe_gru_gates_zr')
 
 
-def gru_gates_h(z, q_pre, h_buf, c, h_out, bias=None):
-    """h_out[:, :c] = (1 - z) * h_buf[:, :c] + z * tanh(q_pre + bias)."""
+def gru_gates_h(z, q_pre, h_buf, c, h_out, bias=None, add=None):
+    """h_out[:, :c] = (1 - z) * h_buf[:, :c] + z * tanh(q_pre + add + bias)."""
     _nchw(z, 'z'); _nchw(q_pre, 'q_pre'); _nchw(h_buf, 'h_buf'); _nchw(h_out, 'h_out')
+    if add is not None and _nchw(add, 'add').shape != q_pre.shape:
+        raise _lib.RpeError('gru_gates_h: add must have the shape of q_pre')
     b, _, hh, ww = q_pre.shape
-    check(lib().rpe_gru_gates_h(ptr(z), ptr(q_pre), ptr(bias), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(h_out),
+    check(lib().rpe_gru_gates_h(ptr(z), ptr(q_pre), ptr(bias), ptr(add), ptr(h_buf), h_buf.shape[1], b, c, hh * ww, ptr(h_out),
                                 h_out.shape[1], stream_ptr()), 'rpe_gru_gates_h')
 
 

@@ -9,6 +9,9 @@ What runs where (MI355X-first split):
     up-sampling: hand-written HIP (csrc/corr.hip, csrc/raft_ops.hip) through the C ABI
 Exact re-associations used (results identical up to float rounding of the conv library):
   * convz/convr of each GRU half share their input, so their weights are stacked into one 256-channel conv
+  * the GRU input is (h | inp | motion | flow) and the context `inp` is the same in all 12 iterations, so the
+    inp-channel part of every GRU convolution (+ bias) is computed once per pass and added inside the gate kernels:
+    the per-iteration convolutions read 256 instead of 384 channels (a third of the GRU's FLOPs hoisted out of the loop)
   * the (h | x) concatenations live in two persistent buffers; the gate kernels write r*h and the new h in place
   * the mask head + convex up-sampling only run for the predictions that are returned (``all_flows=False``
     returns just the final one, which is all the reference's PoseNet reads: ``[0][-1]``)
@@ -147,7 +150,7 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr, cat_buf, hx, rhx):
-        """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [256,384) of hx and rhx.
+        """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [128,256) of hx and rhx.
         Convolutions run without bias; bias + ReLU (+ the cat / copies) are one HIP pass each (rpe_bias_act)."""
         def cv(m, x):
             return F.conv2d(x, m.weight, None, m.stride, m.padding)
@@ -155,8 +158,8 @@ class BasicMotionEncoder(nn.Module):
         ops.bias_act(cv(self.convc2, cor), self.convc2.bias, out=cat_buf, out_offset=0)
         flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)
         ops.bias_act(cv(self.convf2, flo), self.convf2.bias, out=cat_buf, out_offset=192)
-        ops.bias_act(cv(self.conv, cat_buf), self.conv.bias, out=hx, out_offset=256, out2=rhx, out2_offset=256)
-        ops.bias_act(flow, None, relu=False, out=hx, out_offset=382, out2=rhx, out2_offset=382)
+        ops.bias_act(cv(self.conv, cat_buf), self.conv.bias, out=hx, out_offset=128, out2=rhx, out2_offset=128)
+        ops.bias_act(flow, None, relu=False, out=hx, out_offset=254, out2=rhx, out2_offset=254)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -170,35 +173,49 @@ class BasicUpdateBlock(nn.Module):
                                   nn.Conv2d(256, 64 * 9, 1, padding=0))
         self._stacked = None
 
-    def stacked_gate_weights(self):
-        """convz|convr stacked on the output-channel axis (they read the same input)."""
+    def gate_weights(self):
+        """GRU conv weights re-arranged once (cached until a parameter changes):
+          * convz|convr stacked on the output-channel axis (they read the same input),
+          * input channels split into the loop-varying part [h | motion | flow] (256 ch) and the context part
+            `inp` (128 ch, identical in every GRU iteration).
+        Returns dict name -> (w_var, w_ctx, bias) for 'zr1', 'q1', 'zr2', 'q2'."""
         g = self.gru
         key = tuple(p._version for p in g.parameters()) + tuple(p.data_ptr() for p in g.parameters())
         if self._stacked is None or self._stacked[0] != key:
-            w1 = torch.cat((g.convz1.weight, g.convr1.weight), 0).detach().contiguous()
-            b1 = torch.cat((g.convz1.bias, g.convr1.bias), 0).detach().contiguous()
-            w2 = torch.cat((g.convz2.weight, g.convr2.weight), 0).detach().contiguous()
-            b2 = torch.cat((g.convz2.bias, g.convr2.bias), 0).detach().contiguous()
-            self._stacked = (key, (w1, b1, w2, b2))
+            c = self.hidden_dim
+
+            def split(w):                      # (out, 384, kh, kw) -> varying (out,256,..), context (out,128,..)
+                return torch.cat((w[:, :c], w[:, 2 * c:]), 1).detach().contiguous(), w[:, c:2 * c].detach().contiguous()
+            W = {}
+            for name, convs in (('zr1', (g.convz1, g.convr1)), ('q1', (g.convq1,)), ('zr2', (g.convz2, g.convr2)), ('q2', (g.convq2,))):
+                w = torch.cat([m.weight for m in convs], 0)
+                bvec = torch.cat([m.bias for m in convs], 0).detach().contiguous()
+                W[name] = (*split(w), bvec)
+            self._stacked = (key, W)
         return self._stacked[1]
 
-    def step(self, hx, rhx, z_buf, cat_buf, h_buf, corr, flow):
-        """One update.  hx = (h | inp | motion | flow) buffer, rhx = (r*h | same x) buffer; both (b,384,h,w).
+    def context_terms(self, inp):
+        """conv(inp; context channels) + bias of the four GRU convolutions: loop-invariant, computed once per pass."""
+        W = self.gate_weights()
+        pads = {'zr1': (0, 2), 'q1': (0, 2), 'zr2': (2, 0), 'q2': (2, 0)}
+        return {k: F.conv2d(inp, W[k][1], W[k][2], padding=pads[k]) for k in W}
+
+    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow):
+        """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
         Returns delta_flow; the new hidden state is left in hx[:, :128] (and, contiguous, in h_buf)."""
         c = self.hidden_dim
-        g = self.gru
         self.encoder(flow, corr, cat_buf, hx, rhx)
-        w1, b1, w2, b2 = self.stacked_gate_weights()
+        W = self.gate_weights()
         # horizontal half: z = s(convz1 hx), r = s(convr1 hx), q = tanh(convq1 [r*h, x]), h = (1-z) h + z q
-        zr = F.conv2d(hx, w1, None, padding=(0, 2))
-        ops.gru_gates_zr(zr, hx, c, z_buf, rhx, bias=b1)
-        q = F.conv2d(rhx, g.convq1.weight, None, padding=(0, 2))
-        ops.gru_gates_h(z_buf, q, hx, c, hx, bias=g.convq1.bias)
+        zr = F.conv2d(hx, W['zr1'][0], None, padding=(0, 2))
+        ops.gru_gates_zr(zr, hx, c, z_buf, rhx, add=ctx['zr1'])
+        q = F.conv2d(rhx, W['q1'][0], None, padding=(0, 2))
+        ops.gru_gates_h(z_buf, q, hx, c, hx, add=ctx['q1'])
         # vertical half
-        zr = F.conv2d(hx, w2, None, padding=(2, 0))
-        ops.gru_gates_zr(zr, hx, c, z_buf, rhx, bias=b2)
-        q = F.conv2d(rhx, g.convq2.weight, None, padding=(2, 0))
-        ops.gru_gates_h(z_buf, q, hx, c, hx, bias=g.convq2.bias)
+        zr = F.conv2d(hx, W['zr2'][0], None, padding=(2, 0))
+        ops.gru_gates_zr(zr, hx, c, z_buf, rhx, add=ctx['zr2'])
+        q = F.conv2d(rhx, W['q2'][0], None, padding=(2, 0))
+        ops.gru_gates_h(z_buf, q, hx, c, hx, add=ctx['q2'])
         h_buf.copy_(hx[:, :c])                                            # contiguous h for the heads
         fh = self.flow_head
         t = ops.bias_act(F.conv2d(h_buf, fh.conv1.weight, None, padding=1), fh.conv1.bias)
@@ -267,15 +284,14 @@ class RAFT(nn.Module):
         if cnet is None:
             cnet = self.encode_context(image1)
         c = self.hidden_dim
-        hx = torch.empty(N, 3 * c, h8, w8, device=dev)
+        hx = torch.empty(N, 2 * c, h8, w8, device=dev)        # (h | motion | flow); the context lives in ctx
         rhx = torch.empty_like(hx)
         z_buf = torch.empty(N, c, h8, w8, device=dev)
         h_buf = torch.empty(N, c, h8, w8, device=dev)
         cat_buf = torch.empty(N, 2 * c, h8, w8, device=dev)
         torch.tanh(cnet[:, :c], out=hx[:, :c])
         inp = torch.relu(cnet[:, c:])
-        hx[:, c:2 * c].copy_(inp)
-        rhx[:, c:2 * c].copy_(inp)
+        ctx = self.update_block.context_terms(inp)
         coords0 = coords_grid(N, h8, w8, dev)
         coords1 = coords0.clone()
         corr = torch.empty(N, self.corr_levels * (2 * self.corr_radius + 1) ** 2, h8, w8, device=dev)
@@ -283,7 +299,7 @@ class RAFT(nn.Module):
         for itr in range(iters):
             pyr.lookup(coords1, out=corr)
             flow = coords1 - coords0
-            delta = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, corr, flow)
+            delta = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow)
             coords1 = coords1 + delta
             if all_flows or itr == iters - 1:
                 lowres = coords1 - coords0

@@ -34,7 +34,9 @@ with torch.no_grad():
     hx = torch.randn(N, 384, 64, 80, device=dev); h = torch.randn(N, 128, 64, 80, device=dev)
     print('motion enc NCHW: %.2f ms' % t(lambda: ub.encoder(flow, corr)))
     print('flow head  NCHW: %.2f ms' % t(lambda: ub.flow_head(h)))
-    w1, b1, w2, b2 = ub.stacked_gate_weights()
+    g = ub.gru
+    w1 = torch.cat((g.convz1.weight, g.convr1.weight), 0).detach(); b1 = torch.cat((g.convz1.bias, g.convr1.bias), 0).detach()
+    w2 = torch.cat((g.convz2.weight, g.convr2.weight), 0).detach(); b2 = torch.cat((g.convz2.bias, g.convr2.bias), 0).detach()
     F = torch.nn.functional
     print('gru zr1 (1x5, 384->256) NCHW: %.2f ms' % t(lambda: F.conv2d(hx, w1, b1, padding=(0, 2))))
     print('gru q1  (1x5, 384->128) NCHW: %.2f ms' % t(lambda: ub.gru.convq1(hx)))

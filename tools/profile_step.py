@@ -47,9 +47,9 @@ def main():
         pyr = R._pyramid(N, h8, w8, dev).build(f[:N].float(), f[N:].float())
         mark('corr_build')
         c = 128
-        hx = torch.empty(N, 3 * c, h8, w8, device=dev); rhx = torch.empty_like(hx); z = torch.empty(N, c, h8, w8, device=dev)
+        hx = torch.empty(N, 2 * c, h8, w8, device=dev); rhx = torch.empty_like(hx); z = torch.empty(N, c, h8, w8, device=dev)
         hb = torch.empty(N, c, h8, w8, device=dev); catb = torch.empty(N, 2 * c, h8, w8, device=dev); F = torch.nn.functional
-        torch.tanh(cnet[:, :c], out=hx[:, :c]); inp = torch.relu(cnet[:, c:]); hx[:, c:2*c].copy_(inp); rhx[:, c:2*c].copy_(inp)
+        torch.tanh(cnet[:, :c], out=hx[:, :c]); inp = torch.relu(cnet[:, c:]); ctx = ub.context_terms(inp); GW = ub.gate_weights()
         c0 = raft_mod.coords_grid(N, h8, w8, dev); c1 = c0.clone()
         corr = torch.empty(N, 324, h8, w8, device=dev)
         mark('init')
@@ -58,11 +58,10 @@ def main():
             pyr.lookup(c1, out=corr); mark('lookup')
             flow = c1 - c0
             ub.encoder(flow, corr, catb, hx, rhx); mark('motion_enc')
-            w1, b1, w2, b2 = ub.stacked_gate_weights()
-            zr = F.conv2d(hx, w1, None, padding=(0, 2)); ops.gru_gates_zr(zr, hx, c, z, rhx, bias=b1)
-            q = F.conv2d(rhx, ub.gru.convq1.weight, None, padding=(0, 2)); ops.gru_gates_h(z, q, hx, c, hx, bias=ub.gru.convq1.bias)
-            zr = F.conv2d(hx, w2, None, padding=(2, 0)); ops.gru_gates_zr(zr, hx, c, z, rhx, bias=b2)
-            q = F.conv2d(rhx, ub.gru.convq2.weight, None, padding=(2, 0)); ops.gru_gates_h(z, q, hx, c, hx, bias=ub.gru.convq2.bias); mark('gru')
+            zr = F.conv2d(hx, GW['zr1'][0], None, padding=(0, 2)); ops.gru_gates_zr(zr, hx, c, z, rhx, add=ctx['zr1'])
+            q = F.conv2d(rhx, GW['q1'][0], None, padding=(0, 2)); ops.gru_gates_h(z, q, hx, c, hx, add=ctx['q1'])
+            zr = F.conv2d(hx, GW['zr2'][0], None, padding=(2, 0)); ops.gru_gates_zr(zr, hx, c, z, rhx, add=ctx['zr2'])
+            q = F.conv2d(rhx, GW['q2'][0], None, padding=(2, 0)); ops.gru_gates_h(z, q, hx, c, hx, add=ctx['q2']); mark('gru')
             hb.copy_(hx[:, :c]); fh = ub.flow_head
             d = fh.conv2(ops.bias_act(F.conv2d(hb, fh.conv1.weight, None, padding=1), fh.conv1.bias)); c1 = c1 + d; mark('flow_head')
         up = ops.upsample_convex(c1 - c0, ub.up_mask(hb)); mark('mask+upsample')
