@@ -1,72 +1,64 @@
-"""Oracle (test infrastructure): TinyUNet weight head, restating core/unet/unet.py:7-82 of the reference
-(valid 3x3 convs, BN, 2x2 transposed-conv up, centre-crop skips, 1x1 head, bilinear resize).
-Note DownBlock is conv-norm-relu-conv (:15-16) while UpBlock is conv-relu-norm-conv (:18-20)."""
+"""Oracle (test infrastructure): the TinyUNet weight head as one functional forward over a parameter tree.
+
+Restates core/unet/unet.py:7-82 of the reference: three encoder stages of (3x3 valid conv -> BatchNorm -> ReLU ->
+3x3 valid conv) with 2x2 max-pooling in between, two decoder stages of (2x2 stride-2 transposed conv, centre-cropped
+skip concatenation, 3x3 valid conv -> ReLU -> BatchNorm -> 3x3 valid conv -- note the norm/ReLU order differs from the
+encoder, :15-16 vs :18-20), a 1x1 head and a bilinear resize to the image size.  Only the parameter names are shared
+with the reference (``encoder.enc_blocks.i.{conv1,norm,conv2}``, ``decoder.upconvs.i``, ``decoder.dec_blocks.i...``,
+``head``) so that its checkpoints load; the computation is written out with torch.nn.functional calls."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+WIDTHS = (16, 32, 64)
 
-class DownBlock(nn.Module):
-    def __init__(self, in_ch, out_ch):
+
+def _stage(cin, cout):
+    return nn.ModuleDict(dict(conv1=nn.Conv2d(cin, cout, 3), norm=nn.BatchNorm2d(cout), conv2=nn.Conv2d(cout, cout, 3)))
+
+
+class _Params(nn.Module):
+    """A bare namespace of sub-modules (gives the state-dict its prefix)."""
+
+    def __init__(self, **mods):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_ch, out_ch, 3)
-        self.norm = nn.BatchNorm2d(out_ch)
-        self.relu = nn.ReLU()
-        self.conv2 = nn.Conv2d(out_ch, out_ch, 3)
-
-    def forward(self, x):
-        return self.conv2(self.relu(self.norm(self.conv1(x))))
+        for k, v in mods.items():
+            setattr(self, k, v)
 
 
-class UpBlock(DownBlock):
-    def forward(self, x):
-        return self.conv2(self.norm(self.relu(self.conv1(x))))
+def _bn(m, x):
+    return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
 
 
-class Encoder(nn.Module):
-    def __init__(self, chs):
-        super().__init__()
-        self.enc_blocks = nn.ModuleList([DownBlock(chs[i], chs[i + 1]) for i in range(len(chs) - 1)])
-        self.pool = nn.MaxPool2d(2)
-
-    def forward(self, x):
-        ftrs = []
-        for block in self.enc_blocks:
-            x = block(x)
-            ftrs.append(x)
-            x = self.pool(x)
-        return ftrs
+def _conv(m, x):
+    return F.conv2d(x, m.weight, m.bias)
 
 
-class Decoder(nn.Module):
-    def __init__(self, chs):
-        super().__init__()
-        self.chs = chs
-        self.upconvs = nn.ModuleList([nn.ConvTranspose2d(chs[i], chs[i + 1], 2, 2) for i in range(len(chs) - 1)])
-        self.dec_blocks = nn.ModuleList([UpBlock(chs[i], chs[i + 1]) for i in range(len(chs) - 1)])
-
-    def forward(self, x, encoder_features):
-        for i in range(len(self.chs) - 1):
-            x = self.upconvs[i](x)
-            e = encoder_features[i]
-            H, W = x.shape[-2:]
-            H2, W2 = e.shape[-2:]
-            dh, dw = (H2 - H) // 2, (W2 - W) // 2
-            e = e[..., dh:(H2 - dh), dw:(W2 - dw)]
-            x = self.dec_blocks[i](torch.cat([x, e], dim=1))
-        return x
+def _centre_crop(t, h, w):
+    dh, dw = (t.shape[-2] - h) // 2, (t.shape[-1] - w) // 2
+    return t[..., dh:t.shape[-2] - dh, dw:t.shape[-1] - dw]
 
 
 class TinyUNet(nn.Module):
     def __init__(self, in_channels, output_size):
         super().__init__()
-        self.encoder = Encoder((in_channels, 16, 32, 64))
-        self.decoder = Decoder((64, 32, 16))
-        self.head = nn.Conv2d(16, 1, 1)
+        down = (in_channels,) + WIDTHS
+        up = WIDTHS[::-1]
+        self.encoder = _Params(enc_blocks=nn.ModuleList(_stage(down[i], down[i + 1]) for i in range(3)))
+        self.decoder = _Params(upconvs=nn.ModuleList(nn.ConvTranspose2d(up[i], up[i + 1], 2, 2) for i in range(2)),
+                               dec_blocks=nn.ModuleList(_stage(up[i], up[i + 1]) for i in range(2)))
+        self.head = nn.Conv2d(WIDTHS[0], 1, 1)
         self.out_sz = output_size
 
     def forward(self, x):
-        enc = self.encoder(x)
-        out = self.decoder(enc[::-1][0], enc[::-1][1:])
-        out = self.head(out)
-        return F.interpolate(out, self.out_sz, mode='bilinear')
+        skips = []
+        for st in self.encoder.enc_blocks:
+            x = _conv(st['conv2'], F.relu(_bn(st['norm'], _conv(st['conv1'], x))))
+            skips.append(x)
+            x = F.max_pool2d(x, 2)          # the reference pools after the last stage too (result unused) -- so the
+        x = skips.pop()                     # smallest admissible 1/8 grid is 44x44, as there
+        for up, st in zip(self.decoder.upconvs, self.decoder.dec_blocks):
+            x = F.conv_transpose2d(x, up.weight, up.bias, stride=2)
+            x = torch.cat((x, _centre_crop(skips.pop(), *x.shape[-2:])), dim=1)
+            x = _conv(st['conv2'], _bn(st['norm'], F.relu(_conv(st['conv1'], x))))
+        return F.interpolate(_conv(self.head, x), self.out_sz, mode='bilinear')

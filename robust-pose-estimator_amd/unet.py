@@ -1,73 +1,77 @@
-"""TinyUNet weight head -- stays on PyTorch-ROCm (north star).
+"""TinyUNet weight head on the GPU: convolutions on PyTorch-ROCm (MIOpen), every epilogue a fused HIP pass.
 
-Host-side mirror of the reference's core/unet/unet.py:7-82 with identical parameter names, so reference
-checkpoints load unchanged: valid 3x3 convs, BatchNorm, 2x2 transposed-conv up-sampling, centre-cropped
-skips, 1x1 head, bilinear resize to (H, W).  DownBlock = conv-norm-relu-conv (:15-16); UpBlock =
-conv-relu-norm-conv (:18-20)."""
+Host mirror of the reference's ``TinyUNet(in_channels, output_size)`` (core/unet/unet.py:80-82; architecture :7-77)
+with its parameter names (``encoder.enc_blocks.i.conv1/norm/conv2``, ``decoder.upconvs.i``, ``decoder.dec_blocks.i``,
+``head``) so checkpoints load unchanged.  Inference only: the batch norms run frozen and are folded, together with
+the preceding conv bias, into one per-channel affine map applied by ``rpe_affine_act``:
+    encoder stage : conv1 (no bias) -> [affine + ReLU]                 -> conv2            (conv-norm-relu-conv, :15-16)
+    decoder stage : conv1 (no bias) -> [bias + ReLU] -> [affine]       -> conv2            (conv-relu-norm-conv, :18-20)
+The north star keeps the heads' convolutions on PyTorch-ROCm; they cost ~1 ms per 16-frame step."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 
-class DownBlock(nn.Module):
-    def __init__(self, in_ch, out_ch):
+WIDTHS = (16, 32, 64)
+
+
+class _Stage(nn.Module):
+    def __init__(self, cin, cout):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_ch, out_ch, 3)
-        self.norm = nn.BatchNorm2d(out_ch)
-        self.relu = nn.ReLU()
-        self.conv2 = nn.Conv2d(out_ch, out_ch, 3)
+        self.conv1 = nn.Conv2d(cin, cout, 3)
+        self.norm = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3)
 
-    def forward(self, x):
-        return self.conv2(self.relu(self.norm(self.conv1(x))))
+    def folded_norm(self, with_conv_bias):
+        """Frozen BN as y = x*scale + shift; optionally absorbing conv1's bias (when the norm directly follows conv1)."""
+        n = self.norm
+        if n.training:
+            raise RuntimeError('TinyUNet runs with frozen batch norm (inference only)')
+        scale = (n.weight / torch.sqrt(n.running_var + n.eps)).detach()
+        shift = n.bias.detach() - n.running_mean * scale
+        if with_conv_bias:
+            shift = shift + self.conv1.bias.detach() * scale
+        return scale.contiguous(), shift.contiguous()
 
 
-class UpBlock(DownBlock):
-    def forward(self, x):
-        return self.conv2(self.norm(self.relu(self.conv1(x))))
-
-
-class Encoder(nn.Module):
-    def __init__(self, chs):
+class _Tree(nn.Module):
+    def __init__(self, **mods):
         super().__init__()
-        self.enc_blocks = nn.ModuleList([DownBlock(chs[i], chs[i + 1]) for i in range(len(chs) - 1)])
-        self.pool = nn.MaxPool2d(2)
-
-    def forward(self, x):
-        ftrs = []
-        for block in self.enc_blocks:
-            x = block(x)
-            ftrs.append(x)
-            x = self.pool(x)
-        return ftrs
-
-
-class Decoder(nn.Module):
-    def __init__(self, chs):
-        super().__init__()
-        self.chs = chs
-        self.upconvs = nn.ModuleList([nn.ConvTranspose2d(chs[i], chs[i + 1], 2, 2) for i in range(len(chs) - 1)])
-        self.dec_blocks = nn.ModuleList([UpBlock(chs[i], chs[i + 1]) for i in range(len(chs) - 1)])
-
-    def forward(self, x, encoder_features):
-        for i in range(len(self.chs) - 1):
-            x = self.upconvs[i](x)
-            e = encoder_features[i]
-            H, W = x.shape[-2:]
-            H2, W2 = e.shape[-2:]
-            dh, dw = (H2 - H) // 2, (W2 - W) // 2
-            x = self.dec_blocks[i](torch.cat([x, e[..., dh:(H2 - dh), dw:(W2 - dw)]], dim=1))
-        return x
+        for k, v in mods.items():
+            setattr(self, k, v)
 
 
 class TinyUNet(nn.Module):
     def __init__(self, in_channels, output_size):
         super().__init__()
-        self.encoder = Encoder((in_channels, 16, 32, 64))
-        self.decoder = Decoder((64, 32, 16))
-        self.head = nn.Conv2d(16, 1, 1)
+        down = (in_channels,) + WIDTHS
+        up = WIDTHS[::-1]
+        self.encoder = _Tree(enc_blocks=nn.ModuleList(_Stage(down[i], down[i + 1]) for i in range(3)))
+        self.decoder = _Tree(upconvs=nn.ModuleList(nn.ConvTranspose2d(up[i], up[i + 1], 2, 2) for i in range(2)),
+                             dec_blocks=nn.ModuleList(_Stage(up[i], up[i + 1]) for i in range(2)))
+        self.head = nn.Conv2d(WIDTHS[0], 1, 1)
         self.out_sz = output_size
 
+    @torch.no_grad()
     def forward(self, x):
-        enc = self.encoder(x)
-        out = self.decoder(enc[::-1][0], enc[::-1][1:])
-        return F.interpolate(self.head(out), self.out_sz, mode='bilinear')
+        skips = []
+        for st in self.encoder.enc_blocks:
+            scale, shift = st.folded_norm(with_conv_bias=True)
+            y = ops.affine_act(F.conv2d(x.contiguous(), st.conv1.weight), scale, shift, relu=True)
+            x = F.conv2d(y, st.conv2.weight, st.conv2.bias)
+            skips.append(x)
+            if x.shape[-1] < 2 or x.shape[-2] < 2:
+                raise ValueError('TinyUNet needs a 1/8 grid of at least 44x44 (valid convolutions), as in the reference')
+            x = F.max_pool2d(x, 2)
+        x = skips.pop()
+        for upc, st in zip(self.decoder.upconvs, self.decoder.dec_blocks):
+            x = F.conv_transpose2d(x, upc.weight, upc.bias, stride=2)
+            sk = skips.pop()
+            dh, dw = (sk.shape[-2] - x.shape[-2]) // 2, (sk.shape[-1] - x.shape[-1]) // 2
+            x = torch.cat((x, sk[..., dh:sk.shape[-2] - dh, dw:sk.shape[-1] - dw]), dim=1)
+            y = ops.bias_act(F.conv2d(x, st.conv1.weight), st.conv1.bias, relu=True)
+            scale, shift = st.folded_norm(with_conv_bias=False)
+            y = ops.affine_act(y, scale, shift, relu=False)
+            x = F.conv2d(y, st.conv2.weight, st.conv2.bias)
+        return F.interpolate(F.conv2d(x, self.head.weight, self.head.bias), self.out_sz, mode='bilinear')
