@@ -51,3 +51,36 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_bad_arguments_return_status_without_a_gpu(rpe):
+    """Error behaviour of the boundary: null pointers / bad sizes give RPE_E_BADARG (-1) before anything touches the
+    device, so this runs on the CPU-only build container too."""
+    import ctypes
+    L = rpe.lib()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)                      # never dereferenced: argument validation fails first
+    assert L.rpe_se3_exp(null, one, 4, 1, null) == -1
+    assert L.rpe_se3_exp(one, one, 4, 7, null) == -1                     # unknown dtype
+    assert L.rpe_se3_exp(one, one, 0, 1, null) == 0                      # empty batch is fine
+    assert L.rpe_pose_solve(*([null] * 9), 1, 8, 8, 0, 8, one, null, null, null, one, null) == -1
+    assert L.rpe_pose_solve(*([one] * 9), 1, 8, 8, 5, 8, one, null, null, null, one, null) == -1      # unknown mode
+    assert L.rpe_pose_solve_opts(*([one] * 9), 1, 8, 8, 0, 8, 1e-7, 1e-9, 0, one, null, null, null, one, null) == -1   # history 0
+    assert L.rpe_corr_lookup(one, one, 1, 8, 8, 4, 3, one, null) == -1                                 # radius != 4
+    assert L.rpe_corr_build(one, one, 1, 250, 8, 8, 4, one, null) == -1                                # channels % 16
+    assert L.rpe_depth_backproject_warp(*([one] * 9), 1, 12, 16, *([one] * 8), null) == -1             # h % 8
+    assert L.rpe_bias_act(one, null, 1, 4, 16, 1, one, 3, 0, null, 0, 0, null) == -1                   # slice overflow
+
+
+@pytest.mark.gpu
+def test_c_abi_from_a_plain_hip_program(rpe, tmp_path):
+    """No Python, no torch: tests/abi/abi_smoke.cpp links librpe_hip.so and calls the ABI on its own stream."""
+    import subprocess
+    from rpe_amd import _lib
+    exe = str(tmp_path / 'abi_smoke')
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O2', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'tests', 'abi', 'abi_smoke.cpp'), '-L', libdir, '-lrpe_hip', '-Wl,-rpath,' + libdir, '-o', exe],
+                   check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'ABI_SMOKE_OK' in r.stdout, r.stdout + r.stderr
