@@ -171,6 +171,7 @@ def main():
             'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
             'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
             'valid_fraction': float(gpu_in['mask2'].float().mean()),
+            'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
         }
         if args.cpu_frames > 0 and world == 1:        # CPU baseline on rank 0 at N = 1 only
             res['cpu_baseline'] = cpu_baseline(cfg, model, frames, args.cpu_frames, pose)
