@@ -190,6 +190,12 @@ int rpe_instnorm_act(const float *x, const float *bias, int b, int c, int hw, fl
                      const float *residual, float *out, void *stream);
 int rpe_affine_act(const float *x, const float *scale, const float *shift, int b, int c, int hw, int relu,
                    const float *residual, float *out, void *stream);
+/* FlowHead.conv2 (core/RAFT/core/update.py) + the coordinate update of RAFT.forward (core/RAFT/core/raft.py):
+ * out (b,2,h,w) = conv3x3(x (b,c,h,w), weight (2,c,3,3), padding 1) + bias (2) [+ add (b,2,h,w), may be NULL = plain
+ * convolution; pass coords1 to get coords1 + delta_flow].  out may alias add.  Two output channels make this a
+ * streaming problem, not a GEMM. */
+int rpe_conv3x3_to2(const float *x, const float *weight, const float *bias, int b, int c, int h, int w,
+                    const float *add, float *out, void *stream);
 /* flow (b,2,h8,w8), mask (b,576,h8,w8) raw logits already scaled by .25 -> out (b,2,8*h8,8*w8). */
 int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int w8, float *out, void *stream);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     'rpe_bias_act': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     'rpe_instnorm_act': (_i, [_vp, _vp, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
     'rpe_affine_act': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'rpe_conv3x3_to2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_upsample_convex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 

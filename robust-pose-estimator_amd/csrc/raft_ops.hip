@@ -166,6 +166,56 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ x,
     }
 }
 
+// FlowHead.conv2 (core/RAFT/core/update.py): 3x3 convolution C -> 2 channels, padding 1, + bias, optionally added to the
+// running coordinates (coords1 = coords1 + delta_flow, core/RAFT/core/raft.py).  With two output channels this is a
+// bandwidth problem (read C planes once), not a GEMM: the conv library runs it at ~7 TFLOP/s.  One thread per output
+// pixel, 64 consecutive x per wave: every tap is a coalesced 256-B row read and the 9 taps of a channel hit the same
+// three rows (L1), weights are wave-uniform scalar loads; the channel loop is split over the 4 waves of a workgroup
+// (each wave a quarter of the channels, combined through LDS) so the chip gets 4x more waves than pixels/64.
+__global__ __launch_bounds__(256) void k_conv3x3_to2(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                     const float* __restrict__ bias, int C, int h, int w,
+                                                     const float* __restrict__ add, float* __restrict__ out) {
+    __shared__ float part[4][2][64];
+    const int bz = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t hw = (size_t)h * w;
+    const size_t p = (size_t)blockIdx.x * 64 + lane;
+    const bool inside = p < hw;
+    const int py = inside ? (int)(p / w) : 0, px = inside ? (int)(p - (size_t)py * w) : 0;
+    const float* xb = x + (size_t)bz * C * hw;
+    // neighbour offsets / validity are the same for every channel
+    int off[9]; bool ok[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = py + k / 3 - 1, xx = px + k % 3 - 1;
+        ok[k] = inside && yy >= 0 && yy < h && xx >= 0 && xx < w;
+        off[k] = ok[k] ? yy * w + xx : 0;
+    }
+    const int cq = (C + 3) / 4, c_lo = wv * cq, c_hi = min(C, c_lo + cq);
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float* xc = xb + (size_t)c * hw;
+        const float* w0 = wgt + (size_t)c * 9;                       // (2, C, 3, 3)
+        const float* w1 = wgt + (size_t)(C + c) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float v = ok[k] ? xc[off[k]] : 0.0f;
+            a0 += v * w0[k];
+            a1 += v * w1[k];
+        }
+    }
+    part[wv][0][lane] = a0; part[wv][1][lane] = a1;
+    __syncthreads();
+    if (wv == 0 && inside) {
+        a0 = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
+        a1 = ((part[0][1][lane] + part[1][1][lane]) + part[2][1][lane]) + part[3][1][lane];
+        const size_t o = (size_t)bz * 2 * hw + p;
+        a0 += bias ? bias[0] : 0.0f; a1 += bias ? bias[1] : 0.0f;
+        if (add) { a0 += add[o]; a1 += add[o + hw]; }
+        out[o] = a0; out[o + hw] = a1;
+    }
+}
+
 // One thread per 1/8-resolution cell; loops over the 64 sub-pixels.  Mask channel = k*64 + i*8 + j.
 __global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict__ flow, const float* __restrict__ mask, int h8,
                                                          int w8, float* __restrict__ out) {
@@ -224,6 +274,14 @@ extern "C" int rpe_affine_act(const float* x, const float* scale, const float* s
     bool v4 = hw % 4 == 0 && vec_ok(x) && vec_ok(out) && (!residual || vec_ok(residual));
     if (v4) hipLaunchKernelGGL(k_affine_act<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, x, scale, shift, c, hw, relu, residual, out);
     else hipLaunchKernelGGL(k_affine_act<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, x, scale, shift, c, hw, relu, residual, out);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_conv3x3_to2(const float* x, const float* weight, const float* bias, int b, int c, int h, int w,
+                               const float* add, float* out, void* stream) {
+    if (!x || !weight || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_conv3x3_to2, dim3(ceil_div((size_t)h * w, 64), b), dim3(256), 0, (hipStream_t)stream, x, weight, bias,
+                       c, h, w, add, out);
     return rpe_check_launch();
 }
 

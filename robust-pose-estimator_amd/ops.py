@@ -285,6 +285,21 @@ def affine_act(x, scale, shift, relu=True, residual=None, out=None):
     return out
 
 
+def conv3x3_to2(x, weight, bias, add=None, out=None):
+    """out = conv3x3(x, weight (2,c,3,3), padding=1) + bias [+ add]; the flow head's last layer."""
+    _nchw(x, 'x')
+    b, c, hh, ww = x.shape
+    weight = _nchw(weight.detach() if weight.requires_grad else weight, 'weight')
+    if tuple(weight.shape) != (2, c, 3, 3):
+        raise _lib.RpeError('conv3x3_to2: weight must be (2,c,3,3)')
+    if add is not None:
+        _nchw(add, 'add')
+    if out is None:
+        out = torch.empty(b, 2, hh, ww, dtype=torch.float32, device=x.device)
+    check(lib().rpe_conv3x3_to2(ptr(x), ptr(weight), ptr(bias), b, c, hh, ww, ptr(add), ptr(out), stream_ptr()), 'rpe_conv3x3_to2')
+    return out
+
+
 def upsample_convex(flow, mask):
     fl, mk = _dev(flow, torch.float32, 'flow'), _dev(mask, torch.float32, 'mask')
     b, _, h8, w8 = fl.shape

@@ -200,9 +200,9 @@ class BasicUpdateBlock(nn.Module):
         pads = {'zr1': (0, 2), 'q1': (0, 2), 'zr2': (2, 0), 'q2': (2, 0)}
         return {k: F.conv2d(inp, W[k][1], W[k][2], padding=pads[k]) for k in W}
 
-    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow):
+    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1):
         """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
-        Returns delta_flow; the new hidden state is left in hx[:, :128] (and, contiguous, in h_buf)."""
+        Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (and, contiguous, in h_buf)."""
         c = self.hidden_dim
         self.encoder(flow, corr, cat_buf, hx, rhx)
         W = self.gate_weights()
@@ -219,7 +219,7 @@ class BasicUpdateBlock(nn.Module):
         h_buf.copy_(hx[:, :c])                                            # contiguous h for the heads
         fh = self.flow_head
         t = ops.bias_act(F.conv2d(h_buf, fh.conv1.weight, None, padding=1), fh.conv1.bias)
-        return fh.conv2(t)
+        return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)      # coords1 + delta_flow
 
     def up_mask(self, net):
         return .25 * self.mask(net)                                      # scale mask to balance gradients (upstream)
@@ -299,8 +299,7 @@ class RAFT(nn.Module):
         for itr in range(iters):
             pyr.lookup(coords1, out=corr)
             flow = coords1 - coords0
-            delta = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow)
-            coords1 = coords1 + delta
+            coords1 = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1)
             if all_flows or itr == iters - 1:
                 lowres = coords1 - coords0
                 if upsample:

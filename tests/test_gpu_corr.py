@@ -223,3 +223,18 @@ def test_full_size_lookup_properties(rpe):
     centre = pyr.build(f1, f2).lookup(c0)[:, 40]                              # level 0, window index (4,4)
     diag = (f1 * f2).sum(1) / 16.0                                           # <f1[:,q], f2[:,q]> / sqrt(256)
     assert float((centre - diag).abs().max()) <= 4e-5 * float(diag.abs().max())
+
+
+def test_flow_head_last_layer(rpe):
+    from rpe_amd import ops
+    torch.manual_seed(5)
+    for (b, c, h, w) in ((2, 256, 64, 80), (1, 20, 13, 37)):
+        x = torch.randn(b, c, h, w)
+        wt = torch.randn(2, c, 3, 3) * 0.05
+        bias = torch.randn(2)
+        coords = torch.randn(b, 2, h, w) * 10
+        ref = F.conv2d(x, wt, bias, padding=1)
+        got = ops.conv3x3_to2(x.cuda(), wt.cuda(), bias.cuda()).cpu()
+        assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4)
+        got2 = ops.conv3x3_to2(x.cuda(), wt.cuda(), bias.cuda(), add=coords.cuda()).cpu()
+        assert torch.allclose(got2, coords + ref, atol=2e-4, rtol=1e-4)

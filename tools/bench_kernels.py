@@ -77,6 +77,14 @@ def main():
         for mode, name in ((ops.SOLVER_LBFGS, 'lbfgs'), (ops.SOLVER_GN, 'gn')):
             med, mn = timeit(lambda: ops.pose_solve(flow, pcl1, pcl2, w1, w2, m1, m2, K, lw, iters=8, mode=mode), a.reps)
             print(f'pose_solve {name:5s}: {med:9.1f} us for 8 iterations, n={n}  ({8 * alg / med / 1e3:7.1f} GB/s algorithmic)')
+    if want('flowhead'):
+        x = torch.randn(b, 256, h8, w8, device=dev); wt = torch.randn(2, 256, 3, 3, device=dev) * 0.05; bias = torch.randn(2, device=dev)
+        co = torch.randn(b, 2, h8, w8, device=dev)
+        med, mn = timeit(lambda: ops.conv3x3_to2(x, wt, bias, add=co), a.reps)
+        alg = b * 256 * h8 * w8 * 4
+        print(f'conv3x3_to2     : {med:9.1f} us (min {mn:.1f})  {alg / med / 1e3:7.1f} GB/s (input read once, {alg / 1e6:.1f} MB)')
+        med, mn = timeit(lambda: torch.nn.functional.conv2d(x, wt, bias, padding=1), a.reps)
+        print(f'  (MIOpen conv2d: {med:9.1f} us)')
     if want('geom'):
         n = b // 2
         sf2 = torch.randn(n, 2, H, W, device=dev); sf2[:, 0] = -20 - 5 * torch.rand(n, H, W, device=dev)

@@ -63,7 +63,7 @@ def main():
             zr = F.conv2d(hx, GW['zr2'][0], None, padding=(2, 0)); ops.gru_gates_zr(zr, hx, c, z, rhx, add=ctx['zr2'])
             q = F.conv2d(rhx, GW['q2'][0], None, padding=(2, 0)); ops.gru_gates_h(z, q, hx, c, hx, add=ctx['q2']); mark('gru')
             hb.copy_(hx[:, :c]); fh = ub.flow_head
-            d = fh.conv2(ops.bias_act(F.conv2d(hb, fh.conv1.weight, None, padding=1), fh.conv1.bias)); c1 = c1 + d; mark('flow_head')
+            c1 = ops.conv3x3_to2(ops.bias_act(F.conv2d(hb, fh.conv1.weight, None, padding=1), fh.conv1.bias), fh.conv2.weight, fh.conv2.bias, add=c1); mark('flow_head')
         up = ops.upsample_convex(c1 - c0, ub.up_mask(hb)); mark('mask+upsample')
         tfl = up[:n].contiguous(); sf2 = up[n:].contiguous()
         gg = ops.depth_backproject_warp(sf2, tfl, g['baseline'], g['intrinsics'], g['depth1'], g['image1l'], g['image2l'], g['stereo_flow1'], g['mask2'])
