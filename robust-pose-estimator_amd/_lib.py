@@ -12,7 +12,7 @@ import subprocess
 import torch  # noqa: F401  (loads libamdhip64 first, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librpe_hip.so')
+LIB_PATH = os.environ.get('RPE_HIP_LIBRARY', os.path.join(_HERE, 'librpe_hip.so'))   # override: kernel experiments
 CSRC = os.path.join(_HERE, 'csrc')
 
 _c = ctypes
