@@ -177,7 +177,16 @@ __global__ __launch_bounds__(256) void k_corr_pool(float* __restrict__ pyr, PyrG
     {
         const float* g0 = pyr + G.base[0] + qb * G.S[0];
         const int h = G.h[0], w = G.w[0], txc = G.txc[0];
-        for (int p = threadIdx.x; p < h * w; p += blockDim.x) { int y = p / w, x = p - y * w; src[p] = g0[tile_off(y, x, txc)]; }
+        const int n4 = (int)(G.S[0] >> 2);                    // 16-B pieces: one micro-tile row each, contiguous in memory
+        for (int p = threadIdx.x; p < n4; p += blockDim.x) {
+            const float4 v = ((const float4*)g0)[p];
+            const int t = p >> 2, y = (t / txc) * 4 + (p & 3), x = (t % txc) * 4;
+            if (y < h) {
+                float* d = src + (size_t)y * w + x;
+                if (x + 3 < w) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+                else { if (x < w) d[0] = v.x; if (x + 1 < w) d[1] = v.y; if (x + 2 < w) d[2] = v.z; }
+            }
+        }
     }
     __syncthreads();
     for (int l = 1; l < G.levels; ++l) {
