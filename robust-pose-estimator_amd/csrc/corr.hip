@@ -118,11 +118,15 @@ __global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 ra[2], rb[2];
-    ra[0] = load4(Ab, M, lk, m0 + lc, M, a_full); ra[1] = load4(Ab, M, lk + 8, m0 + lc, M, a_full);
-    rb[0] = load4(Bb, N, lk, n0 + lc, N, b_full); rb[1] = load4(Bb, N, lk + 8, n0 + lc, N, b_full);
-    *(float4*)&As[0][lk][lc] = ra[0]; *(float4*)&As[0][lk + 8][lc] = ra[1];
-    *(float4*)&Bs[0][lk][lc] = rb[0]; *(float4*)&Bs[0][lk + 8][lc] = rb[1];
+    constexpr int NL = BK / 8;                  // loader rows per thread (8 k-rows per sweep of the 256 threads)
+    float4 ra[NL], rb[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        ra[u] = load4(Ab, M, lk + 8 * u, m0 + lc, M, a_full);
+        rb[u] = load4(Bb, N, lk + 8 * u, n0 + lc, N, b_full);
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) { *(float4*)&As[0][lk + 8 * u][lc] = ra[u]; *(float4*)&Bs[0][lk + 8 * u][lc] = rb[u]; }
     __syncthreads();
 
     const int nk = K / BK;
@@ -130,8 +134,11 @@ __global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, 
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             const int k1 = (kt + 1) * BK;
-            ra[0] = load4(Ab, M, k1 + lk, m0 + lc, M, a_full); ra[1] = load4(Ab, M, k1 + lk + 8, m0 + lc, M, a_full);
-            rb[0] = load4(Bb, N, k1 + lk, n0 + lc, N, b_full); rb[1] = load4(Bb, N, k1 + lk + 8, n0 + lc, N, b_full);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                ra[u] = load4(Ab, M, k1 + lk + 8 * u, m0 + lc, M, a_full);
+                rb[u] = load4(Bb, N, k1 + lk + 8 * u, n0 + lc, N, b_full);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, 
         }
         if (kt + 1 < nk) {
             const int nxt = cur ^ 1;
-            *(float4*)&As[nxt][lk][lc] = ra[0]; *(float4*)&As[nxt][lk + 8][lc] = ra[1];
-            *(float4*)&Bs[nxt][lk][lc] = rb[0]; *(float4*)&Bs[nxt][lk + 8][lc] = rb[1];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) { *(float4*)&As[nxt][lk + 8 * u][lc] = ra[u]; *(float4*)&Bs[nxt][lk + 8 * u][lc] = rb[u]; }
         }
         __syncthreads();
     }
