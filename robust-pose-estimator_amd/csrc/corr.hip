@@ -84,6 +84,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BK 16
 
 // A: (b, K, M) row-major (fmap1: K = channels, M = queries);  B: (b, K, N) row-major (B');  C: (b, M, N) row-major.
+// EDGE = false: every tile is full and 16-B aligned (M, N multiples of 128): no guards anywhere in the main loop.
+template <bool EDGE>
 __global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                    int M, int N, int K, float scale) {
     __shared__ float As[2][BK][BM];
@@ -97,11 +99,11 @@ __global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, 
     const int wm = wv >> 1, wn = wv & 1;
     // loader mapping: thread -> (k = tid>>5 [+8], 4 consecutive columns at (tid&31)*4)
     const int lk = tid >> 5, lc = (tid & 31) * 4;
-    const bool a_full = (m0 + BM <= M) && (M % 4 == 0), b_full = (n0 + BN <= N) && (N % 4 == 0);
+    const bool a_full = !EDGE || ((m0 + BM <= M) && (M % 4 == 0)), b_full = !EDGE || ((n0 + BN <= N) && (N % 4 == 0));
 
     auto load4 = [&](const float* base, int ld, int k, int c0, int limit, bool full) -> float4 {
         const float* p = base + (size_t)k * ld + c0;
-        if (full) return *(const float4*)p;
+        if (!EDGE || full) return *(const float4*)p;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c0 + 0 < limit) v.x = p[0];
         if (c0 + 1 < limit) v.y = p[1];
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M && col < N) Cb[(size_t)row * N + col] = acc[i][j][r] * scale;
+                if (!EDGE || (row < M && col < N)) Cb[(size_t)row * N + col] = acc[i][j][r] * scale;
             }
         }
 }
@@ -422,8 +424,11 @@ extern "C" int rpe_corr_build(const float* fmap1, const float* fmap2, int b, int
     const long long S0 = G.S[0];
     const int nq = h8 * w8;
     hipLaunchKernelGGL(k_permute_fmap2, dim3(ceil_div(S0, 256), b * c), dim3(256), 0, s, fmap2, Bp, c, h8, w8, G.txc[0], S0);
-    hipLaunchKernelGGL(k_corr_gemm, dim3(ceil_div(S0, BN), ceil_div(nq, BM), b), dim3(256), 0, s, fmap1, (const float*)Bp,
-                       pyr + G.base[0], nq, (int)S0, c, 1.0f / sqrtf((float)c));
+    const bool edge = (nq % BM) || (S0 % BN) || ((uintptr_t)fmap1 % 16) || ((uintptr_t)pyramid % 16);
+    if (edge) hipLaunchKernelGGL(k_corr_gemm<true>, dim3(ceil_div(S0, BN), ceil_div(nq, BM), b), dim3(256), 0, s, fmap1, (const float*)Bp,
+                                 pyr + G.base[0], nq, (int)S0, c, 1.0f / sqrtf((float)c));
+    else hipLaunchKernelGGL(k_corr_gemm<false>, dim3(ceil_div(S0, BN), ceil_div(nq, BM), b), dim3(256), 0, s, fmap1, (const float*)Bp,
+                            pyr + G.base[0], nq, (int)S0, c, 1.0f / sqrtf((float)c));
     if (levels > 1) {
         size_t lds = ((size_t)G.h[0] * G.w[0] + (size_t)G.h[1] * G.w[1]) * sizeof(float);
         if (lds > 160 * 1024) return RPE_E_UNSUPPORTED;
