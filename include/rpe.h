@@ -199,6 +199,39 @@ int rpe_conv3x3_to2(const float *x, const float *weight, const float *bias, int 
 /* flow (b,2,h8,w8), mask (b,576,h8,w8) raw logits already scaled by .25 -> out (b,2,8*h8,8*w8). */
 int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int w8, float *out, void *stream);
 
+/* ---- update-block convolutions (core/RAFT/core/update.py: BasicMotionEncoder convc1/convc2/convf2/conv, SepConvGRU
+ * convz|convr/convq of both halves, FlowHead.conv1) as implicit GEMMs on the f32 matrix cores with their epilogues
+ * fused.  Stride 1, zero padding k/2 ("same"), NCHW, kernel height odd, kernel width 1, 3 or 5, w % 4 == 0
+ * (otherwise RPE_E_UNSUPPORTED: the caller keeps the library convolution + rpe_bias_act / rpe_gru_gates_*).
+ * Every tensor argument is a pointer to channel 0 of a channel slice plus the batch stride (in floats) of the
+ * buffer it lives in, so inputs and outputs can be slices of the concatenated (h | motion | flow) buffers.
+ *   v = conv(x)[co][p] + add[co][p] + bias[co]
+ *   RPE_CONV_LINEAR : out = v                      (and out2 = v when out2 != NULL)
+ *   RPE_CONV_RELU   : out = max(v, 0)              (and out2)
+ *   RPE_CONV_GATE_ZR: cout = 2*gate_channels; co <  gate_channels: out[co]  = sigmoid(v)                 (z)
+ *                                             co >= gate_channels: out2[co-gate_channels] = sigmoid(v) * hidden[co-gate_channels]  (r*h)
+ *   RPE_CONV_GATE_H : out[co] = (1 - zgate[co]) * hidden[co] + zgate[co] * tanh(v);  out may alias hidden.        */
+#define RPE_CONV_LINEAR 0
+#define RPE_CONV_RELU 1
+#define RPE_CONV_GATE_ZR 2
+#define RPE_CONV_GATE_H 3
+typedef struct rpe_conv_desc {
+    const float *x;      long long x_batch_stride;      /* input slice (b, cin, h, w)                              */
+    const float *packed;                                 /* weights from rpe_conv_pack                              */
+    const float *bias;                                   /* (cout) or NULL                                          */
+    const float *add;    long long add_batch_stride;    /* (b, cout, h, w) pre-activation addend or NULL           */
+    float *out;          long long out_batch_stride;
+    float *out2;         long long out2_batch_stride;   /* NULL unless described above                             */
+    const float *hidden; long long hidden_batch_stride; /* gates only                                              */
+    const float *zgate;  long long zgate_batch_stride;  /* RPE_CONV_GATE_H only                                    */
+    int b, cin, cout, h, w, kh, kw, mode, gate_channels;
+} rpe_conv_desc;
+/* number of floats of the packed form of a (cout, cin, kh, kw) weight tensor (0 on bad arguments) */
+size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
+/* weight (cout, cin, kh, kw) contiguous -> packed (tap-major 16-channel steps, output channels padded to 128) */
+int rpe_conv_pack(const float *weight, int cout, int cin, int kh, int kw, float *packed, void *stream);
+int rpe_conv_fused(const rpe_conv_desc *desc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,18 @@ CSRC = os.path.join(_HERE, 'csrc')
 _c = ctypes
 _vp, _i, _i64, _d, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_double, _c.c_size_t
 
+_f, _ll = _c.c_void_p, _c.c_longlong
+
+
+class ConvDesc(_c.Structure):
+    """struct rpe_conv_desc (include/rpe.h)."""
+    _fields_ = [('x', _f), ('x_batch_stride', _ll), ('packed', _f), ('bias', _f), ('add', _f), ('add_batch_stride', _ll),
+                ('out', _f), ('out_batch_stride', _ll), ('out2', _f), ('out2_batch_stride', _ll),
+                ('hidden', _f), ('hidden_batch_stride', _ll), ('zgate', _f), ('zgate_batch_stride', _ll),
+                ('b', _i), ('cin', _i), ('cout', _i), ('h', _i), ('w', _i), ('kh', _i), ('kw', _i), ('mode', _i),
+                ('gate_channels', _i)]
+
+
 # name -> (restype, argtypes); mirrors include/rpe.h one to one
 SIGNATURES = {
     'rpe_version': (_c.c_char_p, []),
@@ -46,6 +58,9 @@ SIGNATURES = {
     'rpe_affine_act': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_conv3x3_to2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_upsample_convex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'rpe_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
+    'rpe_conv_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_conv_fused': (_i, [_c.POINTER(ConvDesc), _vp]),
 }
 
 _lib = None

@@ -1,0 +1,297 @@
+// Stride-1 "same" convolutions of RAFT's update block as implicit GEMMs on the f32 matrix cores, with the
+// element-wise work that follows each of them fused into the epilogue.
+//
+// Replaces (reference's RAFT submodule, call sites core/pose/pose_net.py:47,65,129):
+//   core/RAFT/core/update.py  BasicMotionEncoder.forward  (convc1, convc2, convf2, conv: conv + bias + ReLU + cat)
+//                             SepConvGRU.forward          (convz|convr -> sigmoid, r*h ; convq -> tanh, h blend)
+//                             FlowHead.conv1              (conv + bias + ReLU)
+// The conv library runs these NCHW tensors through NCHW<->NHWC transposes around its GEMM kernel and leaves bias,
+// activation, gate arithmetic and concatenation to separate passes; here the convolution reads NCHW directly and
+// the accumulator tile goes through bias / context addend / activation / gate blend before its only store.
+//
+// GEMM view, per batch item:   out[co][p] = sum_{ci,dy,dx} Wt[co][ci][dy][dx] * x[ci][p + dy*W + dx]
+//   M = output channels (A operand = packed weights), N = pixels (B operand = the input planes, contiguous in p),
+//   K = cin * kh * kw walked as steps of 16 input channels x one tap.
+// Workgroup = 4 waves, tile 128(co) x 128(px) or 64(co) x 256(px); each wave owns 64 x 64 = 2 x 2 MFMA 32x32x2 blocks.
+// LDS: weights tile [16][BM] per step; input tile [16][BN + 8] per (channel chunk, dy): the kw taps of a row are
+// served from the same staged tile by reading it at a column offset (4-B LDS reads have no alignment rule), so the
+// input crosses L2->LDS once per dy instead of once per tap.  Both tiles are double buffered; one barrier per step.
+// Zero padding: rows (y+dy outside the map) are zero-filled by the loader (whole float4s, W % 4 == 0); columns
+// (x+dx outside the row) are masked per lane when the B operand is read.
+#include "rpe_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK 16
+
+struct ConvP {
+    const float* x; long long xbs;            // first input channel of the slice; batch stride (floats)
+    const float* wp;                          // packed weights [step][16][coP]
+    int cin, cout, coP, H, W, hw, kh;
+    const float* bias;                        // [cout] or null
+    const float* add; long long abs_;         // (b, cout, hw) pre-activation addend or null
+    int mode;
+    float* out; long long obs;                // channel 0 of the destination slice; batch stride
+    float* out2; long long o2bs;              // second destination (RPE_CONV_RELU/LINEAR: copy; GATE_ZR: r*h)
+    const float* h; long long hbs;            // hidden state, channels [0, c)
+    const float* z; long long zbs;            // update gate (GATE_H)
+    int cgate;
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// LDS layouts are K-contiguous: As[m][KS], Bs[4 + n][KS] with KS = 20 floats (16 used): a lane fetches the 8 k-values
+// it feeds to 8 consecutive MFMAs with two ds_read_b128 (rows 80 B apart: 16 consecutive rows tile the 64 banks
+// exactly, so reads, the float4 weight stores and the transposing 4-B input stores are all conflict-free).  The MFMA
+// sums over k in any order, so lane half lh of k2-step j supplies k = 8*lh + j for both operands.
+template <int KW, int WM>
+__global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
+    constexpr int WN = 4 / WM, BM = 64 * WM, BN = 64 * WN, PW = KW / 2;
+    constexpr int KS = 20;
+    constexpr int NLA = BM / 64;                                 // float4 per thread of the [4 k4][BM] weights tile
+    constexpr int NLB = BN / 64;                                 // float4 per thread of the [16 k][BN/4] input tile
+    __shared__ __attribute__((aligned(16))) float As[2][BM][KS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN + 8][KS];
+    const int bz = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+    const int W = P.W, hw = P.hw, ph = P.kh / 2;
+    // weights loader: thread -> (m = tid % BM, k4 = tid / BM [+ 256/BM * u]);  packed as [step][k4][coP][4]
+    const int a_m = tid % BM, a_k4 = tid / BM;
+    constexpr int A_K4STEP = 256 / BM;
+    // input loader: lanes 4j..4j+3 fetch 64 contiguous bytes of channel row k = j; thread -> (k = (tid/4) % 16,
+    // pixel float4 n4 = tid % 4 + 4 * wave [+ 16 u]).  Halo (threads 0..31): k = tid % 16, side = tid / 16.
+    const int b_k = (tid >> 2) & 15, b_n4 = (tid & 3) + 4 * wv;
+    const int h_k = tid & 15, h_side = tid >> 4;
+    const float* xrow = P.x + (size_t)bz * P.xbs + (size_t)b_k * hw;          // channel row b_k of chunk 0
+    const float* xrow_h = P.x + (size_t)bz * P.xbs + (size_t)h_k * hw;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // x coordinate of this lane's two B columns: decides which taps fall off the row
+    const int xq0 = (n0 + wn * 64 + l31) % W, xq1 = (n0 + wn * 64 + 32 + l31) % W;
+
+    const int nchunk = (P.cin + CK - 1) / CK;
+    const int G = nchunk * P.kh;                                 // (channel chunk, dy) groups; each has KW steps
+    float4 ra0, ra1;                                             // (scalars: as an array it is demoted to LDS)
+    struct RB { float4 v[NLB]; float4 halo; unsigned ok; };      // one staged input tile (this thread's part); ok bits:
+                                                                 // u (and NLB = halo): lane's float4 is inside the map
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* wnext = P.wp + ((size_t)a_k4 * P.coP + m0 + a_m) * 4;        // this thread's float4 of step 0
+    const size_t wstep = (size_t)4 * P.coP * 4, wk4 = (size_t)A_K4STEP * P.coP * 4;
+    int lc = 0, ld = 0;                                          // (chunk, dy index) of the next group to load
+
+    auto load_a = [&]() {                                        // next step's weights; advances the pointer
+        ra0 = *(const float4*)wnext;
+        if (NLA == 2) ra1 = *(const float4*)(wnext + wk4);
+        wnext += wstep;
+    };
+    // next group's input tile; advances (lc, ld).  Issued unconditionally (groups past the end read the dummy address):
+    // a load under a branch makes the compiler's s_waitcnt placement assume the worst on every path.
+    auto load_b = [&](RB& R) {
+        const bool cok = lc * CK + b_k < P.cin;
+        const int sh = (ld - ph) * W;
+        const float* src = xrow + (size_t)lc * CK * hw;
+        R.ok = 0;
+        // out-of-map lanes read a valid dummy address; they are zeroed when the tile is written to LDS (a conditional
+        // load is split into four branchy dword loads, and a select right here would wait for the data at once)
+#pragma unroll
+        for (int u = 0; u < NLB; ++u) {
+            const int p = n0 + 4 * (b_n4 + 16 * u) + sh;
+            const bool ok = cok && p >= 0 && p + 3 < hw;
+            R.v[u] = *(const float4*)(ok ? src + p : P.x);
+            R.ok |= ok ? (1u << u) : 0u;
+        }
+        if (KW > 1 && tid < 32) {
+            const int p = n0 + (h_side ? BN : -4) + sh;
+            const bool ok = lc * CK + h_k < P.cin && p >= 0 && p + 3 < hw;
+            R.halo = *(const float4*)(ok ? xrow_h + (size_t)lc * CK * hw + p : P.x);
+            R.ok |= ok ? (1u << NLB) : 0u;
+        }
+        if (++ld == P.kh) { ld = 0; ++lc; }
+    };
+    auto store_a = [&](int buf) {
+        *(float4*)&As[buf][a_m][4 * a_k4] = ra0;
+        if (NLA == 2) *(float4*)&As[buf][a_m][4 * (a_k4 + A_K4STEP)] = ra1;
+    };
+    auto store_b = [&](const RB& R, int buf) {
+#pragma unroll
+        for (int u = 0; u < NLB; ++u) {
+            const int n = 4 + 4 * (b_n4 + 16 * u);
+            const float4 v = (R.ok >> u) & 1 ? R.v[u] : zero4;
+            Bs[buf][n + 0][b_k] = v.x; Bs[buf][n + 1][b_k] = v.y; Bs[buf][n + 2][b_k] = v.z; Bs[buf][n + 3][b_k] = v.w;
+        }
+        if (KW > 1 && tid < 32) {
+            const int n = h_side ? 4 + BN : 0;
+            const float4 v = (R.ok >> NLB) & 1 ? R.halo : zero4;
+            Bs[buf][n + 0][h_k] = v.x; Bs[buf][n + 1][h_k] = v.y; Bs[buf][n + 2][h_k] = v.z; Bs[buf][n + 3][h_k] = v.w;
+        }
+    };
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto mma_step = [&](int curA, int curB, int dx) {            // 16 k-values of one tap: 8 ds_read_b128, 32 MFMAs
+        const float* arow = &As[curA][wm * 64 + l31][8 * lh];
+        const float* brow = &Bs[curB][4 + wn * 64 + l31 + dx][8 * lh];
+        f32x4 a0[2], a1[2], b0[2], b1[2];                        // k = 8*lh + 0..3 and + 4..7
+        a0[0] = *(const f32x4*)(arow);            a0[1] = *(const f32x4*)(arow + 4);
+        a1[0] = *(const f32x4*)(arow + 32 * KS);  a1[1] = *(const f32x4*)(arow + 32 * KS + 4);
+        b0[0] = *(const f32x4*)(brow);            b0[1] = *(const f32x4*)(brow + 4);
+        b1[0] = *(const f32x4*)(brow + 32 * KS);  b1[1] = *(const f32x4*)(brow + 32 * KS + 4);
+        if (KW > 1) {
+            const bool v0 = (unsigned)(xq0 + dx) < (unsigned)W, v1 = (unsigned)(xq1 + dx) < (unsigned)W;
+            const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            b0[0] = v0 ? b0[0] : z4; b0[1] = v0 ? b0[1] : z4; b1[0] = v1 ? b1[0] : z4; b1[1] = v1 ? b1[1] : z4;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float fa0 = a0[j >> 2][j & 3], fa1 = a1[j >> 2][j & 3], fb0 = b0[j >> 2][j & 3], fb1 = b1[j >> 2][j & 3];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
+        }
+    };
+
+    // The input planes stream from HBM (each tile is read by only cout/BM * kh workgroups), so their loads are
+    // issued a whole group (KW > 1: KW steps) or three steps (KW == 1, three register sets) ahead of use; the
+    // weights are shared by every workgroup (L2 hits) and are fetched one step ahead.
+    if (KW > 1) {
+        RB R;
+        load_a(); load_b(R);
+        store_a(0); store_b(R, 0);
+        __syncthreads();
+        int step = 0;
+        for (int g = 0; g < G; ++g) {
+            const int curB = g & 1;
+#pragma unroll
+            for (int t = 0; t < KW; ++t, ++step) {
+                const int curA = step & 1;
+                const bool last = (g + 1 == G) && (t + 1 == KW);
+                if (!last) load_a();                              // weights first: their wait must not cover the
+                if (t == 0) load_b(R);                            // input loads issued after them (in-order return)
+                mma_step(curA, curB, t - PW);
+                if (!last) store_a(curA ^ 1);
+                if (t == KW - 1 && g + 1 < G) store_b(R, curB ^ 1);
+                __syncthreads();
+            }
+        }
+    } else {
+        RB R0, R1, R2;
+        load_b(R0);
+        if (G > 1) load_b(R1);
+        if (G > 2) load_b(R2);
+        load_a();
+        store_a(0); store_b(R0, 0);
+        __syncthreads();
+        auto body = [&](int g, RB& Rload, const RB& Rstore) {   // Rload: free (its tile is in LDS); Rstore: group g+1
+            const int cur = g & 1;
+            if (g + 1 < G) load_a();
+            load_b(Rload);
+            mma_step(cur, cur, 0);
+            if (g + 1 < G) { store_a(cur ^ 1); store_b(Rstore, cur ^ 1); }
+            __syncthreads();
+        };
+        for (int g = 0; g < G; g += 3) {
+            body(g, R0, R1);
+            if (g + 1 < G) body(g + 1, R1, R2);
+            if (g + 2 < G) body(g + 2, R2, R0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int mode = P.mode, cg = P.cgate;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int px = n0 + wn * 64 + j * 32 + l31;
+            if (px >= hw) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= P.cout) continue;
+                float v = acc[i][j][r];
+                if (P.add) v += P.add[(size_t)bz * P.abs_ + (size_t)co * hw + px];
+                if (P.bias) v += P.bias[co];
+                if (mode == RPE_CONV_GATE_ZR) {
+                    const float s = sigmoid_f(v);
+                    if (co < cg) P.out[(size_t)bz * P.obs + (size_t)co * hw + px] = s;
+                    else {
+                        const size_t e = (size_t)(co - cg) * hw + px;
+                        P.out2[(size_t)bz * P.o2bs + e] = s * P.h[(size_t)bz * P.hbs + e];
+                    }
+                } else if (mode == RPE_CONV_GATE_H) {
+                    const size_t e = (size_t)co * hw + px;
+                    const float zv = P.z[(size_t)bz * P.zbs + e], hv = P.h[(size_t)bz * P.hbs + e];
+                    P.out[(size_t)bz * P.obs + e] = (1.0f - zv) * hv + zv * tanhf(v);
+                } else {
+                    if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;        // NaN stays NaN, like torch.relu
+                    const size_t e = (size_t)co * hw + px;
+                    P.out[(size_t)bz * P.obs + e] = v;
+                    if (P.out2) P.out2[(size_t)bz * P.o2bs + e] = v;
+                }
+            }
+        }
+}
+
+// (cout, cin, kh, kw) -> [step = (chunk*kh + dy)*kw + dx][k4 = 0..3][coP][4]: element (step, k = 4*k4 + e, co) is
+// weight[co][chunk*16 + k][dy][dx], zero beyond cin / cout.  One 16-B load per (k4, co) fills an As row segment.
+__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int kh, int kw, int coP,
+                            long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int ke = (int)(e & 3);
+    const int co = (int)((e >> 2) % coP);
+    const long long rest = (e >> 2) / coP;
+    const int k4 = (int)(rest & 3);
+    const long long s = rest >> 2;
+    const int dx = (int)(s % kw), dy = (int)((s / kw) % kh), c = (int)(s / ((long long)kw * kh));
+    const int ci = c * CK + 4 * k4 + ke;
+    wp[e] = (co < cout && ci < cin) ? w[(((size_t)co * cin + ci) * kh + dy) * kw + dx] : 0.0f;
+}
+
+static inline int conv_cop(int cout) { return (cout + 127) / 128 * 128; }
+
+extern "C" size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw) {
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)((cin + CK - 1) / CK) * kh * kw * CK * conv_cop(cout);
+}
+
+extern "C" int rpe_conv_pack(const float* weight, int cout, int cin, int kh, int kw, float* packed, void* stream) {
+    if (!weight || !packed || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return RPE_E_BADARG;
+    const long long total = (long long)rpe_conv_packed_floats(cout, cin, kh, kw);
+    hipLaunchKernelGGL(k_conv_pack, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed, cout, cin, kh, kw,
+                       conv_cop(cout), total);
+    return rpe_check_launch();
+}
+
+static_assert(sizeof(rpe_conv_desc) == 152, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->packed || !d->out || d->b <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return RPE_E_BADARG;
+    if (d->kh < 1 || !(d->kh & 1) || (d->kw != 1 && d->kw != 3 && d->kw != 5)) return RPE_E_UNSUPPORTED;
+    if ((d->w & 3) || !al16(d->x) || (d->x_batch_stride & 3)) return RPE_E_UNSUPPORTED;     // 16-B input loads
+    if (d->mode < RPE_CONV_LINEAR || d->mode > RPE_CONV_GATE_H) return RPE_E_BADARG;
+    if (d->mode == RPE_CONV_GATE_ZR && (!d->out2 || !d->hidden || d->gate_channels <= 0 || d->cout != 2 * d->gate_channels)) return RPE_E_BADARG;
+    if (d->mode == RPE_CONV_GATE_H && (!d->hidden || !d->zgate)) return RPE_E_BADARG;
+    ConvP P;
+    P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed;
+    P.cin = d->cin; P.cout = d->cout; P.coP = conv_cop(d->cout); P.H = d->h; P.W = d->w; P.hw = d->h * d->w; P.kh = d->kh;
+    P.bias = d->bias; P.add = d->add; P.abs_ = d->add_batch_stride; P.mode = d->mode;
+    P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
+    P.h = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = (d->cout % 128) != 0;          // 64-row tiles waste less when cout is 64, 126, 192
+    const int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
+    dim3 grid(ceil_div(P.hw, BN), ceil_div(d->cout, BM), d->b), block(256);
+#define LAUNCH(KW_, WM_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_>), grid, block, 0, s, P)
+    if (wide) { if (d->kw == 1) LAUNCH(1, 1); else if (d->kw == 3) LAUNCH(3, 1); else LAUNCH(5, 1); }
+    else      { if (d->kw == 1) LAUNCH(1, 2); else if (d->kw == 3) LAUNCH(3, 2); else LAUNCH(5, 2); }
+#undef LAUNCH
+    return rpe_check_launch();
+}

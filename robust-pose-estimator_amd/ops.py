@@ -308,3 +308,64 @@ def upsample_convex(flow, mask):
     out = torch.empty(b, 2, 8 * h8, 8 * w8, dtype=torch.float32, device=fl.device)
     check(lib().rpe_upsample_convex(ptr(fl), ptr(mk), b, h8, w8, ptr(out), stream_ptr()), 'rpe_upsample_convex')
     return out
+
+
+# ------------------------------------------------------------------------- fused update-block convolutions
+CONV_LINEAR, CONV_RELU, CONV_GATE_ZR, CONV_GATE_H = 0, 1, 2, 3
+
+
+def _chan_slice(t, name):
+    """(pointer, batch stride) of a float32 GPU tensor that is a channel slice ``buf[:, a:b]`` of a contiguous NCHW
+    buffer (or such a buffer itself)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4):
+        raise _lib.RpeError(f'{name}: expected a float32 NCHW tensor on the GPU')
+    _, _, hh, ww = t.shape
+    if t.stride(3) != 1 or t.stride(2) != ww or t.stride(1) != hh * ww:
+        raise _lib.RpeError(f'{name}: expected a channel slice of a contiguous NCHW buffer')
+    return ptr(t), t.stride(0)
+
+
+class PackedConv:
+    """Weights of one stride-1 'same' convolution re-laid for rpe_conv_fused (done once per weight version)."""
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        n = lib().rpe_conv_packed_floats(self.cout, self.cin, self.kh, self.kw)
+        self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(lib().rpe_conv_pack(ptr(w), self.cout, self.cin, self.kh, self.kw, ptr(self.packed), stream_ptr()), 'rpe_conv_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(weight, width):
+        _, _, kh, kw = weight.shape
+        return kh % 2 == 1 and kw in (1, 3, 5) and width % 4 == 0
+
+
+def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0):
+    """rpe_conv_fused: out = epilogue(conv(x; pc) + add + bias).  All tensors are channel slices of NCHW buffers."""
+    d = _lib.ConvDesc()
+    b, cin, hh, ww = x.shape
+    if cin != pc.cin:
+        raise _lib.RpeError(f'conv_fused: input has {cin} channels, weights expect {pc.cin}')
+    d.x, d.x_batch_stride = _chan_slice(x, 'x')
+    d.packed, d.bias = ptr(pc.packed), ptr(pc.bias)
+    for name, t, want_c in (('add', add, pc.cout), ('out', out, None), ('out2', out2, None), ('hidden', hidden, None), ('zgate', zgate, None)):
+        if t is None:
+            setattr(d, name, None); setattr(d, name + '_batch_stride', 0)
+            continue
+        if t.shape[0] != b or tuple(t.shape[2:]) != (hh, ww) or (want_c is not None and t.shape[1] != want_c):
+            raise _lib.RpeError(f'conv_fused: {name} has shape {tuple(t.shape)}')
+        p, s = _chan_slice(t, name)
+        setattr(d, name, p); setattr(d, name + '_batch_stride', s)
+    need = {CONV_LINEAR: pc.cout, CONV_RELU: pc.cout, CONV_GATE_ZR: gate_channels, CONV_GATE_H: pc.cout}[mode]
+    if out.shape[1] < need or (mode == CONV_GATE_ZR and (out2 is None or out2.shape[1] < gate_channels or hidden.shape[1] < gate_channels)):
+        raise _lib.RpeError('conv_fused: destination slice has too few channels')
+    if mode == CONV_GATE_H and (hidden is None or zgate is None or hidden.shape[1] < pc.cout or zgate.shape[1] < pc.cout):
+        raise _lib.RpeError('conv_fused: GATE_H needs hidden and zgate with cout channels')
+    if mode in (CONV_LINEAR, CONV_RELU) and out2 is not None and out2.shape[1] < pc.cout:
+        raise _lib.RpeError('conv_fused: out2 slice has too few channels')
+    d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.gate_channels = b, cin, pc.cout, hh, ww, pc.kh, pc.kw, mode, gate_channels
+    import ctypes
+    check(lib().rpe_conv_fused(ctypes.byref(d), stream_ptr()), 'rpe_conv_fused')
+    return out

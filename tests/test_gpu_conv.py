@@ -1,0 +1,110 @@
+"""GPU: the fused implicit-GEMM convolutions (rpe_conv_fused) against a float64 CPU evaluation of the same
+convolution + epilogue (torch.nn.functional.conv2d in f64 is the reference arithmetic: the f32 result of any
+summation order must sit within a few f32 roundings of it).  Tolerance: 3e-6 * sqrt(K) * max|x| * max|w| per
+accumulated term, K = cin*kh*kw -- about ten times the error of an f32 dot product of that length."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(rng, *shape, s=1.0):
+    return torch.from_numpy((rng.normal(size=shape) * s).astype(np.float32))
+
+
+def _ref_conv(x, w, bias, add):
+    v = F.conv2d(x.double(), w.double(), None, padding=(w.shape[2] // 2, w.shape[3] // 2))
+    if add is not None:
+        v = v + add.double()
+    if bias is not None:
+        v = v + bias.double()[None, :, None, None]
+    return v
+
+
+def _tol(x, w):
+    k = w.shape[1] * w.shape[2] * w.shape[3]
+    return 3e-6 * np.sqrt(k) * float(x.abs().max()) * float(w.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize('cin,cout,kh,kw,h,w,b', [
+    (256, 192, 3, 3, 64, 80, 2),      # convc2: 64-row tiles, three of them
+    (256, 126, 3, 3, 32, 40, 2),      # conv: ragged output channels
+    (128, 64, 3, 3, 44, 48, 1),       # convf2 on a map that is not a multiple of the pixel tile
+    (324, 256, 1, 1, 32, 40, 2),      # convc1: input channels not a multiple of 16
+    (128, 256, 3, 3, 44, 48, 2),      # flow head conv1: 128-row tiles, ragged pixel tile
+    (32, 128, 1, 5, 8, 12, 1),        # tiny map: one partial tile, rows shorter than the halo logic's stride
+    (16, 128, 7, 3, 20, 16, 1),       # tall kernel
+])
+@pytest.mark.parametrize('relu', [False, True])
+def test_conv_bias_act_matches_f64(rpe, cin, cout, kh, kw, h, w, b, relu):
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + kh * 7 + kw)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, kh, kw, s=0.05), _rand(rng, cout, s=0.1)
+    ref = _ref_conv(x, wt, bias, None)
+    if relu:
+        ref = ref.clamp_min(0)
+    # input and outputs are channel slices of wider buffers, as in the update block
+    xbuf = torch.full((b, cin + 7, h, w), float('nan'), device='cuda'); xbuf[:, 3:3 + cin] = x.cuda()
+    obuf = torch.full((b, cout + 5, h, w), -7.0, device='cuda'); o2buf = torch.full((b, cout + 2, h, w), -7.0, device='cuda')
+    pc = ops.PackedConv(wt.cuda(), bias.cuda())
+    ops.conv_fused(xbuf[:, 3:3 + cin], pc, ops.CONV_RELU if relu else ops.CONV_LINEAR, obuf[:, 4:4 + cout], out2=o2buf[:, 2:])
+    got = obuf[:, 4:4 + cout].cpu().double()
+    assert (got - ref).abs().max() < _tol(x, wt)
+    assert torch.equal(obuf[:, 4:4 + cout], o2buf[:, 2:])
+    assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all()            # neighbours untouched
+
+
+@pytest.mark.parametrize('kh,kw,h,w', [(1, 5, 64, 80), (5, 1, 64, 80), (1, 5, 44, 48), (5, 1, 44, 48)])
+def test_gru_half_step_matches_f64(rpe, kh, kw, h, w):
+    """z, r*h and the blended hidden state of one SepConvGRU half, fused into the two convolutions, against f64."""
+    from rpe_amd import ops
+    c, b = 128, 2
+    rng = np.random.default_rng(kh * 10 + kw + h)
+    hx = _rand(rng, b, 2 * c, h, w, s=0.5)
+    wzr, bzr, azr = _rand(rng, 2 * c, 2 * c, kh, kw, s=0.03), _rand(rng, 2 * c, s=0.1), _rand(rng, b, 2 * c, h, w, s=0.3)
+    wq, bq, aq = _rand(rng, c, 2 * c, kh, kw, s=0.03), _rand(rng, c, s=0.1), _rand(rng, b, c, h, w, s=0.3)
+    hid = hx[:, :c].double()
+    zr = torch.sigmoid(_ref_conv(hx, wzr, bzr, azr))
+    z, r = zr[:, :c], zr[:, c:]
+    rhx = torch.cat((r * hid, hx[:, c:].double()), 1)
+    q = torch.tanh(_ref_conv(rhx.float(), wq, bq, aq))      # the q convolution reads the f32 r*h the kernel stored
+    hnew = (1 - z) * hid + z * q
+
+    g_hx, g_rhx = hx.cuda(), hx.cuda().clone()
+    g_z = torch.empty(b, c, h, w, device='cuda')
+    pzr, pq = ops.PackedConv(wzr.cuda(), bzr.cuda()), ops.PackedConv(wq.cuda(), bq.cuda())
+    ops.conv_fused(g_hx, pzr, ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
+    tz = _tol(hx, wzr) * 0.25 + 2e-7
+    assert (g_z.cpu().double() - z).abs().max() < tz
+    assert (g_rhx[:, :c].cpu().double() - r * hid).abs().max() < tz * float(hx.abs().max())
+    assert torch.equal(g_rhx[:, c:], g_hx[:, c:])
+    ops.conv_fused(g_rhx, pq, ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)   # in place on h
+    assert (g_hx[:, :c].cpu().double() - hnew).abs().max() < _tol(hx, wq) + tz * 2
+    assert torch.equal(g_hx[:, c:].cpu(), hx[:, c:])
+
+
+def test_fused_gates_agree_with_the_separate_kernels(rpe):
+    """Same inputs through library convolution + rpe_gru_gates_* (the path used when the width is not a multiple of 4)."""
+    from rpe_amd import ops
+    c, b, h, w = 128, 1, 32, 40
+    rng = np.random.default_rng(5)
+    hx = _rand(rng, b, 2 * c, h, w, s=0.5).cuda()
+    wzr, bzr, azr = _rand(rng, 2 * c, 2 * c, 1, 5, s=0.03).cuda(), _rand(rng, 2 * c, s=0.1).cuda(), _rand(rng, b, 2 * c, h, w, s=0.3).cuda()
+    z1, rh1 = torch.empty(b, c, h, w, device='cuda'), hx.clone()
+    ops.gru_gates_zr(F.conv2d(hx, wzr, None, padding=(0, 2)), hx, c, z1, rh1, bias=bzr, add=azr)
+    z2, rh2 = torch.empty_like(z1), hx.clone()
+    ops.conv_fused(hx, ops.PackedConv(wzr, bzr), ops.CONV_GATE_ZR, z2, out2=rh2[:, :c], add=azr, hidden=hx[:, :c], gate_channels=c)
+    assert (z1 - z2).abs().max() < 2e-5 and (rh1 - rh2).abs().max() < 4e-5
+
+
+def test_unsupported_shapes_are_refused(rpe):
+    from rpe_amd import ops
+    x = torch.zeros(1, 16, 8, 10, device='cuda')                 # width not a multiple of 4
+    pc = ops.PackedConv(torch.zeros(8, 16, 3, 3, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
+        ops.conv_fused(x, pc, ops.CONV_LINEAR, torch.empty(1, 8, 8, 10, device='cuda'))
+    assert not ops.PackedConv.supported(torch.zeros(8, 16, 3, 3), 10) and ops.PackedConv.supported(torch.zeros(8, 16, 3, 3), 12)
+    with pytest.raises(rpe.RpeError):
+        ops.conv_fused(torch.zeros(1, 8, 8, 12, device='cuda'), pc, ops.CONV_LINEAR, torch.empty(1, 8, 8, 12, device='cuda'))
