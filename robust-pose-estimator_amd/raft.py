@@ -149,16 +149,24 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr, cat_buf, hx, rhx):
+    def forward(self, flow, corr, cat_buf, hx, rhx, packed=None):
         """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [128,256) of hx and rhx.
-        Convolutions run without bias; bias + ReLU (+ the cat / copies) are one HIP pass each (rpe_bias_act)."""
+        ``packed`` (BasicUpdateBlock.packed_convs) selects the fused HIP convolutions (conv + bias + ReLU + cat in
+        one kernel each); otherwise the library convolution runs without bias and rpe_bias_act does the rest."""
         def cv(m, x):
             return F.conv2d(x, m.weight, None, m.stride, m.padding)
-        cor = ops.bias_act(cv(self.convc1, corr), self.convc1.bias)
-        ops.bias_act(cv(self.convc2, cor), self.convc2.bias, out=cat_buf, out_offset=0)
-        flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)
-        ops.bias_act(cv(self.convf2, flo), self.convf2.bias, out=cat_buf, out_offset=192)
-        ops.bias_act(cv(self.conv, cat_buf), self.conv.bias, out=hx, out_offset=128, out2=rhx, out2_offset=128)
+        if packed is not None:
+            cor = ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, packed['cor_buf'](corr))
+            ops.conv_fused(cor, packed['convc2'], ops.CONV_RELU, cat_buf[:, :192])
+            flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)           # 7x7 on 2 channels: not a GEMM
+            ops.conv_fused(flo, packed['convf2'], ops.CONV_RELU, cat_buf[:, 192:])
+            ops.conv_fused(cat_buf, packed['conv'], ops.CONV_RELU, hx[:, 128:254], out2=rhx[:, 128:254])
+        else:
+            cor = ops.bias_act(cv(self.convc1, corr), self.convc1.bias)
+            ops.bias_act(cv(self.convc2, cor), self.convc2.bias, out=cat_buf, out_offset=0)
+            flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)
+            ops.bias_act(cv(self.convf2, flo), self.convf2.bias, out=cat_buf, out_offset=192)
+            ops.bias_act(cv(self.conv, cat_buf), self.conv.bias, out=hx, out_offset=128, out2=rhx, out2_offset=128)
         ops.bias_act(flow, None, relu=False, out=hx, out_offset=254, out2=rhx, out2_offset=254)
 
 
@@ -200,11 +208,48 @@ class BasicUpdateBlock(nn.Module):
         pads = {'zr1': (0, 2), 'q1': (0, 2), 'zr2': (2, 0), 'q2': (2, 0)}
         return {k: F.conv2d(inp, W[k][1], W[k][2], padding=pads[k]) for k in W}
 
+    def packed_convs(self, width):
+        """Weights of the update block's convolutions in rpe_conv_fused's layout (cached until a parameter changes), or
+        None when the fused kernels do not apply (map width not a multiple of 4)."""
+        if width % 4 != 0:
+            return None
+        e, fh = self.encoder, self.flow_head
+        mods = (e.convc1, e.convc2, e.convf2, e.conv, fh.conv1)
+        key = tuple(p._version for m in mods for p in m.parameters()) + tuple(p.data_ptr() for m in mods for p in m.parameters()) + \
+            (id(self.gate_weights()),)
+        if getattr(self, '_packed', None) is None or self._packed[0] != key:
+            W = self.gate_weights()
+            P = {n: ops.PackedConv(m.weight, m.bias) for n, m in zip(('convc1', 'convc2', 'convf2', 'conv', 'fh1'), mods)}
+            for n in ('zr1', 'q1', 'zr2', 'q2'):
+                P[n] = ops.PackedConv(W[n][0])                # bias is part of the context term (context_terms)
+            scratch = {}
+
+            def buf(name, like, c):                            # per-shape scratch for intermediate activations
+                k = (name, like.shape[0], c, like.shape[2], like.shape[3], like.device)
+                if k not in scratch:
+                    scratch[k] = torch.empty(like.shape[0], c, like.shape[2], like.shape[3], device=like.device)
+                return scratch[k]
+            P['cor_buf'] = lambda like: buf('cor', like, 256)
+            P['fh_buf'] = lambda like: buf('fh', like, 256)
+            self._packed = (key, P)
+        return self._packed[1]
+
     def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1):
         """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
-        Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (and, contiguous, in h_buf)."""
+        Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (h_buf is written by the library
+        path only: the fused flow head reads the slice directly)."""
         c = self.hidden_dim
-        self.encoder(flow, corr, cat_buf, hx, rhx)
+        P = self.packed_convs(hx.shape[-1])
+        self.encoder(flow, corr, cat_buf, hx, rhx, packed=P)
+        fh = self.flow_head
+        if P is not None:
+            # each GRU half = two implicit-GEMM convolutions whose epilogues are the gates:
+            #   z = s(convz hx + ctx), r*h -> rhx ;  h <- (1-z) h + z tanh(convq rhx + ctx)   (in place on hx[:, :c])
+            for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
+                ops.conv_fused(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c)
+                ops.conv_fused(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf)
+            t = ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx))
+            return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)  # coords1 + delta_flow
         W = self.gate_weights()
         # horizontal half: z = s(convz1 hx), r = s(convr1 hx), q = tanh(convq1 [r*h, x]), h = (1-z) h + z q
         zr = F.conv2d(hx, W['zr1'][0], None, padding=(0, 2))
@@ -217,7 +262,6 @@ class BasicUpdateBlock(nn.Module):
         q = F.conv2d(rhx, W['q2'][0], None, padding=(2, 0))
         ops.gru_gates_h(z_buf, q, hx, c, hx, add=ctx['q2'])
         h_buf.copy_(hx[:, :c])                                            # contiguous h for the heads
-        fh = self.flow_head
         t = ops.bias_act(F.conv2d(h_buf, fh.conv1.weight, None, padding=1), fh.conv1.bias)
         return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)      # coords1 + delta_flow
 
@@ -303,7 +347,9 @@ class RAFT(nn.Module):
             if all_flows or itr == iters - 1:
                 lowres = coords1 - coords0
                 if upsample:
+                    h_buf.copy_(hx[:, :c])                     # contiguous hidden state for the mask head
                     flow_predictions.append(ops.upsample_convex(lowres, self.update_block.up_mask(h_buf)))
                 else:
                     flow_predictions.append(lowres)
+        h_buf.copy_(hx[:, :c])
         return flow_predictions, h_buf, inp

@@ -62,6 +62,34 @@ def test_raft_matches_oracle(models):
     assert low[-1].shape == (2, 2, H // 8, W // 8) and float((low[-1].cpu() - olow[-1]).abs().max()) < 5e-3
 
 
+def test_fused_and_library_update_block_agree(models, monkeypatch):
+    """The update block has two GPU routes: fused implicit-GEMM convolutions (map width % 4 == 0) and the library
+    convolutions + separate gate / bias kernels (any width).  Same weights, same pair -> same flow to round-off."""
+    model, om, synth = models
+    fr = synth.stereo_frames(5, 1, H, W)
+    i1, i2 = fr['image1l'].cuda(), fr['image2l'].cuda()
+    ub = model.flow.update_block
+    assert ub.packed_convs(W // 8) is not None
+    fused, hid_f, _ = model.flow(i1, i2)
+    monkeypatch.setattr(type(ub), 'packed_convs', lambda self, width: None)
+    lib, hid_l, _ = model.flow(i1, i2)
+    d = float((fused[-1] - lib[-1]).abs().max())
+    print(f'fused vs library update block: flow diff {d:.2e} px')
+    assert d < 1e-3 and float((hid_f - hid_l).abs().max()) < 5e-3
+
+
+def test_library_route_for_odd_widths_matches_oracle(models):
+    """Map width 45 (not a multiple of 4): rpe_conv_fused refuses, the library route runs; parity with the oracle."""
+    model, om, synth = models
+    h, w = 352, 360
+    fr = synth.stereo_frames(6, 1, h, w)
+    assert model.flow.update_block.packed_convs(w // 8) is None
+    flows, _, _ = model.flow(fr['image1l'].cuda(), fr['image2l'].cuda())
+    with torch.no_grad():
+        oflows, _, _ = om.flow(fr['image1l'], fr['image2l'])
+    assert float((flows[-1].cpu() - oflows[-1]).abs().max()) < 1e-3
+
+
 def test_stages_match_oracle(models):
     model, om, synth = models
     fr = synth.stereo_frames(4, 2, H, W)                     # n = 2 frames: RAFT batch 4

@@ -70,6 +70,18 @@ def test_bad_arguments_return_status_without_a_gpu(rpe):
     assert L.rpe_corr_build(one, one, 1, 250, 8, 8, 4, one, null) == -1                                # channels % 16
     assert L.rpe_depth_backproject_warp(*([one] * 9), 1, 12, 16, *([one] * 8), null) == -1             # h % 8
     assert L.rpe_bias_act(one, null, 1, 4, 16, 1, one, 3, 0, null, 0, 0, null) == -1                   # slice overflow
+    # fused convolutions: descriptor validation and the layout of the ctypes mirror
+    from rpe_amd import _lib
+    assert ctypes.sizeof(_lib.ConvDesc) == 152
+    assert L.rpe_conv_packed_floats(256, 256, 1, 5) == 16 * 5 * 16 * 256 and L.rpe_conv_packed_floats(126, 324, 1, 1) == 21 * 16 * 128
+    assert L.rpe_conv_packed_floats(0, 4, 3, 3) == 0
+    assert L.rpe_conv_fused(None, null) == -1 and L.rpe_conv_pack(null, 8, 8, 3, 3, one, null) == -1
+    d = _lib.ConvDesc(x=16, packed=16, out=16, b=1, cin=16, cout=16, h=8, w=10, kh=3, kw=3, mode=0)
+    assert L.rpe_conv_fused(ctypes.byref(d), null) == -3                  # width % 4 != 0
+    d.w, d.kw = 12, 7
+    assert L.rpe_conv_fused(ctypes.byref(d), null) == -3                  # kernel width 7
+    d.kw, d.mode = 3, 2
+    assert L.rpe_conv_fused(ctypes.byref(d), null) == -1                  # GATE_ZR without out2 / hidden
 
 
 @pytest.mark.gpu
