@@ -22,6 +22,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CK 16
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)     /* nothing is scheduled across this point */
 
 struct ConvP {
     const float* x; long long xbs;            // first input channel of the slice; batch stride (floats)
@@ -132,27 +133,36 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             Bs[buf][n + 0][h_k] = v.x; Bs[buf][n + 1][h_k] = v.y; Bs[buf][n + 2][h_k] = v.z; Bs[buf][n + 3][h_k] = v.w;
         }
     };
+    // One step = 16 k-values of one tap = two halves of 16 MFMAs.  Half 1 (k = 8*lh + 0..3) runs on fragments that
+    // were read from LDS during the previous step; half 2 (k = 8*lh + 4..7) on fragments read at the top of this
+    // step.  The next tile goes to LDS and the workgroup barrier sits BETWEEN the halves, while 16 MFMAs are in
+    // flight, and the first-half fragments of the next step are read right after it: the matrix pipe never waits
+    // for an LDS round trip or for the barrier.  (Hazards: buffer (s+1)%2 is written before barrier(s); its last
+    // readers, halves of step s-1, sit before barrier(s-1).  Half-2 reads of step s precede barrier(s); the buffer
+    // they read is next written in step s+1, after barrier(s).)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    auto mma_step = [&](int curA, int curB, int dx) {            // 16 k-values of one tap: 8 ds_read_b128, 32 MFMAs
-        const float* arow = &As[curA][wm * 64 + l31][8 * lh];
-        const float* brow = &Bs[curB][4 + wn * 64 + l31 + dx][8 * lh];
-        f32x4 a0[2], a1[2], b0[2], b1[2];                        // k = 8*lh + 0..3 and + 4..7
-        a0[0] = *(const f32x4*)(arow);            a0[1] = *(const f32x4*)(arow + 4);
-        a1[0] = *(const f32x4*)(arow + 32 * KS);  a1[1] = *(const f32x4*)(arow + 32 * KS + 4);
-        b0[0] = *(const f32x4*)(brow);            b0[1] = *(const f32x4*)(brow + 4);
-        b1[0] = *(const f32x4*)(brow + 32 * KS);  b1[1] = *(const f32x4*)(brow + 32 * KS + 4);
-        if (KW > 1) {
-            const bool v0 = (unsigned)(xq0 + dx) < (unsigned)W, v1 = (unsigned)(xq1 + dx) < (unsigned)W;
-            const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            b0[0] = v0 ? b0[0] : z4; b0[1] = v0 ? b0[1] : z4; b1[0] = v1 ? b1[0] : z4; b1[1] = v1 ? b1[1] : z4;
-        }
+    f32x4 a0h1, a1h1, b0h1, b1h1, a0h2, a1h2, b0h2, b1h2;
+    auto read_h1 = [&](int bufA, int bufB, int dx) {
+        const float* arow = &As[bufA][wm * 64 + l31][8 * lh];
+        const float* brow = &Bs[bufB][4 + wn * 64 + l31 + dx][8 * lh];
+        a0h1 = *(const f32x4*)(arow); a1h1 = *(const f32x4*)(arow + 32 * KS);
+        b0h1 = *(const f32x4*)(brow); b1h1 = *(const f32x4*)(brow + 32 * KS);
+    };
+    auto read_h2 = [&](int bufA, int bufB, int dx) {
+        const float* arow = &As[bufA][wm * 64 + l31][8 * lh + 4];
+        const float* brow = &Bs[bufB][4 + wn * 64 + l31 + dx][8 * lh + 4];
+        a0h2 = *(const f32x4*)(arow); a1h2 = *(const f32x4*)(arow + 32 * KS);
+        b0h2 = *(const f32x4*)(brow); b1h2 = *(const f32x4*)(brow + 32 * KS);
+    };
+    auto mma_half = [&](const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, int dx) {
+        const bool v0 = KW == 1 || (unsigned)(xq0 + dx) < (unsigned)W, v1 = KW == 1 || (unsigned)(xq1 + dx) < (unsigned)W;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float fa0 = a0[j >> 2][j & 3], fa1 = a1[j >> 2][j & 3], fb0 = b0[j >> 2][j & 3], fb1 = b1[j >> 2][j & 3];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {                            // the column mask is applied at use, not at the read
+            const float fb0 = v0 ? b0[j] : 0.0f, fb1 = v1 ? b1[j] : 0.0f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb1, acc[1][1], 0, 0, 0);
         }
     };
 
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
         load_a(); load_b(R);
         store_a(0); store_b(R, 0);
         __syncthreads();
+        read_h1(0, 0, -PW);
         int step = 0;
         for (int g = 0; g < G; ++g) {
             const int curB = g & 1;
@@ -173,27 +184,40 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
                 const bool last = (g + 1 == G) && (t + 1 == KW);
                 if (!last) load_a();                              // weights first: their wait must not cover the
                 if (t == 0) load_b(R);                            // input loads issued after them (in-order return)
-                mma_step(curA, curB, t - PW);
+                read_h2(curA, curB, t - PW);
+                SCHED_FENCE();                                    // (keep the order written here: left alone, the
+                mma_half(a0h1, a1h1, b0h1, b1h1, t - PW);         //  scheduler sinks the global loads to just before
+                SCHED_FENCE();                                    //  the LDS stores and reads all fragments at once)
                 if (!last) store_a(curA ^ 1);
                 if (t == KW - 1 && g + 1 < G) store_b(R, curB ^ 1);
                 __syncthreads();
+                if (!last) read_h1(curA ^ 1, t == KW - 1 ? curB ^ 1 : curB, t == KW - 1 ? -PW : t + 1 - PW);
+                SCHED_FENCE();
+                mma_half(a0h2, a1h2, b0h2, b1h2, t - PW);
+                SCHED_FENCE();
             }
         }
     } else {
         RB R0, R1, R2;
-        load_b(R0);
-        if (G > 1) load_b(R1);
-        if (G > 2) load_b(R2);
+        load_b(R0); load_b(R1); load_b(R2);
         load_a();
         store_a(0); store_b(R0, 0);
         __syncthreads();
+        read_h1(0, 0, 0);
         auto body = [&](int g, RB& Rload, const RB& Rstore) {   // Rload: free (its tile is in LDS); Rstore: group g+1
             const int cur = g & 1;
             if (g + 1 < G) load_a();
             load_b(Rload);
-            mma_step(cur, cur, 0);
+            read_h2(cur, cur, 0);
+            SCHED_FENCE();
+            mma_half(a0h1, a1h1, b0h1, b1h1, 0);
+            SCHED_FENCE();
             if (g + 1 < G) { store_a(cur ^ 1); store_b(Rstore, cur ^ 1); }
             __syncthreads();
+            if (g + 1 < G) read_h1(cur ^ 1, cur ^ 1, 0);
+            SCHED_FENCE();
+            mma_half(a0h2, a1h2, b0h2, b1h2, 0);
+            SCHED_FENCE();
         };
         for (int g = 0; g < G; g += 3) {
             body(g, R0, R1);

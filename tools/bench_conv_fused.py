@@ -17,7 +17,7 @@ def t(fn, reps=10):
     return a.elapsed_time(b) / reps * 1e3
 
 dev = torch.device('cuda:0'); torch.manual_seed(0)
-N, H, W = 32, 64, 80
+N, H, W = int(os.environ.get("CONV_N", 32)), 64, 80
 cases = [('gru zr 1x5', 256, 256, 1, 5), ('gru q 1x5', 256, 128, 1, 5), ('gru zr 5x1', 256, 256, 5, 1), ('gru q 5x1', 256, 128, 5, 1),
          ('convc1 1x1', 324, 256, 1, 1), ('convc2 3x3', 256, 192, 3, 3), ('convf2 3x3', 128, 64, 3, 3), ('conv 3x3', 256, 126, 3, 3),
          ('fh1 3x3', 128, 256, 3, 3)]
