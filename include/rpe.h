@@ -205,9 +205,12 @@ int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int
  * (otherwise RPE_E_UNSUPPORTED: the caller keeps the library convolution + rpe_bias_act / rpe_gru_gates_*).
  * Every tensor argument is a pointer to channel 0 of a channel slice plus the batch stride (in floats) of the
  * buffer it lives in, so inputs and outputs can be slices of the concatenated (h | motion | flow) buffers.
- *   v = conv(x)[co][p] + add[co][p] + bias[co]
- *   RPE_CONV_LINEAR : out = v                      (and out2 = v when out2 != NULL)
- *   RPE_CONV_RELU   : out = max(v, 0)              (and out2)
+ *   v = conv(x)[co][p] * scale[co] + add[co][p] + bias[co]           (scale, add, bias: each may be NULL)
+ *   RPE_CONV_LINEAR : y = v;  RPE_CONV_RELU : y = max(v, 0);  then, if residual != NULL, y = max(residual + y, 0)
+ *                     (the encoder's ResidualBlock tail, core/RAFT/core/extractor.py); out = y (and out2 = y when
+ *                     out2 != NULL).  If stats != NULL the kernel also writes per-tile partial sums of v and v*v,
+ *                     stats[b][cout][rpe_conv_stats_tiles(cout,h,w)][2], for rpe_instnorm_apply (instance norm in one
+ *                     further read + write pass instead of three).
  *   RPE_CONV_GATE_ZR: cout = 2*gate_channels; co <  gate_channels: out[co]  = sigmoid(v)                 (z)
  *                                             co >= gate_channels: out2[co-gate_channels] = sigmoid(v) * hidden[co-gate_channels]  (r*h)
  *   RPE_CONV_GATE_H : out[co] = (1 - zgate[co]) * hidden[co] + zgate[co] * tanh(v);  out may alias hidden.        */
@@ -224,6 +227,9 @@ typedef struct rpe_conv_desc {
     float *out2;         long long out2_batch_stride;   /* NULL unless described above                             */
     const float *hidden; long long hidden_batch_stride; /* gates only                                              */
     const float *zgate;  long long zgate_batch_stride;  /* RPE_CONV_GATE_H only                                    */
+    const float *scale;                                  /* (cout) or NULL (folded batch norm: scale, bias = shift) */
+    const float *residual; long long residual_batch_stride; /* LINEAR / RELU only                                   */
+    float *stats;                                        /* LINEAR / RELU only                                      */
     int b, cin, cout, h, w, kh, kw, mode, gate_channels;
 } rpe_conv_desc;
 /* number of floats of the packed form of a (cout, cin, kh, kw) weight tensor (0 on bad arguments) */
@@ -231,6 +237,13 @@ size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
 /* weight (cout, cin, kh, kw) contiguous -> packed (tap-major 16-channel steps, output channels padded to 128) */
 int rpe_conv_pack(const float *weight, int cout, int cin, int kh, int kw, float *packed, void *stream);
 int rpe_conv_fused(const rpe_conv_desc *desc, void *stream);
+/* number of pixel tiles (= partial-sum slots per (b, channel) plane) rpe_conv_fused uses for this shape */
+int rpe_conv_stats_tiles(int cout, int h, int w);
+/* Instance norm (torch.nn.InstanceNorm2d, affine=False; fnet of core/RAFT/core/extractor.py) of x (b,c,hw) given the
+ * partial sums rpe_conv_fused left in `partials` (b,c,tiles,2):
+ *   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y,0); if (residual) y = max(residual + y, 0).  out may alias x. */
+int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
+                       const float *residual, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -36,15 +36,32 @@ struct ConvP {
     const float* h; long long hbs;            // hidden state, channels [0, c)
     const float* z; long long zbs;            // update gate (GATE_H)
     int cgate;
+    const float* scale;                       // [cout] or null: v = acc * scale + ...
+    const float* res; long long rbs;          // residual added after the activation, then ReLU again (encoder blocks)
+    float* stats;                             // [b][cout][tiles_n][2] partial (sum, sum of squares) of v, or null
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Sum over each 32-lane half of the wave with DPP moves (VALU rate, no LDS traffic): quad butterflies, row half-mirror,
+// row mirror, then lane 15 of each even 16-lane row is broadcast into the odd row.  Lanes 31 and 63 hold the totals.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));   // row_bcast:15 into rows 1, 3
+    return v;
+}
 
 // LDS layouts are K-contiguous: As[m][KS], Bs[4 + n][KS] with KS = 20 floats (16 used): a lane fetches the 8 k-values
 // it feeds to 8 consecutive MFMAs with two ds_read_b128 (rows 80 B apart: 16 consecutive rows tile the 64 banks
 // exactly, so reads, the float4 weight stores and the transposing 4-B input stores are all conflict-free).  The MFMA
 // sums over k in any order, so lane half lh of k2-step j supplies k = 8*lh + j for both operands.
-template <int KW, int WM>
+// ENC = false: update-block epilogues (bias / addend / ReLU / GRU gates).  ENC = true: encoder epilogues (folded batch
+// norm scale+shift, ReLU, residual, partial statistics for instance norm) and output tiles whose upper 32 rows may be
+// missing (cout = 96).  Two instantiations keep the update-block kernels free of the encoder's registers and branches.
+template <int KW, int WM, bool ENC>
 __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     constexpr int WN = 4 / WM, BM = 64 * WM, BN = 64 * WN, PW = KW / 2;
     constexpr int KS = 20;
@@ -142,6 +159,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     // they read is next written in step s+1, after barrier(s).)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 a0h1, a1h1, b0h1, b1h1, a0h2, a1h2, b0h2, b1h2;
+    const bool hi_rows = m0 + wm * 64 + 32 < P.cout;
     auto read_h1 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * 64 + l31][8 * lh];
         const float* brow = &Bs[bufB][4 + wn * 64 + l31 + dx][8 * lh];
@@ -156,13 +174,23 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     };
     auto mma_half = [&](const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, int dx) {
         const bool v0 = KW == 1 || (unsigned)(xq0 + dx) < (unsigned)W, v1 = KW == 1 || (unsigned)(xq1 + dx) < (unsigned)W;
+        float fb0[4], fb1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                            // the column mask is applied at use, not at the read
-            const float fb0 = v0 ? b0[j] : 0.0f, fb1 = v1 ? b1[j] : 0.0f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb1, acc[1][1], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) { fb0[j] = v0 ? b0[j] : 0.0f; fb1[j] = v1 ? b1[j] : 0.0f; }   // column mask at use, not at the read
+        if (!ENC || hi_rows) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb1[j], acc[1][1], 0, 0, 0);
+            }
+        } else {                                                 // wave-uniform: rows 32..63 of this tile do not exist
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1[j], acc[0][1], 0, 0, 0);
+            }
         }
     };
 
@@ -228,38 +256,121 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int mode = P.mode, cg = P.cgate;
+    if (!ENC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int px = n0 + wn * 64 + j * 32 + l31;
+                if (px >= hw) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (co >= P.cout) continue;
+                    float v = acc[i][j][r];
+                    if (P.add) v += P.add[(size_t)bz * P.abs_ + (size_t)co * hw + px];
+                    if (P.bias) v += P.bias[co];
+                    if (mode == RPE_CONV_GATE_ZR) {
+                        const float sg = sigmoid_f(v);
+                        if (co < cg) P.out[(size_t)bz * P.obs + (size_t)co * hw + px] = sg;
+                        else {
+                            const size_t e = (size_t)(co - cg) * hw + px;
+                            P.out2[(size_t)bz * P.o2bs + e] = sg * P.h[(size_t)bz * P.hbs + e];
+                        }
+                    } else if (mode == RPE_CONV_GATE_H) {
+                        const size_t e = (size_t)co * hw + px;
+                        const float zv = P.z[(size_t)bz * P.zbs + e], hv = P.h[(size_t)bz * P.hbs + e];
+                        P.out[(size_t)bz * P.obs + e] = (1.0f - zv) * hv + zv * tanhf(v);
+                    } else {
+                        if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;        // NaN stays NaN, like torch.relu
+                        const size_t e = (size_t)co * hw + px;
+                        P.out[(size_t)bz * P.obs + e] = v;
+                        if (P.out2) P.out2[(size_t)bz * P.o2bs + e] = v;
+                    }
+                }
+            }
+        return;
+    }
+    float* red = &As[0][0][0];                                   // [WN][BM][2] partial statistics (LDS is free now:
+                                                                 // nothing reads the tiles after the last barrier)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int px = n0 + wn * 64 + j * 32 + l31;
-            if (px >= hw) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = m0 + row;
+            const bool cok = co < P.cout;
+            const float sc = (P.scale && cok) ? P.scale[co] : 1.0f, bi = (P.bias && cok) ? P.bias[co] : 0.0f;
+            float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co >= P.cout) continue;
+            for (int j = 0; j < 2; ++j) {
+                const int px = n0 + wn * 64 + j * 32 + l31;
+                if (!cok || px >= hw) continue;
                 float v = acc[i][j][r];
+                if (P.scale) v *= sc;
                 if (P.add) v += P.add[(size_t)bz * P.abs_ + (size_t)co * hw + px];
-                if (P.bias) v += P.bias[co];
-                if (mode == RPE_CONV_GATE_ZR) {
-                    const float s = sigmoid_f(v);
-                    if (co < cg) P.out[(size_t)bz * P.obs + (size_t)co * hw + px] = s;
-                    else {
-                        const size_t e = (size_t)(co - cg) * hw + px;
-                        P.out2[(size_t)bz * P.o2bs + e] = s * P.h[(size_t)bz * P.hbs + e];
-                    }
-                } else if (mode == RPE_CONV_GATE_H) {
-                    const size_t e = (size_t)co * hw + px;
-                    const float zv = P.z[(size_t)bz * P.zbs + e], hv = P.h[(size_t)bz * P.hbs + e];
-                    P.out[(size_t)bz * P.obs + e] = (1.0f - zv) * hv + zv * tanhf(v);
-                } else {
-                    if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;        // NaN stays NaN, like torch.relu
-                    const size_t e = (size_t)co * hw + px;
-                    P.out[(size_t)bz * P.obs + e] = v;
-                    if (P.out2) P.out2[(size_t)bz * P.o2bs + e] = v;
-                }
+                v += bi;
+                ssum += v; ssq += v * v;
+                if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;
+                const size_t e = (size_t)co * hw + px;
+                if (P.res) { v = P.res[(size_t)bz * P.rbs + e] + v; v = v < 0.0f ? 0.0f : v; }
+                P.out[(size_t)bz * P.obs + e] = v;
+                if (P.out2) P.out2[(size_t)bz * P.o2bs + e] = v;
+            }
+            if (P.stats) {                                       // sum over the 32 lanes that share this channel row
+                ssum = half_wave_sum(ssum); ssq = half_wave_sum(ssq);
+                if (l31 == 31) { red[(wn * BM + row) * 2] = ssum; red[(wn * BM + row) * 2 + 1] = ssq; }
             }
         }
+    if (P.stats) {                                               // combine the WN waves that cover the same channels
+        __syncthreads();
+        if (tid < BM && m0 + tid < P.cout) {
+            float a = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int w2 = 0; w2 < WN; ++w2) { a += red[(w2 * BM + tid) * 2]; q += red[(w2 * BM + tid) * 2 + 1]; }
+            float* st = P.stats + (((size_t)bz * P.cout + m0 + tid) * gridDim.x + blockIdx.x) * 2;
+            st[0] = a; st[1] = q;
+        }
+    }
+}
+
+// Instance norm from the per-tile partial sums k_conv_igemm left behind: one workgroup per (b, c) plane combines them
+// in f64 (mean, biased variance as E[x^2] - mean^2), then normalises in ONE read + write pass:
+//   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y, 0); if (residual) y = max(residual + y, 0)
+__global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict__ x, const float* __restrict__ partials, int tiles, int hw,
+                                                        float eps, int relu, const float* __restrict__ residual, float* __restrict__ out) {
+    const int plane = blockIdx.x;
+    __shared__ double rs[4], rq[4];
+    __shared__ float s_mean, s_inv;
+    double a = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
+        a += (double)partials[((size_t)plane * tiles + i) * 2]; q += (double)partials[((size_t)plane * tiles + i) * 2 + 1];
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = a; rq[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sa = rs[0] + rs[1] + rs[2] + rs[3], sq = rq[0] + rq[1] + rq[2] + rq[3];
+        const double mean = sa / hw;
+        double var = sq / hw - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        s_mean = (float)mean; s_inv = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mean = s_mean, inv = s_inv;
+    const float4* xp = (const float4*)(x + (size_t)plane * hw);
+    const float4* rp = residual ? (const float4*)(residual + (size_t)plane * hw) : nullptr;
+    float4* op = (float4*)(out + (size_t)plane * hw);
+    auto fin = [&](float v, float r) -> float {
+        float y = (v - mean) * inv;
+        if (relu) y = y < 0.0f ? 0.0f : y;
+        if (rp) { y = r + y; y = y < 0.0f ? 0.0f : y; }
+        return y;
+    };
+    for (int i = threadIdx.x; i < (hw >> 2); i += blockDim.x) {
+        const float4 v = xp[i];
+        const float4 r = rp ? rp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        op[i] = make_float4(fin(v.x, r.x), fin(v.y, r.y), fin(v.z, r.z), fin(v.w, r.w));
+    }
 }
 
 // (cout, cin, kh, kw) -> [step = (chunk*kh + dy)*kw + dx][k4 = 0..3][coP][4]: element (step, k = 4*k4 + e, co) is
@@ -293,7 +404,7 @@ extern "C" int rpe_conv_pack(const float* weight, int cout, int cin, int kh, int
     return rpe_check_launch();
 }
 
-static_assert(sizeof(rpe_conv_desc) == 152, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
+static_assert(sizeof(rpe_conv_desc) == 184, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
@@ -303,19 +414,39 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     if (d->mode < RPE_CONV_LINEAR || d->mode > RPE_CONV_GATE_H) return RPE_E_BADARG;
     if (d->mode == RPE_CONV_GATE_ZR && (!d->out2 || !d->hidden || d->gate_channels <= 0 || d->cout != 2 * d->gate_channels)) return RPE_E_BADARG;
     if (d->mode == RPE_CONV_GATE_H && (!d->hidden || !d->zgate)) return RPE_E_BADARG;
+    if ((d->mode == RPE_CONV_GATE_ZR || d->mode == RPE_CONV_GATE_H) && (d->scale || d->residual || d->stats)) return RPE_E_BADARG;
     ConvP P;
     P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed;
     P.cin = d->cin; P.cout = d->cout; P.coP = conv_cop(d->cout); P.H = d->h; P.W = d->w; P.hw = d->h * d->w; P.kh = d->kh;
     P.bias = d->bias; P.add = d->add; P.abs_ = d->add_batch_stride; P.mode = d->mode;
     P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.h = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels;
+    P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (d->cout % 128) != 0;          // 64-row tiles waste less when cout is 64, 126, 192
     const int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
     dim3 grid(ceil_div(P.hw, BN), ceil_div(d->cout, BM), d->b), block(256);
-#define LAUNCH(KW_, WM_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_>), grid, block, 0, s, P)
-    if (wide) { if (d->kw == 1) LAUNCH(1, 1); else if (d->kw == 3) LAUNCH(3, 1); else LAUNCH(5, 1); }
-    else      { if (d->kw == 1) LAUNCH(1, 2); else if (d->kw == 3) LAUNCH(3, 2); else LAUNCH(5, 2); }
+#define LAUNCH(KW_, WM_, ENC_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_>), grid, block, 0, s, P)
+    const bool half_tile = (d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3 && d->mode <= RPE_CONV_RELU;   // cout = 96
+    const bool enc = d->scale || d->residual || d->stats || half_tile;
+    if (enc) {                                       // encoder epilogues exist for the encoders' 3x3 convolutions only
+        if (d->kw != 3 || d->mode > RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
+        if (wide) LAUNCH(3, 1, true); else LAUNCH(3, 2, true);
+    } else if (wide) { if (d->kw == 1) LAUNCH(1, 1, false); else if (d->kw == 3) LAUNCH(3, 1, false); else LAUNCH(5, 1, false); }
+    else             { if (d->kw == 1) LAUNCH(1, 2, false); else if (d->kw == 3) LAUNCH(3, 2, false); else LAUNCH(5, 2, false); }
 #undef LAUNCH
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_conv_stats_tiles(int cout, int h, int w) {
+    if (cout <= 0 || h <= 0 || w <= 0) return 0;
+    return ceil_div((int64_t)h * w, (cout % 128) != 0 ? 256 : 128);
+}
+
+extern "C" int rpe_instnorm_apply(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,
+                                  const float* residual, float* out, void* stream) {
+    if (!x || !partials || !out || tiles <= 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, hw, eps, relu, residual, out);
     return rpe_check_launch();
 }

@@ -342,15 +342,23 @@ class PackedConv:
         return kh % 2 == 1 and kw in (1, 3, 5) and width % 4 == 0
 
 
-def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0):
-    """rpe_conv_fused: out = epilogue(conv(x; pc) + add + bias).  All tensors are channel slices of NCHW buffers."""
+def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
+               residual=None, stats=None):
+    """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.
+    ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the partial sums
+    instnorm_apply needs."""
     d = _lib.ConvDesc()
     b, cin, hh, ww = x.shape
     if cin != pc.cin:
         raise _lib.RpeError(f'conv_fused: input has {cin} channels, weights expect {pc.cin}')
     d.x, d.x_batch_stride = _chan_slice(x, 'x')
-    d.packed, d.bias = ptr(pc.packed), ptr(pc.bias)
-    for name, t, want_c in (('add', add, pc.cout), ('out', out, None), ('out2', out2, None), ('hidden', hidden, None), ('zgate', zgate, None)):
+    bias = pc.bias if isinstance(bias, str) else bias
+    for name, t in (('bias', bias), ('scale', scale)):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != pc.cout):
+            raise _lib.RpeError(f'conv_fused: {name} must be a contiguous float32 GPU vector of cout elements')
+    d.packed, d.bias, d.scale = ptr(pc.packed), ptr(bias), ptr(scale)
+    for name, t, want_c in (('add', add, pc.cout), ('out', out, None), ('out2', out2, None), ('hidden', hidden, None), ('zgate', zgate, None),
+                            ('residual', residual, pc.cout)):
         if t is None:
             setattr(d, name, None); setattr(d, name + '_batch_stride', 0)
             continue
@@ -365,7 +373,32 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
         raise _lib.RpeError('conv_fused: GATE_H needs hidden and zgate with cout channels')
     if mode in (CONV_LINEAR, CONV_RELU) and out2 is not None and out2.shape[1] < pc.cout:
         raise _lib.RpeError('conv_fused: out2 slice has too few channels')
+    if stats is not None:
+        tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww)
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 2)):
+            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},2) GPU tensor')
+    d.stats = ptr(stats)
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.gate_channels = b, cin, pc.cout, hh, ww, pc.kh, pc.kw, mode, gate_channels
     import ctypes
     check(lib().rpe_conv_fused(ctypes.byref(d), stream_ptr()), 'rpe_conv_fused')
+    return out
+
+
+def conv_stats_buffer(b, cout, hh, ww, device):
+    """Partial-sum buffer rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 2)."""
+    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww), 2, dtype=torch.float32, device=device)
+
+
+def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):
+    """Instance norm of x (b,c,h,w) from the partial sums of conv_fused(..., stats=stats): one read + one write pass."""
+    _nchw(x, 'x')
+    b, c, hh, ww = x.shape
+    if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and tuple(stats.shape[:2]) == (b, c)
+            and stats.shape[3] == 2):
+        raise _lib.RpeError('instnorm_apply: stats must be the (b,c,tiles,2) buffer of conv_fused')
+    if residual is not None and _nchw(residual, 'residual').shape != x.shape:
+        raise _lib.RpeError('instnorm_apply: residual must have the shape of x')
+    out = x if out is None else _nchw(out, 'out')
+    check(lib().rpe_instnorm_apply(ptr(x), ptr(stats), stats.shape[2], b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
+                                   stream_ptr()), 'rpe_instnorm_apply')
     return out

@@ -69,15 +69,37 @@ def _bn_affine(conv, norm):
     return cached[1], cached[2]
 
 
+def _packed(conv):
+    """PackedConv of a module's weight (no bias), cached on the module until the weight changes."""
+    key = (conv.weight._version, conv.weight.data_ptr())
+    cached = getattr(conv, '_rpe_packed', None)
+    if cached is None or cached[0] != key:
+        conv._rpe_packed = cached = (key, ops.PackedConv(conv.weight, None))
+    return cached[1]
+
+
 def conv_norm_act(conv, norm, x, relu, residual=None):
-    pre = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
-    if isinstance(norm, nn.InstanceNorm2d):
-        return ops.instnorm_act(pre, conv.bias, eps=norm.eps, relu=relu, residual=residual)
+    """norm(conv(x) + bias) [ReLU] [+ residual, ReLU].  Stride-1 3x3 convolutions on maps whose width is a multiple of
+    4 run on the fused HIP implicit GEMM (folded batch norm / ReLU / residual inside its epilogue; for instance norm the
+    epilogue leaves per-tile partial sums and one more read+write pass normalises); the stride-2 and 7x7 / 1x1
+    convolutions stay on the library with a fused HIP epilogue pass."""
+    fused = conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and x.shape[-1] % 4 == 0 and x.is_contiguous()
     if isinstance(norm, nn.BatchNorm2d):
         if norm.training:
             raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')
         scale, shift = _bn_affine(conv, norm)
-        return ops.affine_act(pre, scale, shift, relu=relu, residual=residual)
+        if fused:
+            out = torch.empty(x.shape[0], conv.out_channels, x.shape[2], x.shape[3], device=x.device)
+            return ops.conv_fused(x, _packed(conv), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, scale=scale, bias=shift, residual=residual)
+        return ops.affine_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), scale, shift, relu=relu, residual=residual)
+    if isinstance(norm, nn.InstanceNorm2d):
+        if fused:
+            b, _, hh, ww = x.shape
+            stats = ops.conv_stats_buffer(b, conv.out_channels, hh, ww, x.device)
+            pre = ops.conv_fused(x, _packed(conv), ops.CONV_LINEAR, torch.empty(b, conv.out_channels, hh, ww, device=x.device),
+                                 bias=conv.bias.detach(), stats=stats)
+            return ops.instnorm_apply(pre, stats, eps=norm.eps, relu=relu, residual=residual)
+        return ops.instnorm_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), conv.bias, eps=norm.eps, relu=relu, residual=residual)
     raise NotImplementedError(type(norm))
 
 

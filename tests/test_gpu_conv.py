@@ -108,3 +108,37 @@ def test_unsupported_shapes_are_refused(rpe):
     assert not ops.PackedConv.supported(torch.zeros(8, 16, 3, 3), 10) and ops.PackedConv.supported(torch.zeros(8, 16, 3, 3), 12)
     with pytest.raises(rpe.RpeError):
         ops.conv_fused(torch.zeros(1, 8, 8, 12, device='cuda'), pc, ops.CONV_LINEAR, torch.empty(1, 8, 8, 12, device='cuda'))
+
+
+@pytest.mark.parametrize('c,h,w,b', [(64, 64, 80, 3), (96, 44, 48, 2), (128, 32, 40, 2)])
+def test_encoder_block_epilogues_match_f64(rpe, c, h, w, b):
+    """The two encoder epilogues: folded batch norm (scale, shift) + ReLU + residual + ReLU in the convolution, and
+    instance norm from the partial sums the convolution leaves behind (rpe_instnorm_apply)."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(c + h)
+    x, wt, bias = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, s=0.5)
+    res = _rand(rng, b, c, h, w).abs()
+    scale, shift = _rand(rng, c).abs() + 0.5, _rand(rng, c, s=0.3)
+    pc = ops.PackedConv(wt.cuda(), bias.cuda())
+    conv = F.conv2d(x.double(), wt.double(), None, padding=1)
+    # cnet: y = max(res + max(conv*scale + shift, 0), 0)
+    ref = (res.double() + (conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]).clamp_min(0)).clamp_min(0)
+    got = ops.conv_fused(x.cuda(), pc, ops.CONV_RELU, torch.empty(b, c, h, w, device='cuda'), scale=scale.cuda(), bias=shift.cuda(),
+                         residual=res.cuda())
+    assert (got.cpu().double() - ref).abs().max() < _tol(x, wt) * 2.5
+    # fnet: instance norm of conv + bias, ReLU, residual, ReLU
+    pre = conv + bias.double()[None, :, None, None]
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    ref2 = (res.double() + ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)).clamp_min(0)
+    stats = ops.conv_stats_buffer(b, c, h, w, 'cuda')
+    raw = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), stats=stats)
+    assert (raw.cpu().double() - pre).abs().max() < _tol(x, wt)
+    ssum = stats[..., 0].sum(-1).cpu().double() / (h * w)
+    assert (ssum - mean[:, :, 0, 0]).abs().max() < 1e-5
+    got2 = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True, residual=res.cuda())
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert (got2.cpu().double() - ref2).abs().max() < (_tol(x, wt) + 2e-6) * inv * 2
+    # and against the three-pass kernel on the same raw tensor
+    raw2 = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'))
+    three = ops.instnorm_act(raw2, None, eps=1e-5, relu=True, residual=res.cuda())
+    assert (three - got2).abs().max() < 2e-5 * inv
