@@ -330,26 +330,33 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
     for (int pass = 0; pass < LK_PASSES; ++pass) {
         // ---- loader: 16 coalesced 16-B loads per lane-group of 16
         f32x4 v[16];
+        unsigned okbits = 0;                    // which of the 16 pieces are inside the map: applied when they go to LDS (a
+                                                // select right after the load makes the compiler branch around every load
+                                                // and wait for each shuffle in turn)
+        int pks[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pks[i] = __shfl(my_packed, 4 * i + ld_sub, 64);   // all shuffles first: one LDS round trip
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int src = 4 * i + ld_sub;                                          // query (within the wave) served
-            const int pk = __shfl(my_packed, src, 64);
+            const int pk = pks[i];
             const int ylo_s = (int)((unsigned)pk >> 16) - 32768, tx0_s = ((pk >> 2) & 0x3fff) - 8192, need4_s = pk & 1;
             const int last_row = (pk & 2) ? WIN + 1 : WIN;                           // highest footprint row index needed
             const int qs = q_wave0 + src;
             const int yy = ylo_s + 4 * pass + ld_row;
             const int tx = tx0_s + ld_piece;
-            const bool ok = qs < nq && (4 * pass + ld_row) <= last_row && yy >= 0 && yy < hl && tx >= 0 && tx < txc &&
-                            (ld_piece < 3 || need4_s);
+            // (bitwise &, not &&: short-circuit evaluation puts a branch in front of every load)
+            const bool ok = (qs < nq) & ((4 * pass + ld_row) <= last_row) & (yy >= 0) & (yy < hl) & (tx >= 0) & (tx < txc) &
+                            ((ld_piece < 3) | (need4_s != 0));
             const float* p = lvl + (size_t)(ok ? qs : 0) * S + (ok ? ((((yy >> 2) * txc + tx) << 4) + ((yy & 3) << 2)) : 0);
-            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             v[i] = *(const f32x4*)p;
-            v[i] = ok ? v[i] : zero;
+            okbits |= ok ? (1u << i) : 0u;
         }
         __syncthreads();                                                             // previous pass fully consumed
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            *(f32x4*)(wstage + (4 * i + ld_sub) * LK_QSTRIDE + ld_row * 16 + ld_piece * 4) = v[i];
+            *(f32x4*)(wstage + (4 * i + ld_sub) * LK_QSTRIDE + ld_row * 16 + ld_piece * 4) = ((okbits >> i) & 1) ? v[i] : zero;
         __syncthreads();
         // ---- consumer: lane = query
         const float* mine = wstage + lane * LK_QSTRIDE;
