@@ -61,9 +61,11 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // ENC = false: update-block epilogues (bias / addend / ReLU / GRU gates).  ENC = true: encoder epilogues (folded batch
 // norm scale+shift, ReLU, residual, partial statistics for instance norm) and output tiles whose upper 32 rows may be
 // missing (cout = 96).  Two instantiations keep the update-block kernels free of the encoder's registers and branches.
-template <int KW, int WM, bool ENC>
+// T = 32x32 MFMA blocks per wave in each direction: 2 -> 64x64 per wave (tiles 128x128 / 64x256), 1 -> 32x32 per wave
+// (tile 64x64, for launches that would not fill the chip with the large tiles: batch-1 tracking).
+template <int KW, int WM, bool ENC, int T>
 __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
-    constexpr int WN = 4 / WM, BM = 64 * WM, BN = 64 * WN, PW = KW / 2;
+    constexpr int WN = 4 / WM, WT = 32 * T, BM = WT * WM, BN = WT * WN, PW = KW / 2;
     constexpr int KS = 20;
     constexpr int NLA = BM / 64;                                 // float4 per thread of the [4 k4][BM] weights tile
     constexpr int NLB = BN / 64;                                 // float4 per thread of the [16 k][BN/4] input tile
@@ -83,16 +85,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const float* xrow = P.x + (size_t)bz * P.xbs + (size_t)b_k * hw;          // channel row b_k of chunk 0
     const float* xrow_h = P.x + (size_t)bz * P.xbs + (size_t)h_k * hw;
 
-    f32x16 acc[2][2];
+    f32x16 acc[T][T];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < T; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // x coordinate of this lane's two B columns: decides which taps fall off the row
-    const int xq0 = (n0 + wn * 64 + l31) % W, xq1 = (n0 + wn * 64 + 32 + l31) % W;
+    const int xq0 = (n0 + wn * WT + l31) % W, xq1 = (n0 + wn * WT + 32 + l31) % W;
 
     const int nchunk = (P.cin + CK - 1) / CK;
     const int G = nchunk * P.kh;                                 // (channel chunk, dy) groups; each has KW steps
@@ -159,37 +161,40 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     // they read is next written in step s+1, after barrier(s).)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 a0h1, a1h1, b0h1, b1h1, a0h2, a1h2, b0h2, b1h2;
-    const bool hi_rows = m0 + wm * 64 + 32 < P.cout;
+    const bool hi_rows = T == 1 || m0 + wm * WT + 32 < P.cout;
     auto read_h1 = [&](int bufA, int bufB, int dx) {
-        const float* arow = &As[bufA][wm * 64 + l31][8 * lh];
-        const float* brow = &Bs[bufB][4 + wn * 64 + l31 + dx][8 * lh];
-        a0h1 = *(const f32x4*)(arow); a1h1 = *(const f32x4*)(arow + 32 * KS);
-        b0h1 = *(const f32x4*)(brow); b1h1 = *(const f32x4*)(brow + 32 * KS);
+        const float* arow = &As[bufA][wm * WT + l31][8 * lh];
+        const float* brow = &Bs[bufB][4 + wn * WT + l31 + dx][8 * lh];
+        a0h1 = *(const f32x4*)(arow); b0h1 = *(const f32x4*)(brow);
+        if (T == 2) { a1h1 = *(const f32x4*)(arow + 32 * KS); b1h1 = *(const f32x4*)(brow + 32 * KS); }
     };
     auto read_h2 = [&](int bufA, int bufB, int dx) {
-        const float* arow = &As[bufA][wm * 64 + l31][8 * lh + 4];
-        const float* brow = &Bs[bufB][4 + wn * 64 + l31 + dx][8 * lh + 4];
-        a0h2 = *(const f32x4*)(arow); a1h2 = *(const f32x4*)(arow + 32 * KS);
-        b0h2 = *(const f32x4*)(brow); b1h2 = *(const f32x4*)(brow + 32 * KS);
+        const float* arow = &As[bufA][wm * WT + l31][8 * lh + 4];
+        const float* brow = &Bs[bufB][4 + wn * WT + l31 + dx][8 * lh + 4];
+        a0h2 = *(const f32x4*)(arow); b0h2 = *(const f32x4*)(brow);
+        if (T == 2) { a1h2 = *(const f32x4*)(arow + 32 * KS); b1h2 = *(const f32x4*)(brow + 32 * KS); }
     };
     auto mma_half = [&](const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, int dx) {
         const bool v0 = KW == 1 || (unsigned)(xq0 + dx) < (unsigned)W, v1 = KW == 1 || (unsigned)(xq1 + dx) < (unsigned)W;
         float fb0[4], fb1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fb0[j] = v0 ? b0[j] : 0.0f; fb1[j] = v1 ? b1[j] : 0.0f; }   // column mask at use, not at the read
-        if (!ENC || hi_rows) {
+        if (T == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
+        } else if (!ENC || hi_rows) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb1[j], acc[1][1], 0, 0, 0);
+                acc[0][T - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1[j], acc[0][T - 1], 0, 0, 0);
+                acc[T - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb0[j], acc[T - 1][0], 0, 0, 0);
+                acc[T - 1][T - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], fb1[j], acc[T - 1][T - 1], 0, 0, 0);
             }
         } else {                                                 // wave-uniform: rows 32..63 of this tile do not exist
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1[j], acc[0][1], 0, 0, 0);
+                acc[0][T - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb1[j], acc[0][T - 1], 0, 0, 0);
             }
         }
     };
@@ -258,14 +263,14 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const int mode = P.mode, cg = P.cgate;
     if (!ENC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < T; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int px = n0 + wn * 64 + j * 32 + l31;
+            for (int j = 0; j < T; ++j) {
+                const int px = n0 + wn * WT + j * 32 + l31;
                 if (px >= hw) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int co = m0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (co >= P.cout) continue;
                     float v = acc[i][j][r];
                     if (P.add) v += P.add[(size_t)bz * P.abs_ + (size_t)co * hw + px];
@@ -294,16 +299,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     float* red = &As[0][0][0];                                   // [WN][BM][2] partial statistics (LDS is free now:
                                                                  // nothing reads the tiles after the last barrier)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < T; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = m0 + row;
+            const int row = wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = m0 + row;
             const bool cok = co < P.cout;
             const float sc = (P.scale && cok) ? P.scale[co] : 1.0f, bi = (P.bias && cok) ? P.bias[co] : 0.0f;
             float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int px = n0 + wn * 64 + j * 32 + l31;
+            for (int j = 0; j < T; ++j) {
+                const int px = n0 + wn * WT + j * 32 + l31;
                 if (!cok || px >= hw) continue;
                 float v = acc[i][j][r];
                 if (P.scale) v *= sc;
@@ -423,17 +428,22 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     P.h = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels;
     P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats;
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = (d->cout % 128) != 0;          // 64-row tiles waste less when cout is 64, 126, 192
-    const int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
-    dim3 grid(ceil_div(P.hw, BN), ceil_div(d->cout, BM), d->b), block(256);
-#define LAUNCH(KW_, WM_, ENC_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_>), grid, block, 0, s, P)
+    bool wide = (d->cout % 128) != 0;                // 64-row tiles waste less when cout is 64, 126, 192
+    int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
     const bool half_tile = (d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3 && d->mode <= RPE_CONV_RELU;   // cout = 96
     const bool enc = d->scale || d->residual || d->stats || half_tile;
+    // Launches that would leave most of the 256 CUs with at most one workgroup use 64x64 tiles instead (4x the
+    // workgroups, 6+ of them resident per CU): the batch-1 / batch-2 maps of sequential tracking.
+    const bool small = !enc && (long long)ceil_div(P.hw, BN) * ceil_div(d->cout, BM) * d->b < 512;
+    if (small) { BM = 64; BN = 64; }
+    dim3 grid(ceil_div(P.hw, BN), ceil_div(d->cout, BM), d->b), block(256);
+#define LAUNCH(KW_, WM_, ENC_, T_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_, T_>), grid, block, 0, s, P)
     if (enc) {                                       // encoder epilogues exist for the encoders' 3x3 convolutions only
         if (d->kw != 3 || d->mode > RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
-        if (wide) LAUNCH(3, 1, true); else LAUNCH(3, 2, true);
-    } else if (wide) { if (d->kw == 1) LAUNCH(1, 1, false); else if (d->kw == 3) LAUNCH(3, 1, false); else LAUNCH(5, 1, false); }
-    else             { if (d->kw == 1) LAUNCH(1, 2, false); else if (d->kw == 3) LAUNCH(3, 2, false); else LAUNCH(5, 2, false); }
+        if (wide) LAUNCH(3, 1, true, 2); else LAUNCH(3, 2, true, 2);
+    } else if (small) { if (d->kw == 1) LAUNCH(1, 2, false, 1); else if (d->kw == 3) LAUNCH(3, 2, false, 1); else LAUNCH(5, 2, false, 1); }
+    else if (wide) { if (d->kw == 1) LAUNCH(1, 1, false, 2); else if (d->kw == 3) LAUNCH(3, 1, false, 2); else LAUNCH(5, 1, false, 2); }
+    else           { if (d->kw == 1) LAUNCH(1, 2, false, 2); else if (d->kw == 3) LAUNCH(3, 2, false, 2); else LAUNCH(5, 2, false, 2); }
 #undef LAUNCH
     return rpe_check_launch();
 }
