@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--raft-iters', type=int, default=12)
     ap.add_argument('--solver', default='lbfgs', choices=['lbfgs', 'gn'])
     ap.add_argument('--solver-iters', type=int, default=8)
-    ap.add_argument('--cpu-frames', type=int, default=4, help='frames timed on the CPU oracle (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=8, help='frames timed on the CPU oracle (0 = skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
