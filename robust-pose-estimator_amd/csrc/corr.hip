@@ -268,9 +268,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LDS staging geometry: per wave, 64 queries x (4 footprint rows x 64 B) with the query stride padded to 272 B
 // so that ds_read_b128 by lane = query is bank-conflict free (4*lane mod 64 distinct within each 16-lane group).
 #define LK_WAVES 4
-#define LK_QSTRIDE 68                          // floats per query slot: 4 rows x 16 floats + 4 pad
+#ifndef LK_RPP
+#define LK_RPP 4                               // footprint rows staged per pass (4: rows 0-3, 4-7, 8-10;  2: six passes)
+#endif
+#define LK_QSTRIDE (LK_RPP * 16 + 4)           // floats per query slot: RPP rows x 16 floats + 4 pad (68 / 36: conflict-free b128)
 #define LK_WAVE_FLOATS (64 * LK_QSTRIDE)
-#define LK_PASSES 3                            // footprint rows 0-3, 4-7, 8-10
+#define LK_PASSES ((WIN + 2 + LK_RPP - 1) / LK_RPP)
+#define LK_NI (4 * LK_RPP)                     // loader instructions per pass: each serves 64 / (4 * RPP) queries
+#define LK_QPI (16 / LK_RPP)                   // queries per loader instruction
 
 // One workgroup = 4 waves = 256 consecutive queries of one (batch item, level).
 // Loader role (per pass, 16 instructions): instruction i serves queries 4i..4i+3 of the wave; lane L fetches the
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
     const int my_packed = ((cl_ylo + 32768) << 16) | ((cl_tx0 + 8192) << 2) | (need_r10 << 1) | need4;
 
     float* wstage = stage + wv * LK_WAVE_FLOATS;
-    const int ld_row = (lane >> 2) & 3, ld_piece = lane & 3, ld_sub = lane >> 4;      // loader role of this lane
+    const int ld_row = (lane >> 2) & (LK_RPP - 1), ld_piece = lane & 3, ld_sub = lane / (4 * LK_RPP);   // loader role of this lane
     const int q_wave0 = blockIdx.x * blockDim.x + wv * 64;                           // first query of this wave
 
     float hm2[WIN], hm1[WIN], hc[WIN];        // horizontally interpolated rows r-2, r-1, r
@@ -329,24 +334,24 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
 #pragma unroll
     for (int pass = 0; pass < LK_PASSES; ++pass) {
         // ---- loader: 16 coalesced 16-B loads per lane-group of 16
-        f32x4 v[16];
+        f32x4 v[LK_NI];
         unsigned okbits = 0;                    // which of the 16 pieces are inside the map: applied when they go to LDS (a
                                                 // select right after the load makes the compiler branch around every load
                                                 // and wait for each shuffle in turn)
-        int pks[16];
+        int pks[LK_NI];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pks[i] = __shfl(my_packed, 4 * i + ld_sub, 64);   // all shuffles first: one LDS round trip
+        for (int i = 0; i < LK_NI; ++i) pks[i] = __shfl(my_packed, LK_QPI * i + ld_sub, 64);   // all shuffles first: one LDS round trip
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int src = 4 * i + ld_sub;                                          // query (within the wave) served
+        for (int i = 0; i < LK_NI; ++i) {
+            const int src = LK_QPI * i + ld_sub;                                          // query (within the wave) served
             const int pk = pks[i];
             const int ylo_s = (int)((unsigned)pk >> 16) - 32768, tx0_s = ((pk >> 2) & 0x3fff) - 8192, need4_s = pk & 1;
             const int last_row = (pk & 2) ? WIN + 1 : WIN;                           // highest footprint row index needed
             const int qs = q_wave0 + src;
-            const int yy = ylo_s + 4 * pass + ld_row;
+            const int yy = ylo_s + LK_RPP * pass + ld_row;
             const int tx = tx0_s + ld_piece;
             // (bitwise &, not &&: short-circuit evaluation puts a branch in front of every load)
-            const bool ok = (qs < nq) & ((4 * pass + ld_row) <= last_row) & (yy >= 0) & (yy < hl) & (tx >= 0) & (tx < txc) &
+            const bool ok = (qs < nq) & ((LK_RPP * pass + ld_row) <= last_row) & (yy >= 0) & (yy < hl) & (tx >= 0) & (tx < txc) &
                             ((ld_piece < 3) | (need4_s != 0));
             const float* p = lvl + (size_t)(ok ? qs : 0) * S + (ok ? ((((yy >> 2) * txc + tx) << 4) + ((yy & 3) << 2)) : 0);
             v[i] = *(const f32x4*)p;
@@ -355,14 +360,14 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
         __syncthreads();                                                             // previous pass fully consumed
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            *(f32x4*)(wstage + (4 * i + ld_sub) * LK_QSTRIDE + ld_row * 16 + ld_piece * 4) = ((okbits >> i) & 1) ? v[i] : zero;
+        for (int i = 0; i < LK_NI; ++i)
+            *(f32x4*)(wstage + (LK_QPI * i + ld_sub) * LK_QSTRIDE + ld_row * 16 + ld_piece * 4) = ((okbits >> i) & 1) ? v[i] : zero;
         __syncthreads();
         // ---- consumer: lane = query
         const float* mine = wstage + lane * LK_QSTRIDE;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * pass + rr;
+        for (int rr = 0; rr < LK_RPP; ++rr) {
+            const int r = LK_RPP * pass + rr;
             if (r >= WIN + 2) break;
             const f32x4 f0 = *(const f32x4*)(mine + rr * 16 + 0), f1 = *(const f32x4*)(mine + rr * 16 + 4);
             const f32x4 f2 = *(const f32x4*)(mine + rr * 16 + 8), f3 = *(const f32x4*)(mine + rr * 16 + 12);
