@@ -245,6 +245,22 @@ int rpe_conv_stats_tiles(int cout, int h, int w);
 int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                        const float *residual, float *out, void *stream);
 
+/* ---- input side: what the reference's datasets do on the CPU before a frame reaches
+ * PoseEstimator (dataset/stereo_dataset.py:12-16,35-40, dataset/video_dataset.py:59-63, dataset/transforms.py:20-39).
+ * mask_specularities: out (h,w) u8 = erode_11x11((r+g+b < sum_threshold) & mask) on the decoded uint8 (h,w,3) image;
+ * mask may be NULL; sum_threshold = ceil(3*255*spec_thr) (numpy compares the integer sum with a float); pixels outside
+ * the image never erode (cv2.erode's default border value). */
+int rpe_mask_specularities(const uint8_t *img_hwc, const uint8_t *mask, int h, int w, int sum_threshold, uint8_t *out,
+                           void *stream);
+/* ResizeStereo on one image: bilinear resize (torchvision 0.14 on tensors: align_corners=False, no antialias) of the
+ * input to (resized_h, resized_w), then the centre crop [top, top+out_h) x [left, left+out_w); out (c,out_h,out_w) f32.
+ * Input: float32 (c,h,w), or -- in_is_u8_hwc -- the decoded uint8 (h,w,c) image (fuses .permute(2,0,1).float()). */
+int rpe_resize_crop(const void *in, int in_is_u8_hwc, int c, int h, int w, int resized_h, int resized_w, int top, int left,
+                    int out_h, int out_w, float *out, void *stream);
+/* the same with nearest sampling for the (h,w) u8 mask (InterpolationMode.NEAREST) */
+int rpe_resize_crop_mask(const uint8_t *in, int h, int w, int resized_h, int resized_w, int top, int left, int out_h,
+                         int out_w, uint8_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

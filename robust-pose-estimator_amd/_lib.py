@@ -64,6 +64,9 @@ SIGNATURES = {
     'rpe_conv_fused': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
+    'rpe_mask_specularities': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'rpe_resize_crop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_resize_crop_mask': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

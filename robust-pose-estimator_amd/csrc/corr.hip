@@ -236,7 +236,7 @@ __device__ __forceinline__ void make_taps(float c, int size, TapAxis& T) {
     int lo = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < WIN; ++i) {
-        float pos = rt_pos(__fadd_rn(c, (float)(i - RADIUS)), size);     // centroid + delta, then grid_sample
+        float pos = rt_pos(rn_add(c, (float)(i - RADIUS)), size);     // centroid + delta, then grid_sample
         float pf;
         f[i] = safe_floor(pos, pf) - i;
         w1[i] = pos - pf;                                                // ix - ix_nw

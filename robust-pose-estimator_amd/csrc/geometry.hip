@@ -30,11 +30,11 @@ __device__ __forceinline__ Kinv3 invert_k(const float* K) {
 
 // un-normalised grid_sample position of flow_utils.py:9-11 for pixel index idx displaced by flow
 __device__ __forceinline__ float sample_pos(float flow, int idx, int size) {
-    return rt_pos(__fadd_rn(flow, (float)idx), size);
+    return rt_pos(rn_add(flow, (float)idx), size);
 }
 
 __device__ __forceinline__ float depth_from_disp(float b, float sfx, bool& valid) {
-    float d = __fdiv_rn(b, -sfx);                 // pose_net.py:73
+    float d = rn_div(b, -sfx);                 // pose_net.py:73
     valid = (d > 0.0f) && (d <= 1.0f);            // :74
     return valid ? d : 1.0f;                      // :75
 }

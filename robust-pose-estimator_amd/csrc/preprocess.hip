@@ -1,0 +1,135 @@
+// Input side of the path: the per-frame preprocessing the reference runs with numpy / cv2 /
+// torchvision on the CPU before PoseEstimator sees a frame.
+//
+// Replaces:
+//   dataset/stereo_dataset.py:12-16  mask_specularities  (brightness threshold, AND with the tool mask, 11x11 erosion)
+//   dataset/transforms.py:20-39      ResizeStereo        (bilinear / nearest resize that conserves the aspect ratio,
+//                                                         then centre crop; torchvision 0.14: antialias off,
+//                                                         align_corners=False)
+//   dataset/video_dataset.py:59-61, stereo_dataset.py:35-37   uint8 HWC -> float32 CHW
+// All of it is HBM-bound byte work: one read of the decoded frame, one write of the network input.
+#include "rpe_common.h"
+
+// torch rounds every operation of the bilinear formula separately; HIP's __fmul_rn / __fadd_rn are plain * and + (still
+// contractable into FMAs) unless OCML_BASIC_ROUNDED_OPERATIONS is defined, so contraction is switched off for this file.
+#pragma clang fp contract(off)
+
+#define ER 5                                   // 11x11 structuring element
+#define TW 64
+#define TH 16
+
+// out = erode_11x11((r + g + b < thr) & mask).  cv2.erode's default border is +inf: pixels outside the image never erode.
+__global__ __launch_bounds__(256) void k_mask_specularities(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask, int h, int w,
+                                                            int thr, uint8_t* __restrict__ out) {
+    __shared__ uint8_t tile[TH + 2 * ER][TW + 2 * ER + 2];
+    __shared__ uint8_t hmin[TH + 2 * ER][TW];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = threadIdx.x; i < (TH + 2 * ER) * (TW + 2 * ER); i += blockDim.x) {
+        const int ty = i / (TW + 2 * ER), tx = i % (TW + 2 * ER);
+        const int y = y0 + ty - ER, x = x0 + tx - ER;
+        uint8_t v = 1;
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            const uint8_t* p = img + ((size_t)y * w + x) * 3;
+            const int s = (int)p[0] + (int)p[1] + (int)p[2];
+            v = (s < thr) && (!mask || mask[(size_t)y * w + x] != 0);
+        }
+        tile[ty][tx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (TH + 2 * ER) * TW; i += blockDim.x) {
+        const int ty = i / TW, tx = i % TW;
+        uint8_t m = 1;
+#pragma unroll
+        for (int d = 0; d <= 2 * ER; ++d) m &= tile[ty][tx + d];
+        hmin[ty][tx] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += blockDim.x) {
+        const int ty = i / TW, tx = i % TW;
+        const int y = y0 + ty, x = x0 + tx;
+        if (y >= h || x >= w) continue;
+        uint8_t m = 1;
+#pragma unroll
+        for (int d = 0; d <= 2 * ER; ++d) m &= hmin[ty + d][tx];
+        out[(size_t)y * w + x] = m;
+    }
+}
+
+// Source position of torch's upsample_bilinear2d (align_corners=False): scale * (dst + 0.5) - 0.5, clamped at 0.
+__device__ __forceinline__ void bil(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = rn_sub(rn_mul(scale, rn_add((float)dst, 0.5f)), 0.5f);     // as torch rounds it: no FMA
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = rn_sub(src, (float)i0);
+    l0 = rn_sub(1.0f, l1);
+}
+
+// out (c, oh, ow) f32 = centre crop (top, left) of bilinear resize of the input to (rh, rw).
+// U8HWC: input uint8 (h, w, c) as decoded; else float32 (c, h, w).
+template <bool U8HWC>
+__global__ __launch_bounds__(256) void k_resize_crop(const void* __restrict__ in, int c, int h, int w, int rh, int rw, int top, int left,
+                                                     int oh, int ow, float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    const float sh = rn_div((float)h, (float)rh), sw = rn_div((float)w, (float)rw);   // area_pixel_compute_scale<float>
+    int y0, y1, x0, x1; float hy0, hy1, wx0, wx1;
+    bil(y + top, sh, h, y0, y1, hy0, hy1);
+    bil(x + left, sw, w, x0, x1, wx0, wx1);
+    for (int ch = 0; ch < c; ++ch) {
+        float p00, p01, p10, p11;
+        if (U8HWC) {
+            const uint8_t* p = (const uint8_t*)in;
+            p00 = p[((size_t)y0 * w + x0) * c + ch]; p01 = p[((size_t)y0 * w + x1) * c + ch];
+            p10 = p[((size_t)y1 * w + x0) * c + ch]; p11 = p[((size_t)y1 * w + x1) * c + ch];
+        } else {
+            const float* p = (const float*)in + (size_t)ch * h * w;
+            p00 = p[(size_t)y0 * w + x0]; p01 = p[(size_t)y0 * w + x1]; p10 = p[(size_t)y1 * w + x0]; p11 = p[(size_t)y1 * w + x1];
+        }
+        // torch: h0lambda * (w0lambda * p00 + w1lambda * p01) + h1lambda * (w0lambda * p10 + w1lambda * p11)
+        // (one correctly-rounded operation at a time: no FMA contraction, so both input formats give the same bits)
+        const float r0 = rn_add(rn_mul(wx0, p00), rn_mul(wx1, p01)), r1 = rn_add(rn_mul(wx0, p10), rn_mul(wx1, p11));
+        out[((size_t)ch * oh + y) * ow + x] = rn_add(rn_mul(hy0, r0), rn_mul(hy1, r1));
+    }
+}
+
+// Nearest resize + centre crop of a one-channel byte mask: torch 'nearest' = floor(dst * scale), scale = in / out in f32.
+__global__ __launch_bounds__(256) void k_resize_crop_nearest(const uint8_t* __restrict__ in, int h, int w, int rh, int rw, int top, int left,
+                                                             int oh, int ow, uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    const float sh = rn_div((float)h, (float)rh), sw = rn_div((float)w, (float)rw);
+    int ys = (int)floorf(rn_mul((float)(y + top), sh)), xs = (int)floorf(rn_mul((float)(x + left), sw));
+    ys = ys > h - 1 ? h - 1 : ys; xs = xs > w - 1 ? w - 1 : xs;
+    out[(size_t)y * ow + x] = in[(size_t)ys * w + xs];
+}
+
+extern "C" int rpe_mask_specularities(const uint8_t* img_hwc, const uint8_t* mask, int h, int w, int sum_threshold, uint8_t* out,
+                                      void* stream) {
+    if (!img_hwc || !out || h <= 0 || w <= 0) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_mask_specularities, dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), 0, (hipStream_t)stream, img_hwc, mask, h, w,
+                       sum_threshold, out);
+    return rpe_check_launch();
+}
+
+static bool crop_ok(int rh, int rw, int top, int left, int oh, int ow) {
+    return rh > 0 && rw > 0 && top >= 0 && left >= 0 && oh > 0 && ow > 0 && top + oh <= rh && left + ow <= rw;
+}
+
+extern "C" int rpe_resize_crop(const void* in, int in_is_u8_hwc, int c, int h, int w, int resized_h, int resized_w, int top, int left,
+                               int out_h, int out_w, float* out, void* stream) {
+    if (!in || !out || c <= 0 || h <= 0 || w <= 0 || !crop_ok(resized_h, resized_w, top, left, out_h, out_w)) return RPE_E_BADARG;
+    dim3 grid(ceil_div(out_w, 256), out_h), block(256);
+    if (in_is_u8_hwc) hipLaunchKernelGGL(k_resize_crop<true>, grid, block, 0, (hipStream_t)stream, in, c, h, w, resized_h, resized_w, top, left, out_h, out_w, out);
+    else hipLaunchKernelGGL(k_resize_crop<false>, grid, block, 0, (hipStream_t)stream, in, c, h, w, resized_h, resized_w, top, left, out_h, out_w, out);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_resize_crop_mask(const uint8_t* in, int h, int w, int resized_h, int resized_w, int top, int left, int out_h, int out_w,
+                                    uint8_t* out, void* stream) {
+    if (!in || !out || h <= 0 || w <= 0 || !crop_ok(resized_h, resized_w, top, left, out_h, out_w)) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_resize_crop_nearest, dim3(ceil_div(out_w, 256), out_h), dim3(256), 0, (hipStream_t)stream, in, h, w, resized_h,
+                       resized_w, top, left, out_h, out_w, out);
+    return rpe_check_launch();
+}

@@ -18,4 +18,23 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+// One correctly-rounded f32 operation, never contracted into an FMA with its neighbours.  (HIP's __fmul_rn & co. are plain
+// operators compiled with contraction allowed unless OCML_BASIC_ROUNDED_OPERATIONS is defined, so they do fuse.)
+__device__ __forceinline__ float rn_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float rn_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float rn_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float rn_div(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

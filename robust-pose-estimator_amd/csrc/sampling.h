@@ -4,15 +4,16 @@
 // core/RAFT/core/utils/utils.py) normalise a pixel coordinate v to g = 2*v/(size-1) - 1 and let
 // torch.nn.functional.grid_sample(align_corners=True) un-normalise it again as ((g + 1) / 2) * (size - 1).
 // The round trip is not the identity in float32, and floor()/rint() of the result decide which pixels are
-// read, so it is reproduced here one correctly-rounded operation at a time (the __f*_rn intrinsics are
-// never contracted into FMAs).
+// read, so it is reproduced here one correctly-rounded operation at a time (contraction into FMAs is switched
+// off inside rt_pos; the sequence has no multiply feeding an add anyway).
 #pragma once
 #include <hip/hip_runtime.h>
 
 __device__ __forceinline__ float rt_pos(float v, int size) {
+#pragma clang fp contract(off)      // (__f*_rn are plain operators in this HIP: keep every operation separately rounded)
     float sm1 = (float)(size - 1);
-    float g = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, v), sm1), 1.0f);
-    return __fmul_rn(__fdiv_rn(__fadd_rn(g, 1.0f), 2.0f), sm1);
+    float g = rn_sub(rn_div(rn_mul(2.0f, v), sm1), 1.0f);
+    return rn_mul(rn_div(rn_add(g, 1.0f), 2.0f), sm1);
 }
 
 // floor() to int that never overflows: positions beyond +-1e6 (or NaN) are reported far outside any image.
