@@ -15,6 +15,7 @@ are the timing barrier and the MAX over ranks.
 
 Rank 0 prints ONE JSON line: metric/value (pose solves per second over the whole job), ``roofline`` for the
 correlation-lookup kernel (algorithmic bytes per launch / HIP-event time measured inside the timed region) and
+``roofline_conv`` (the fused f32-MFMA convolutions that now hold most of the step) and
 ``cpu_baseline`` (the CPU oracle -- a PyTorch-CPU port of the reference path -- on a bounded sample of the
 same inputs with the same weights).
 """
@@ -30,6 +31,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X dense f32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz); the packed-f32 vector pipe shares it
+
+
+def conv_roofline(events, steps):
+    """k_conv_igemm (update-block + encoder residual-block convolutions, epilogues included): algorithmic FLOPs
+    2*cin*kh*kw*cout per output element over the HIP-event time of the same launches."""
+    if not events:
+        return None
+    ms = sum(a.elapsed_time(b) for a, b, _ in events)
+    flop = sum(f for _, _, f in events)
+    tf = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {'kernel': 'k_conv_igemm', 'bound': 'mfma', 'achieved': tf, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tf / F32_MFMA_PEAK_TFLOPS, 'launches_per_step': len(events) // max(1, steps), 'ms_per_step': ms / max(1, steps),
+            'tflop_per_step': flop / max(1, steps) / 1e12}
 
 
 def lookup_algorithmic_bytes(pairs, h8, w8, levels=4, r=4):
@@ -109,6 +126,22 @@ def main():
     rpe_amd.ops.pose_solve = timed_solve
     rpe_amd.pose_head.ops.pose_solve = timed_solve
 
+    # the fused convolutions (k_conv_igemm): FLOPs and HIP-event time of every launch inside the timed region
+    conv_events = []
+    real_conv = rpe_amd.ops.conv_fused
+
+    def timed_conv(x, pc, *a, **k):
+        if not timing['on']:
+            return real_conv(x, pc, *a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real_conv(x, pc, *a, **k)
+        e1.record()
+        conv_events.append((e0, e1, 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * pc.cin * pc.cout * pc.kh * pc.kw))
+        return r
+
+    rpe_amd.ops.conv_fused = timed_conv            # raft.py calls it as ops.conv_fused
+
     def step():
         gpu_in['mask2'].copy_(mask2_init)          # infer() mutates mask2 in place, as the reference does
         return model.infer(**gpu_in, ret_details=True)
@@ -169,6 +202,7 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
                          'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
             'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
+            'roofline_conv': conv_roofline(conv_events, args.steps),
             'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
             'valid_fraction': float(gpu_in['mask2'].float().mean()),
             'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
