@@ -63,15 +63,22 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // missing (cout = 96).  Two instantiations keep the update-block kernels free of the encoder's registers and branches.
 // T = 32x32 MFMA blocks per wave in each direction: 2 -> 64x64 per wave (tiles 128x128 / 64x256), 1 -> 32x32 per wave
 // (tile 64x64, for launches that would not fill the chip with the large tiles: batch-1 tracking).
-template <int KW, int WM, bool ENC, int T>
+// VERT: KW then counts VERTICAL taps (a KW x 1 kernel: the GRU's 5x1 convolutions).  The pixel tile is a 16 x 8 patch staged
+// with KW/2 halo rows above and below, and tap t reads it 16*t LDS rows further down -- the vertical twin of the dx
+// offset, so a 5x1 convolution stages one input tile per channel chunk like a 1x5 one (as a k x 1 kernel walked with
+// one flattened 128-pixel tile per dy it staged five, and ran 10 % slower).  Zero rows come from the loader; no masks.
+template <int KW, int WM, bool ENC, int T, bool VERT>
 __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
-    constexpr int WN = 4 / WM, WT = 32 * T, BM = WT * WM, BN = WT * WN, PW = KW / 2;
+    constexpr int WN = 4 / WM, WT = 32 * T, BM = WT * WM, BN = WT * WN, PW = VERT ? 0 : KW / 2;
+    constexpr int VTX = 16, VTY = 8, VROWS = VTY + KW - 1;       // VERT patch: 16 x 8 pixels, VROWS staged rows of 16
     constexpr int KS = 20;
     constexpr int NLA = BM / 64;                                 // float4 per thread of the [4 k4][BM] weights tile
-    constexpr int NLB = BN / 64;                                 // float4 per thread of the [16 k][BN/4] input tile
+    constexpr int NLB = VERT ? (VROWS * VTX / 4 * CK + 255) / 256 : BN / 64;   // float4 per thread of the input tile
     __shared__ __attribute__((aligned(16))) float As[2][BM][KS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN + 8][KS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][VERT ? VROWS * VTX : BN + 8][KS];
     const int bz = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int vtiles_x = (P.W + VTX - 1) / VTX;                  // VERT: blockIdx.x -> patch (vx0, vy0)
+    const int vx0 = VERT ? (blockIdx.x % vtiles_x) * VTX : 0, vy0 = VERT ? (blockIdx.x / vtiles_x) * VTY : 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = wv / WN, wn = wv % WN;
     const int W = P.W, hw = P.hw, ph = P.kh / 2;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const int xq0 = (n0 + wn * WT + l31) % W, xq1 = (n0 + wn * WT + 32 + l31) % W;
 
     const int nchunk = (P.cin + CK - 1) / CK;
-    const int G = nchunk * P.kh;                                 // (channel chunk, dy) groups; each has KW steps
+    const int G = VERT ? nchunk : nchunk * P.kh;                 // groups = staged input tiles; each serves KW steps
     float4 ra0, ra1;                                             // (scalars: as an array it is demoted to LDS)
     struct RB { float4 v[NLB]; float4 halo; unsigned ok; };      // one staged input tile (this thread's part); ok bits:
                                                                  // u (and NLB = halo): lane's float4 is inside the map
@@ -114,10 +121,24 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     // next group's input tile; advances (lc, ld).  Issued unconditionally (groups past the end read the dummy address):
     // a load under a branch makes the compiler's s_waitcnt placement assume the worst on every path.
     auto load_b = [&](RB& R) {
+        R.ok = 0;
+        if (VERT) {                                              // thread -> (k, float4 q4 of the 16-px row, rows rg + 4u)
+            const int q4 = tid & 3, rg = tid >> 6;
+            const bool cok = lc * CK + b_k < P.cin && vx0 + 4 * q4 + 3 < W;
+            const float* src = xrow + (size_t)lc * CK * hw + vx0 + 4 * q4;
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) {
+                const int r = rg + 4 * u, y = vy0 + r - KW / 2;
+                const bool ok = cok && r < VROWS && y >= 0 && y < P.H;
+                R.v[u] = *(const float4*)(ok ? src + (size_t)y * W : P.x);
+                R.ok |= ok ? (1u << u) : 0u;
+            }
+            ++lc;
+            return;
+        }
         const bool cok = lc * CK + b_k < P.cin;
         const int sh = (ld - ph) * W;
         const float* src = xrow + (size_t)lc * CK * hw;
-        R.ok = 0;
         // out-of-map lanes read a valid dummy address; they are zeroed when the tile is written to LDS (a conditional
         // load is split into four branchy dword loads, and a select right here would wait for the data at once)
 #pragma unroll
@@ -140,6 +161,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
         if (NLA == 2) *(float4*)&As[buf][a_m][4 * (a_k4 + A_K4STEP)] = ra1;
     };
     auto store_b = [&](const RB& R, int buf) {
+        if (VERT) {
+            const int q4 = tid & 3, rg = tid >> 6;
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) {
+                const int r = rg + 4 * u;
+                if (r >= VROWS) continue;
+                const int n = r * VTX + 4 * q4;
+                const float4 v = (R.ok >> u) & 1 ? R.v[u] : zero4;
+                Bs[buf][n + 0][b_k] = v.x; Bs[buf][n + 1][b_k] = v.y; Bs[buf][n + 2][b_k] = v.z; Bs[buf][n + 3][b_k] = v.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NLB; ++u) {
             const int n = 4 + 4 * (b_n4 + 16 * u);
@@ -164,18 +197,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const bool hi_rows = T == 1 || m0 + wm * WT + 32 < P.cout;
     auto read_h1 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * WT + l31][8 * lh];
-        const float* brow = &Bs[bufB][4 + wn * WT + l31 + dx][8 * lh];
+        const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : 4 + wn * WT + l31 + dx][8 * lh];
         a0h1 = *(const f32x4*)(arow); b0h1 = *(const f32x4*)(brow);
         if (T == 2) { a1h1 = *(const f32x4*)(arow + 32 * KS); b1h1 = *(const f32x4*)(brow + 32 * KS); }
     };
     auto read_h2 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * WT + l31][8 * lh + 4];
-        const float* brow = &Bs[bufB][4 + wn * WT + l31 + dx][8 * lh + 4];
+        const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : 4 + wn * WT + l31 + dx][8 * lh + 4];
         a0h2 = *(const f32x4*)(arow); b0h2 = *(const f32x4*)(brow);
         if (T == 2) { a1h2 = *(const f32x4*)(arow + 32 * KS); b1h2 = *(const f32x4*)(brow + 32 * KS); }
     };
     auto mma_half = [&](const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, int dx) {
-        const bool v0 = KW == 1 || (unsigned)(xq0 + dx) < (unsigned)W, v1 = KW == 1 || (unsigned)(xq1 + dx) < (unsigned)W;
+        const bool v0 = KW == 1 || VERT || (unsigned)(xq0 + dx) < (unsigned)W, v1 = KW == 1 || VERT || (unsigned)(xq1 + dx) < (unsigned)W;
         float fb0[4], fb1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fb0[j] = v0 ? b0[j] : 0.0f; fb1[j] = v1 ? b1[j] : 0.0f; }   // column mask at use, not at the read
@@ -266,8 +299,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
         for (int i = 0; i < T; ++i)
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-                const int px = n0 + wn * WT + j * 32 + l31;
-                if (px >= hw) continue;
+                const int nl = wn * WT + j * 32 + l31;               // column of the tile -> pixel
+                const int px = VERT ? (vy0 + nl / VTX) * W + vx0 + nl % VTX : n0 + nl;
+                if (VERT ? (vy0 + nl / VTX >= P.H || vx0 + nl % VTX >= W) : px >= hw) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -437,13 +471,16 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     const bool small = !enc && (long long)ceil_div(P.hw, BN) * ceil_div(d->cout, BM) * d->b < 512;
     if (small) { BM = 64; BN = 64; }
     dim3 grid(ceil_div(P.hw, BN), ceil_div(d->cout, BM), d->b), block(256);
-#define LAUNCH(KW_, WM_, ENC_, T_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_, T_>), grid, block, 0, s, P)
+#define LAUNCH(KW_, WM_, ENC_, T_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_, T_, false>), grid, block, 0, s, P)
     if (enc) {                                       // encoder epilogues exist for the encoders' 3x3 convolutions only
         if (d->kw != 3 || d->mode > RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
         if (wide) LAUNCH(3, 1, true, 2); else LAUNCH(3, 2, true, 2);
     } else if (small) { if (d->kw == 1) LAUNCH(1, 2, false, 1); else if (d->kw == 3) LAUNCH(3, 2, false, 1); else LAUNCH(5, 2, false, 1); }
     else if (wide) { if (d->kw == 1) LAUNCH(1, 1, false, 2); else if (d->kw == 3) LAUNCH(3, 1, false, 2); else LAUNCH(5, 1, false, 2); }
-    else           { if (d->kw == 1) LAUNCH(1, 2, false, 2); else if (d->kw == 3) LAUNCH(3, 2, false, 2); else LAUNCH(5, 2, false, 2); }
+    else if (d->kw == 1 && d->kh == 5) {             // 5x1 (GRU, vertical half): 16 x 8 pixel patches, taps along y
+        dim3 vgrid(ceil_div(d->w, 16) * ceil_div(d->h, 8), grid.y, grid.z);
+        hipLaunchKernelGGL((k_conv_igemm<5, 2, false, 2, true>), vgrid, block, 0, s, P);
+    } else         { if (d->kw == 1) LAUNCH(1, 2, false, 2); else if (d->kw == 3) LAUNCH(3, 2, false, 2); else LAUNCH(5, 2, false, 2); }
 #undef LAUNCH
     return rpe_check_launch();
 }

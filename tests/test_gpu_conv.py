@@ -168,3 +168,22 @@ def test_large_and_small_tiles_agree_bitwise(rpe, cin, cout, kh, kw, mode):
     ref = F.conv2d(x[:1], wt, bias, padding=(kh // 2, kw // 2))          # and sanity against the library on one map
     ref = torch.cat((torch.sigmoid(ref[:, :c]), torch.sigmoid(ref[:, c:]) * x[:1, :c]), 1) if mode == 'zr' else ref.clamp_min(0)
     assert (big[:1] - ref).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize('h,w', [(64, 80), (44, 48), (30, 36)])
+def test_vertical_patch_tiles_match_library(rpe, h, w):
+    """5x1 convolutions of launches that fill the chip use 16x8 pixel patches (taps as LDS row offsets); maps that are not
+    a multiple of the patch exercise the zero-filled halo rows and the masked stores.  Reference: the library's f32
+    convolution on the same GPU (tolerance of an f32 dot product of length 1280) and, bitwise, the small-tile kernel."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(h * w)
+    b, cin, cout = 24, 256, 256
+    x, wt, bias = _rand(rng, b, cin, h, w, s=0.5).cuda(), _rand(rng, cout, cin, 5, 1, s=0.03).cuda(), _rand(rng, cout, s=0.1).cuda()
+    pc = ops.PackedConv(wt, bias)
+    out = torch.full((b, cout + 1, h, w), -3.0, device='cuda')
+    ops.conv_fused(x, pc, ops.CONV_LINEAR, out[:, :cout])
+    ref = F.conv2d(x, wt, bias, padding=(2, 0))
+    assert (out[:, :cout] - ref).abs().max() < 3e-6 * np.sqrt(1280) * float(x.abs().max()) * float(wt.abs().max()) * 4
+    assert (out[:, cout] == -3.0).all()
+    one = ops.conv_fused(x[5:6].contiguous(), pc, ops.CONV_LINEAR, torch.empty(1, cout, h, w, device='cuda'))     # small tiles
+    assert torch.equal(one, out[5:6, :cout])
