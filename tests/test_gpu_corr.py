@@ -228,7 +228,8 @@ def test_full_size_lookup_properties(rpe):
 def test_flow_head_last_layer(rpe):
     from rpe_amd import ops
     torch.manual_seed(5)
-    for (b, c, h, w) in ((2, 256, 64, 80), (1, 20, 13, 37)):
+    # widths that are a multiple of 4 take the four-pixels-per-thread kernel, the others the one-pixel kernel
+    for (b, c, h, w) in ((2, 256, 64, 80), (1, 20, 13, 37), (3, 37, 9, 12), (1, 256, 44, 48), (2, 5, 3, 4)):
         x = torch.randn(b, c, h, w)
         wt = torch.randn(2, c, 3, 3) * 0.05
         bias = torch.randn(2)
