@@ -137,7 +137,8 @@ def main():
         e0.record()
         r = real_conv(x, pc, *a, **k)
         e1.record()
-        conv_events.append((e0, e1, 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * pc.cin * pc.cout * pc.kh * pc.kw))
+        st = k.get('stride', 1)
+        conv_events.append((e0, e1, 2.0 * x.shape[0] * (x.shape[2] // st) * (x.shape[3] // st) * pc.cin * pc.cout * pc.kh * pc.kw))
         return r
 
     rpe_amd.ops.conv_fused = timed_conv            # raft.py calls it as ops.conv_fused

@@ -201,7 +201,7 @@ int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int
 
 /* ---- update-block convolutions (core/RAFT/core/update.py: BasicMotionEncoder convc1/convc2/convf2/conv, SepConvGRU
  * convz|convr/convq of both halves, FlowHead.conv1) as implicit GEMMs on the f32 matrix cores with their epilogues
- * fused.  Stride 1, zero padding k/2 ("same"), NCHW, kernel height odd, kernel width 1, 3 or 5, w % 4 == 0
+ * fused.  Stride 1 (stride 2: see the descriptor), zero padding k/2 ("same"), NCHW, kernel height odd, kernel width 1, 3 or 5, w % 4 == 0
  * (otherwise RPE_E_UNSUPPORTED: the caller keeps the library convolution + rpe_bias_act / rpe_gru_gates_*).
  * Every tensor argument is a pointer to channel 0 of a channel slice plus the batch stride (in floats) of the
  * buffer it lives in, so inputs and outputs can be slices of the concatenated (h | motion | flow) buffers.
@@ -230,15 +230,17 @@ typedef struct rpe_conv_desc {
     const float *scale;                                  /* (cout) or NULL (folded batch norm: scale, bias = shift) */
     const float *residual; long long residual_batch_stride; /* LINEAR / RELU only                                   */
     float *stats;                                        /* LINEAR / RELU only                                      */
-    int b, cin, cout, h, w, kh, kw, mode, gate_channels;
+    int b, cin, cout, h, w, kh, kw, mode, gate_channels;  /* h, w: INPUT map                                       */
+    int stride;                                          /* 0 or 1: stride 1; 2: the encoders' down-sampling convolutions (3x3 pad 1 or 1x1 pad 0,
+                                                          * even h and w, LINEAR / RELU only); the output map is (h/2, w/2)                        */
 } rpe_conv_desc;
 /* number of floats of the packed form of a (cout, cin, kh, kw) weight tensor (0 on bad arguments) */
 size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
 /* weight (cout, cin, kh, kw) contiguous -> packed (tap-major 16-channel steps, output channels padded to 128) */
 int rpe_conv_pack(const float *weight, int cout, int cin, int kh, int kw, float *packed, void *stream);
 int rpe_conv_fused(const rpe_conv_desc *desc, void *stream);
-/* number of pixel tiles (= partial-sum slots per (b, channel) plane) rpe_conv_fused uses for this shape */
-int rpe_conv_stats_tiles(int cout, int h, int w);
+/* number of pixel tiles (= partial-sum slots per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input) */
+int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
 /* Instance norm (torch.nn.InstanceNorm2d, affine=False; fnet of core/RAFT/core/extractor.py) of x (b,c,hw) given the
  * partial sums rpe_conv_fused left in `partials` (b,c,tiles,2):
  *   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y,0); if (residual) y = max(residual + y, 0).  out may alias x. */

@@ -27,7 +27,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvP {
     const float* x; long long xbs;            // first input channel of the slice; batch stride (floats)
     const float* wp;                          // packed weights [step][16][coP]
-    int cin, cout, coP, H, W, hw, kh;
+    int cin, cout, coP, H, W, hw, kh;         // H, W, hw: OUTPUT map
+    int Hin, Win;                             // input map (= H, W unless stride 2)
     const float* bias;                        // [cout] or null
     const float* add; long long abs_;         // (b, cout, hw) pre-activation addend or null
     int mode;
@@ -67,21 +68,27 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // with KW/2 halo rows above and below, and tap t reads it 16*t LDS rows further down -- the vertical twin of the dx
 // offset, so a 5x1 convolution stages one input tile per channel chunk like a 1x5 one (as a k x 1 kernel walked with
 // one flattened 128-pixel tile per dy it staged five, and ran 10 % slower).  Zero rows come from the loader; no masks.
-template <int KW, int WM, bool ENC, int T, bool VERT>
+// S2: stride 2 (the encoders' 3x3 pad-1 and 1x1 down-sampling convolutions).  The staged tile holds, per output pixel n
+// of the tile, the even input pixel E[n] = in[yi][2x] (LDS rows 0..BN-1) and the odd one O[n] = in[yi][2x+1] (rows
+// BN+1+n; row BN = O[-1] of the tile's first pixel), yi = 2y + dy - pad: the loader's aligned float4 (E,O,E,O of two
+// neighbouring outputs) is de-interleaved by the 4-byte LDS stores it needs anyway.  Taps: in[2x-1] = O[n-1], in[2x] =
+// E[n], in[2x+1] = O[n] -- plain row offsets again.
+template <int KW, int WM, bool ENC, int T, bool VERT, bool S2>
 __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     constexpr int WN = 4 / WM, WT = 32 * T, BM = WT * WM, BN = WT * WN, PW = VERT ? 0 : KW / 2;
     constexpr int VTX = 16, VTY = 8, VROWS = VTY + KW - 1;       // VERT patch: 16 x 8 pixels, VROWS staged rows of 16
     constexpr int KS = 20;
     constexpr int NLA = BM / 64;                                 // float4 per thread of the [4 k4][BM] weights tile
-    constexpr int NLB = VERT ? (VROWS * VTX / 4 * CK + 255) / 256 : BN / 64;   // float4 per thread of the input tile
+    constexpr int NLB = VERT ? (VROWS * VTX / 4 * CK + 255) / 256 : S2 ? BN / 32 : BN / 64;   // float4 per thread of the input tile
     __shared__ __attribute__((aligned(16))) float As[2][BM][KS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][VERT ? VROWS * VTX : BN + 8][KS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][VERT ? VROWS * VTX : S2 ? 2 * BN + 8 : BN + 8][KS];
     const int bz = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int vtiles_x = (P.W + VTX - 1) / VTX;                  // VERT: blockIdx.x -> patch (vx0, vy0)
     const int vx0 = VERT ? (blockIdx.x % vtiles_x) * VTX : 0, vy0 = VERT ? (blockIdx.x / vtiles_x) * VTY : 0;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = wv / WN, wn = wv % WN;
     const int W = P.W, hw = P.hw, ph = P.kh / 2;
+    const int hw_in = S2 ? P.Hin * P.Win : hw;
     // weights loader: thread -> (m = tid % BM, k4 = tid / BM [+ 256/BM * u]);  packed as [step][k4][coP][4]
     const int a_m = tid % BM, a_k4 = tid / BM;
     constexpr int A_K4STEP = 256 / BM;
@@ -89,8 +96,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     // pixel float4 n4 = tid % 4 + 4 * wave [+ 16 u]).  Halo (threads 0..31): k = tid % 16, side = tid / 16.
     const int b_k = (tid >> 2) & 15, b_n4 = (tid & 3) + 4 * wv;
     const int h_k = tid & 15, h_side = tid >> 4;
-    const float* xrow = P.x + (size_t)bz * P.xbs + (size_t)b_k * hw;          // channel row b_k of chunk 0
-    const float* xrow_h = P.x + (size_t)bz * P.xbs + (size_t)h_k * hw;
+    const float* xrow = P.x + (size_t)bz * P.xbs + (size_t)b_k * hw_in;       // channel row b_k of chunk 0
+    const float* xrow_h = P.x + (size_t)bz * P.xbs + (size_t)h_k * hw_in;
 
     f32x16 acc[T][T];
 #pragma unroll
@@ -136,6 +143,26 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             ++lc;
             return;
         }
+        if (S2) {                                                // thread -> (k, output pixel pair n = 2q, 2q+1)
+            const bool cok = lc * CK + b_k < P.cin;
+            const float* src = xrow + (size_t)lc * CK * hw_in;
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) {
+                const int na = n0 + 2 * (b_n4 + 16 * u);
+                const int y = na / W, x = na - y * W, yi = 2 * y + ld - ph;
+                const bool ok = cok && na < hw && yi >= 0 && yi < P.Hin;
+                R.v[u] = *(const float4*)(ok ? src + (size_t)yi * P.Win + 2 * x : P.x);
+                R.ok |= ok ? (1u << u) : 0u;
+            }
+            if (KW > 1 && tid < 16) {                            // O[-1]: the input pixel left of the tile's first one
+                const int y = n0 / W, x = n0 - y * W, yi = 2 * y + ld - ph;
+                const bool ok = lc * CK + h_k < P.cin && x > 0 && yi >= 0 && yi < P.Hin;
+                R.halo.x = *(ok ? xrow_h + (size_t)lc * CK * hw_in + (size_t)yi * P.Win + 2 * x - 1 : P.x);
+                R.ok |= ok ? (1u << NLB) : 0u;
+            }
+            if (++ld == P.kh) { ld = 0; ++lc; }
+            return;
+        }
         const bool cok = lc * CK + b_k < P.cin;
         const int sh = (ld - ph) * W;
         const float* src = xrow + (size_t)lc * CK * hw;
@@ -173,6 +200,16 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             }
             return;
         }
+        if (S2) {
+#pragma unroll
+            for (int u = 0; u < NLB; ++u) {
+                const int n = 2 * (b_n4 + 16 * u);
+                const float4 v = (R.ok >> u) & 1 ? R.v[u] : zero4;
+                Bs[buf][n][b_k] = v.x; Bs[buf][BN + 1 + n][b_k] = v.y; Bs[buf][n + 1][b_k] = v.z; Bs[buf][BN + 2 + n][b_k] = v.w;
+            }
+            if (KW > 1 && tid < 16) Bs[buf][BN][h_k] = (R.ok >> NLB) & 1 ? R.halo.x : 0.0f;
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NLB; ++u) {
             const int n = 4 + 4 * (b_n4 + 16 * u);
@@ -197,18 +234,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const bool hi_rows = T == 1 || m0 + wm * WT + 32 < P.cout;
     auto read_h1 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * WT + l31][8 * lh];
-        const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : 4 + wn * WT + l31 + dx][8 * lh];
+        const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : S2 ? wn * WT + l31 + (dx == 0 ? 0 : dx < 0 ? BN : BN + 1) : 4 + wn * WT + l31 + dx][8 * lh];
         a0h1 = *(const f32x4*)(arow); b0h1 = *(const f32x4*)(brow);
         if (T == 2) { a1h1 = *(const f32x4*)(arow + 32 * KS); b1h1 = *(const f32x4*)(brow + 32 * KS); }
     };
     auto read_h2 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * WT + l31][8 * lh + 4];
-        const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : 4 + wn * WT + l31 + dx][8 * lh + 4];
+        const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : S2 ? wn * WT + l31 + (dx == 0 ? 0 : dx < 0 ? BN : BN + 1) : 4 + wn * WT + l31 + dx][8 * lh + 4];
         a0h2 = *(const f32x4*)(arow); b0h2 = *(const f32x4*)(brow);
         if (T == 2) { a1h2 = *(const f32x4*)(arow + 32 * KS); b1h2 = *(const f32x4*)(brow + 32 * KS); }
     };
     auto mma_half = [&](const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, int dx) {
-        const bool v0 = KW == 1 || VERT || (unsigned)(xq0 + dx) < (unsigned)W, v1 = KW == 1 || VERT || (unsigned)(xq1 + dx) < (unsigned)W;
+        const bool v0 = KW == 1 || VERT || (S2 ? (dx >= 0 || xq0 > 0) : (unsigned)(xq0 + dx) < (unsigned)W);
+        const bool v1 = KW == 1 || VERT || (S2 ? (dx >= 0 || xq1 > 0) : (unsigned)(xq1 + dx) < (unsigned)W);
         float fb0[4], fb1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fb0[j] = v0 ? b0[j] : 0.0f; fb1[j] = v1 ? b1[j] : 0.0f; }   // column mask at use, not at the read
@@ -235,7 +273,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     // The input planes stream from HBM (each tile is read by only cout/BM * kh workgroups), so their loads are
     // issued a whole group (KW > 1: KW steps) or three steps (KW == 1, three register sets) ahead of use; the
     // weights are shared by every workgroup (L2 hits) and are fetched one step ahead.
-    if (KW > 1) {
+    if (KW > 1 || S2) {
         RB R;
         load_a(); load_b(R);
         store_a(0); store_b(R, 0);
@@ -454,14 +492,25 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     if (d->mode == RPE_CONV_GATE_ZR && (!d->out2 || !d->hidden || d->gate_channels <= 0 || d->cout != 2 * d->gate_channels)) return RPE_E_BADARG;
     if (d->mode == RPE_CONV_GATE_H && (!d->hidden || !d->zgate)) return RPE_E_BADARG;
     if ((d->mode == RPE_CONV_GATE_ZR || d->mode == RPE_CONV_GATE_H) && (d->scale || d->residual || d->stats)) return RPE_E_BADARG;
+    const int stride = d->stride ? d->stride : 1;
+    if (stride != 1 && stride != 2) return RPE_E_UNSUPPORTED;
+    if (stride == 2 && ((d->h & 1) || (d->w & 1) || d->mode > RPE_CONV_RELU || !((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))))
+        return RPE_E_UNSUPPORTED;                    // stride 2: 3x3 (pad 1) or 1x1 (pad 0) on even maps
     ConvP P;
     P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed;
-    P.cin = d->cin; P.cout = d->cout; P.coP = conv_cop(d->cout); P.H = d->h; P.W = d->w; P.hw = d->h * d->w; P.kh = d->kh;
+    P.cin = d->cin; P.cout = d->cout; P.coP = conv_cop(d->cout); P.kh = d->kh;
+    P.Hin = d->h; P.Win = d->w; P.H = d->h / stride; P.W = d->w / stride; P.hw = P.H * P.W;
     P.bias = d->bias; P.add = d->add; P.abs_ = d->add_batch_stride; P.mode = d->mode;
     P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.h = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels;
     P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats;
     hipStream_t s = (hipStream_t)stream;
+    if (stride == 2) {                               // 128x128 tiles only (the E/O staging doubles the input tile)
+        dim3 g2(ceil_div(P.hw, 128), ceil_div(d->cout, 128), d->b);
+        if (d->kw == 3) hipLaunchKernelGGL((k_conv_igemm<3, 2, true, 2, false, true>), g2, dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((k_conv_igemm<1, 2, true, 2, false, true>), g2, dim3(256), 0, s, P);
+        return rpe_check_launch();
+    }
     bool wide = (d->cout % 128) != 0;                // 64-row tiles waste less when cout is 64, 126, 192
     int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
     const bool half_tile = (d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3 && d->mode <= RPE_CONV_RELU;   // cout = 96
@@ -471,7 +520,7 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     const bool small = !enc && (long long)ceil_div(P.hw, BN) * ceil_div(d->cout, BM) * d->b < 512;
     if (small) { BM = 64; BN = 64; }
     dim3 grid(ceil_div(P.hw, BN), ceil_div(d->cout, BM), d->b), block(256);
-#define LAUNCH(KW_, WM_, ENC_, T_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_, T_, false>), grid, block, 0, s, P)
+#define LAUNCH(KW_, WM_, ENC_, T_) hipLaunchKernelGGL((k_conv_igemm<KW_, WM_, ENC_, T_, false, false>), grid, block, 0, s, P)
     if (enc) {                                       // encoder epilogues exist for the encoders' 3x3 convolutions only
         if (d->kw != 3 || d->mode > RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
         if (wide) LAUNCH(3, 1, true, 2); else LAUNCH(3, 2, true, 2);
@@ -479,14 +528,15 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     else if (wide) { if (d->kw == 1) LAUNCH(1, 1, false, 2); else if (d->kw == 3) LAUNCH(3, 1, false, 2); else LAUNCH(5, 1, false, 2); }
     else if (d->kw == 1 && d->kh == 5) {             // 5x1 (GRU, vertical half): 16 x 8 pixel patches, taps along y
         dim3 vgrid(ceil_div(d->w, 16) * ceil_div(d->h, 8), grid.y, grid.z);
-        hipLaunchKernelGGL((k_conv_igemm<5, 2, false, 2, true>), vgrid, block, 0, s, P);
+        hipLaunchKernelGGL((k_conv_igemm<5, 2, false, 2, true, false>), vgrid, block, 0, s, P);
     } else         { if (d->kw == 1) LAUNCH(1, 2, false, 2); else if (d->kw == 3) LAUNCH(3, 2, false, 2); else LAUNCH(5, 2, false, 2); }
 #undef LAUNCH
     return rpe_check_launch();
 }
 
-extern "C" int rpe_conv_stats_tiles(int cout, int h, int w) {
-    if (cout <= 0 || h <= 0 || w <= 0) return 0;
+extern "C" int rpe_conv_stats_tiles(int cout, int h, int w, int stride) {
+    if (cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2)) return 0;
+    if (stride == 2) return ceil_div((int64_t)(h / 2) * (w / 2), 128);
     return ceil_div((int64_t)h * w, (cout % 128) != 0 ? 256 : 128);
 }
 

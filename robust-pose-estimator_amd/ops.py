@@ -343,7 +343,7 @@ class PackedConv:
 
 
 def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
-               residual=None, stats=None):
+               residual=None, stats=None, stride=1):
     """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.
     ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the partial sums
     instnorm_apply needs."""
@@ -362,7 +362,7 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
         if t is None:
             setattr(d, name, None); setattr(d, name + '_batch_stride', 0)
             continue
-        if t.shape[0] != b or tuple(t.shape[2:]) != (hh, ww) or (want_c is not None and t.shape[1] != want_c):
+        if t.shape[0] != b or tuple(t.shape[2:]) != (hh // stride, ww // stride) or (want_c is not None and t.shape[1] != want_c):
             raise _lib.RpeError(f'conv_fused: {name} has shape {tuple(t.shape)}')
         p, s = _chan_slice(t, name)
         setattr(d, name, p); setattr(d, name + '_batch_stride', s)
@@ -374,19 +374,20 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     if mode in (CONV_LINEAR, CONV_RELU) and out2 is not None and out2.shape[1] < pc.cout:
         raise _lib.RpeError('conv_fused: out2 slice has too few channels')
     if stats is not None:
-        tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww)
+        tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride)
         if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 2)):
             raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},2) GPU tensor')
     d.stats = ptr(stats)
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.gate_channels = b, cin, pc.cout, hh, ww, pc.kh, pc.kw, mode, gate_channels
+    d.stride = stride
     import ctypes
     check(lib().rpe_conv_fused(ctypes.byref(d), stream_ptr()), 'rpe_conv_fused')
     return out
 
 
-def conv_stats_buffer(b, cout, hh, ww, device):
-    """Partial-sum buffer rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 2)."""
-    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww), 2, dtype=torch.float32, device=device)
+def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
+    """Partial-sum buffer rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 2); hh, ww = input map."""
+    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 2, dtype=torch.float32, device=device)
 
 
 def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):

@@ -79,25 +79,30 @@ def _packed(conv):
 
 
 def conv_norm_act(conv, norm, x, relu, residual=None):
-    """norm(conv(x) + bias) [ReLU] [+ residual, ReLU].  Stride-1 3x3 convolutions on maps whose width is a multiple of
-    4 run on the fused HIP implicit GEMM (folded batch norm / ReLU / residual inside its epilogue; for instance norm the
-    epilogue leaves per-tile partial sums and one more read+write pass normalises); the stride-2 and 7x7 / 1x1
-    convolutions stay on the library with a fused HIP epilogue pass."""
-    fused = conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and x.shape[-1] % 4 == 0 and x.is_contiguous()
+    """norm(conv(x) + bias) [ReLU] [+ residual, ReLU].  The residual blocks' convolutions -- 3x3 stride 1, 3x3 stride 2 and
+    the 1x1 stride-2 shortcut -- run on the fused HIP implicit GEMM when the map width is a multiple of 4 (folded batch
+    norm / ReLU / residual inside its epilogue; for instance norm the epilogue leaves per-tile partial sums and one more
+    read+write pass normalises); the 7x7 stem and the final 1x1 stay on the library with a fused HIP epilogue pass."""
+    b, _, hh, ww = x.shape
+    s1 = conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+    s2 = conv.stride == (2, 2) and hh % 2 == 0 and ww % 2 == 0 and \
+        ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
+    stride = 2 if s2 else 1
+    fused = (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous()
     if isinstance(norm, nn.BatchNorm2d):
         if norm.training:
             raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')
         scale, shift = _bn_affine(conv, norm)
         if fused:
-            out = torch.empty(x.shape[0], conv.out_channels, x.shape[2], x.shape[3], device=x.device)
-            return ops.conv_fused(x, _packed(conv), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, scale=scale, bias=shift, residual=residual)
+            out = torch.empty(b, conv.out_channels, hh // stride, ww // stride, device=x.device)
+            return ops.conv_fused(x, _packed(conv), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, scale=scale, bias=shift, residual=residual,
+                                  stride=stride)
         return ops.affine_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), scale, shift, relu=relu, residual=residual)
     if isinstance(norm, nn.InstanceNorm2d):
         if fused:
-            b, _, hh, ww = x.shape
-            stats = ops.conv_stats_buffer(b, conv.out_channels, hh, ww, x.device)
-            pre = ops.conv_fused(x, _packed(conv), ops.CONV_LINEAR, torch.empty(b, conv.out_channels, hh, ww, device=x.device),
-                                 bias=conv.bias.detach(), stats=stats)
+            stats = ops.conv_stats_buffer(b, conv.out_channels, hh, ww, x.device, stride=stride)
+            pre = ops.conv_fused(x, _packed(conv), ops.CONV_LINEAR, torch.empty(b, conv.out_channels, hh // stride, ww // stride, device=x.device),
+                                 bias=conv.bias.detach(), stats=stats, stride=stride)
             return ops.instnorm_apply(pre, stats, eps=norm.eps, relu=relu, residual=residual)
         return ops.instnorm_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), conv.bias, eps=norm.eps, relu=relu, residual=residual)
     raise NotImplementedError(type(norm))

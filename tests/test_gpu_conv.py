@@ -187,3 +187,39 @@ def test_vertical_patch_tiles_match_library(rpe, h, w):
     assert (out[:, cout] == -3.0).all()
     one = ops.conv_fused(x[5:6].contiguous(), pc, ops.CONV_LINEAR, torch.empty(1, cout, h, w, device='cuda'))     # small tiles
     assert torch.equal(one, out[5:6, :cout])
+
+
+@pytest.mark.parametrize('cin,cout,k,h,w,b', [(64, 96, 3, 64, 80, 3), (96, 128, 3, 44, 48, 2), (64, 96, 1, 64, 80, 2), (96, 128, 1, 36, 40, 3),
+                                              (16, 32, 3, 12, 16, 1)])
+def test_stride2_convolutions_match_f64(rpe, cin, cout, k, h, w, b):
+    """The encoders' down-sampling convolutions: 3x3 stride 2 pad 1 and 1x1 stride 2, with both encoder epilogues
+    (folded batch norm + ReLU; instance-norm partial sums + rpe_instnorm_apply)."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + k + h)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, k, k, s=0.05), _rand(rng, cout, s=0.5)
+    scale, shift = _rand(rng, cout).abs() + 0.5, _rand(rng, cout, s=0.3)
+    pc = ops.PackedConv(wt.cuda(), bias.cuda())
+    conv = F.conv2d(x.double(), wt.double(), None, stride=2, padding=k // 2)
+    ho, wo = h // 2, w // 2
+    assert conv.shape[-2:] == (ho, wo)
+    ref = (conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]).clamp_min(0)
+    got = ops.conv_fused(x.cuda(), pc, ops.CONV_RELU, torch.empty(b, cout, ho, wo, device='cuda'), scale=scale.cuda(), bias=shift.cuda(), stride=2)
+    assert (got.cpu().double() - ref).abs().max() < _tol(x, wt) * 2.5
+    pre = conv + bias.double()[None, :, None, None]
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    stats = ops.conv_stats_buffer(b, cout, h, w, 'cuda', stride=2)
+    raw = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, cout, ho, wo, device='cuda'), stats=stats, stride=2)
+    assert (raw.cpu().double() - pre).abs().max() < _tol(x, wt)
+    got2 = ops.instnorm_apply(raw, stats, eps=1e-5, relu=False)
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert (got2.cpu().double() - (pre - mean) / torch.sqrt(var + 1e-5)).abs().max() < (_tol(x, wt) + 2e-6) * inv * 2
+
+
+def test_stride2_refusals(rpe):
+    from rpe_amd import ops
+    pc = ops.PackedConv(torch.zeros(32, 16, 3, 3, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):          # odd map height
+        ops.conv_fused(torch.zeros(1, 16, 9, 12, device='cuda'), pc, ops.CONV_LINEAR, torch.empty(1, 32, 4, 6, device='cuda'), stride=2)
+    pc5 = ops.PackedConv(torch.zeros(32, 16, 1, 5, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):          # only 3x3 and 1x1 have a stride-2 kernel
+        ops.conv_fused(torch.zeros(1, 16, 8, 12, device='cuda'), pc5, ops.CONV_LINEAR, torch.empty(1, 32, 4, 6, device='cuda'), stride=2)
