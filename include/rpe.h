@@ -230,6 +230,8 @@ typedef struct rpe_conv_desc {
     const float *scale;                                  /* (cout) or NULL (folded batch norm: scale, bias = shift) */
     const float *residual; long long residual_batch_stride; /* LINEAR / RELU only                                   */
     float *stats;                                        /* LINEAR / RELU only                                      */
+    const float *pre_norm;                               /* (b, cin, 2) = (mean, 1/std) from rpe_instnorm_finalize or NULL: x is the RAW output
+                                                          * of the previous convolution and is normalised + ReLU'd while it is staged (3x3, stride 1) */
     int b, cin, cout, h, w, kh, kw, mode, gate_channels;  /* h, w: INPUT map                                       */
     int stride;                                          /* 0 or 1: stride 1; 2: the encoders' down-sampling convolutions (3x3 pad 1 or 1x1 pad 0,
                                                           * even h and w, LINEAR / RELU only); the output map is (h/2, w/2)                        */
@@ -246,6 +248,9 @@ int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
  *   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y,0); if (residual) y = max(residual + y, 0).  out may alias x. */
 int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                        const float *residual, float *out, void *stream);
+/* mean_inv (b,c,2) = (mean, 1/sqrt(var + eps)) of each plane from the same partial sums: the `pre_norm` input of the
+ * next rpe_conv_fused, which then normalises its input on the fly (no separate pass for norm1 + ReLU of a ResidualBlock). */
+int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw, float eps, float *mean_inv, void *stream);
 
 /* ---- input side: what the reference's datasets do on the CPU before a frame reaches
  * PoseEstimator (dataset/stereo_dataset.py:12-16,35-40, dataset/video_dataset.py:59-63, dataset/transforms.py:20-39).

@@ -26,7 +26,7 @@ class ConvDesc(_c.Structure):
     _fields_ = [('x', _f), ('x_batch_stride', _ll), ('packed', _f), ('bias', _f), ('add', _f), ('add_batch_stride', _ll),
                 ('out', _f), ('out_batch_stride', _ll), ('out2', _f), ('out2_batch_stride', _ll),
                 ('hidden', _f), ('hidden_batch_stride', _ll), ('zgate', _f), ('zgate_batch_stride', _ll),
-                ('scale', _f), ('residual', _f), ('residual_batch_stride', _ll), ('stats', _f),
+                ('scale', _f), ('residual', _f), ('residual_batch_stride', _ll), ('stats', _f), ('pre_norm', _f),
                 ('b', _i), ('cin', _i), ('cout', _i), ('h', _i), ('w', _i), ('kh', _i), ('kw', _i), ('mode', _i),
                 ('gate_channels', _i), ('stride', _i)]
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     'rpe_conv_fused': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
+    'rpe_instnorm_finalize': (_i, [_vp, _i, _i, _i, _i, _c.c_float, _vp, _vp]),
     'rpe_mask_specularities': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop_mask': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -40,6 +40,7 @@ struct ConvP {
     const float* scale;                       // [cout] or null: v = acc * scale + ...
     const float* res; long long rbs;          // residual added after the activation, then ReLU again (encoder blocks)
     float* stats;                             // [b][cout][tiles_n][2] partial (sum, sum of squares) of v, or null
+    const float* pre;                         // [b][cin][2] (mean, 1/std) or null: the input is normalised + ReLU'd as it is staged
 };
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const int nchunk = (P.cin + CK - 1) / CK;
     const int G = VERT ? nchunk : nchunk * P.kh;                 // groups = staged input tiles; each serves KW steps
     float4 ra0, ra1;                                             // (scalars: as an array it is demoted to LDS)
-    struct RB { float4 v[NLB]; float4 halo; unsigned ok; };      // one staged input tile (this thread's part); ok bits:
+    struct RB { float4 v[NLB]; float4 halo; unsigned ok; float pm, pi, hm, hi; };   // one staged input tile (this thread's part); ok bits:
                                                                  // u (and NLB = halo): lane's float4 is inside the map
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* wnext = P.wp + ((size_t)a_k4 * P.coP + m0 + a_m) * 4;        // this thread's float4 of step 0
@@ -166,6 +167,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
         const bool cok = lc * CK + b_k < P.cin;
         const int sh = (ld - ph) * W;
         const float* src = xrow + (size_t)lc * CK * hw;
+        if (ENC && P.pre) {                                      // instance norm of the INPUT (previous convolution's raw output)
+            const float* pp = P.pre + ((size_t)bz * P.cin + (cok ? lc * CK + b_k : 0)) * 2;
+            R.pm = pp[0]; R.pi = pp[1];
+            if (tid < 32) { const float* ph2 = P.pre + ((size_t)bz * P.cin + (lc * CK + h_k < P.cin ? lc * CK + h_k : 0)) * 2; R.hm = ph2[0]; R.hi = ph2[1]; }
+        }
         // out-of-map lanes read a valid dummy address; they are zeroed when the tile is written to LDS (a conditional
         // load is split into four branchy dword loads, and a select right here would wait for the data at once)
 #pragma unroll
@@ -210,15 +216,21 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             if (KW > 1 && tid < 16) Bs[buf][BN][h_k] = (R.ok >> NLB) & 1 ? R.halo.x : 0.0f;
             return;
         }
+        const bool pre = ENC && P.pre != nullptr;
+        auto prep = [&](float4 v, float m, float iv) -> float4 {  // relu((x - mean) / std): padding stays zero (applied to valid lanes only)
+            v.x = (v.x - m) * iv; v.y = (v.y - m) * iv; v.z = (v.z - m) * iv; v.w = (v.w - m) * iv;
+            v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+            return v;
+        };
 #pragma unroll
         for (int u = 0; u < NLB; ++u) {
             const int n = 4 + 4 * (b_n4 + 16 * u);
-            const float4 v = (R.ok >> u) & 1 ? R.v[u] : zero4;
+            const float4 v = (R.ok >> u) & 1 ? (pre ? prep(R.v[u], R.pm, R.pi) : R.v[u]) : zero4;
             Bs[buf][n + 0][b_k] = v.x; Bs[buf][n + 1][b_k] = v.y; Bs[buf][n + 2][b_k] = v.z; Bs[buf][n + 3][b_k] = v.w;
         }
         if (KW > 1 && tid < 32) {
             const int n = h_side ? 4 + BN : 0;
-            const float4 v = (R.ok >> NLB) & 1 ? R.halo : zero4;
+            const float4 v = (R.ok >> NLB) & 1 ? (pre ? prep(R.halo, R.hm, R.hi) : R.halo) : zero4;
             Bs[buf][n + 0][h_k] = v.x; Bs[buf][n + 1][h_k] = v.y; Bs[buf][n + 2][h_k] = v.z; Bs[buf][n + 3][h_k] = v.w;
         }
     };
@@ -410,6 +422,20 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     }
 }
 
+// (mean, 1/sqrt(var + eps)) per (b, c) plane from the partial sums: what k_conv_igemm's loader-side normalisation reads.
+__global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restrict__ partials, int tiles, int hw, float eps, float* __restrict__ mi) {
+    const int plane = blockIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < tiles; i += 64) { a += (double)partials[((size_t)plane * tiles + i) * 2]; q += (double)partials[((size_t)plane * tiles + i) * 2 + 1]; }
+    a = wave_sum(a); q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        const double mean = a / hw;
+        double var = q / hw - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        mi[(size_t)plane * 2] = (float)mean; mi[(size_t)plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // Instance norm from the per-tile partial sums k_conv_igemm left behind: one workgroup per (b, c) plane combines them
 // in f64 (mean, biased variance as E[x^2] - mean^2), then normalises in ONE read + write pass:
 //   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y, 0); if (residual) y = max(residual + y, 0)
@@ -481,7 +507,7 @@ extern "C" int rpe_conv_pack(const float* weight, int cout, int cin, int kh, int
     return rpe_check_launch();
 }
 
-static_assert(sizeof(rpe_conv_desc) == 184, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
+static_assert(sizeof(rpe_conv_desc) == 192, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
@@ -494,6 +520,7 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     if ((d->mode == RPE_CONV_GATE_ZR || d->mode == RPE_CONV_GATE_H) && (d->scale || d->residual || d->stats)) return RPE_E_BADARG;
     const int stride = d->stride ? d->stride : 1;
     if (stride != 1 && stride != 2) return RPE_E_UNSUPPORTED;
+    if (d->pre_norm && (stride != 1 || d->kw != 3 || d->mode > RPE_CONV_RELU)) return RPE_E_UNSUPPORTED;   // loader-side norm: 3x3 stride 1 only
     if (stride == 2 && ((d->h & 1) || (d->w & 1) || d->mode > RPE_CONV_RELU || !((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))))
         return RPE_E_UNSUPPORTED;                    // stride 2: 3x3 (pad 1) or 1x1 (pad 0) on even maps
     ConvP P;
@@ -503,7 +530,7 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     P.bias = d->bias; P.add = d->add; P.abs_ = d->add_batch_stride; P.mode = d->mode;
     P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.h = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels;
-    P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats;
+    P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats; P.pre = d->pre_norm;
     hipStream_t s = (hipStream_t)stream;
     if (stride == 2) {                               // 128x128 tiles only (the E/O staging doubles the input tile)
         dim3 g2(ceil_div(P.hw, 128), ceil_div(d->cout, 128), d->b);
@@ -514,7 +541,7 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     bool wide = (d->cout % 128) != 0;                // 64-row tiles waste less when cout is 64, 126, 192
     int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
     const bool half_tile = (d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3 && d->mode <= RPE_CONV_RELU;   // cout = 96
-    const bool enc = d->scale || d->residual || d->stats || half_tile;
+    const bool enc = d->scale || d->residual || d->stats || d->pre_norm || half_tile;
     // Launches that would leave most of the 256 CUs with at most one workgroup use 64x64 tiles instead (4x the
     // workgroups, 6+ of them resident per CU): the batch-1 / batch-2 maps of sequential tracking.
     const bool small = !enc && (long long)ceil_div(P.hw, BN) * ceil_div(d->cout, BM) * d->b < 512;
@@ -545,5 +572,11 @@ extern "C" int rpe_instnorm_apply(const float* x, const float* partials, int til
     if (!x || !partials || !out || tiles <= 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
     if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, hw, eps, relu, residual, out);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_instnorm_finalize(const float* partials, int tiles, int b, int c, int hw, float eps, float* mean_inv, void* stream) {
+    if (!partials || !mean_inv || tiles <= 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_instnorm_finalize, dim3(b * c), dim3(64), 0, (hipStream_t)stream, partials, tiles, hw, eps, mean_inv);
     return rpe_check_launch();
 }

@@ -343,7 +343,7 @@ class PackedConv:
 
 
 def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
-               residual=None, stats=None, stride=1):
+               residual=None, stats=None, stride=1, pre_norm=None):
     """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.
     ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the partial sums
     instnorm_apply needs."""
@@ -378,6 +378,10 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
         if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 2)):
             raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},2) GPU tensor')
     d.stats = ptr(stats)
+    if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
+                                     and tuple(pre_norm.shape) == (b, cin, 2)):
+        raise _lib.RpeError(f'conv_fused: pre_norm must be a contiguous float32 ({b},{cin},2) GPU tensor')
+    d.pre_norm = ptr(pre_norm)
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.gate_channels = b, cin, pc.cout, hh, ww, pc.kh, pc.kw, mode, gate_channels
     d.stride = stride
     import ctypes
@@ -388,6 +392,14 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
     """Partial-sum buffer rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 2); hh, ww = input map."""
     return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 2, dtype=torch.float32, device=device)
+
+
+def instnorm_finalize(stats, hw, eps=1e-5):
+    """(b,c,2) = (mean, 1/std) per plane from conv_fused's partial sums: the ``pre_norm`` argument of the next conv_fused."""
+    b, c, tiles, _ = stats.shape
+    mi = torch.empty(b, c, 2, dtype=torch.float32, device=stats.device)
+    check(lib().rpe_instnorm_finalize(ptr(stats), tiles, b, c, hw, float(eps), ptr(mi), stream_ptr()), 'rpe_instnorm_finalize')
+    return mi
 
 
 def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):

@@ -50,8 +50,24 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        """relu(x' + relu(norm2(conv2(relu(norm1(conv1 x)))))), x' = x or norm3(conv1x1 x); convolutions without
-        bias on MIOpen, every (bias, norm, ReLU, residual) epilogue one fused HIP pass (ops.conv_norm_act)."""
+        """relu(x' + relu(norm2(conv2(relu(norm1(conv1 x)))))), x' = x or norm3(conv1x1 x); every convolution with its
+        (bias, norm, ReLU, residual) epilogue fused (conv_norm_act).  With instance norm (fnet) norm1 + ReLU never exist
+        as a tensor: conv1 leaves its raw output and partial sums, and conv2 normalises that input while staging it."""
+        fused_in = isinstance(self.norm1, nn.InstanceNorm2d) and _fusable(self.conv1, x) and x.shape[-1] // self.conv1.stride[0] % 4 == 0
+        if fused_in:
+            b, _, hh, ww = x.shape
+            st = self.conv1.stride[0]
+            stats1 = ops.conv_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device, stride=st)
+            raw1 = ops.conv_fused(x, _packed(self.conv1), ops.CONV_LINEAR, torch.empty(b, self.conv1.out_channels, hh // st, ww // st, device=x.device),
+                                  bias=self.conv1.bias.detach(), stats=stats1, stride=st)
+            mi = ops.instnorm_finalize(stats1, (hh // st) * (ww // st), eps=self.norm1.eps)
+            if self.downsample is not None:
+                x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
+            ho, wo = raw1.shape[-2:]
+            stats2 = ops.conv_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
+            raw2 = ops.conv_fused(raw1, _packed(self.conv2), ops.CONV_LINEAR, torch.empty(b, self.conv2.out_channels, ho, wo, device=x.device),
+                                  bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
+            return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x)
         y = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         if self.downsample is not None:
             x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
@@ -78,17 +94,24 @@ def _packed(conv):
     return cached[1]
 
 
+def _fusable(conv, x):
+    """Can rpe_conv_fused run this encoder convolution on this input?  (3x3 stride 1; 3x3 pad 1 / 1x1 stride 2 on even maps.)"""
+    _, _, hh, ww = x.shape
+    s1 = conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+    s2 = conv.stride == (2, 2) and hh % 2 == 0 and ww % 2 == 0 and \
+        ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
+    stride = 2 if s2 else 1
+    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous()
+
+
 def conv_norm_act(conv, norm, x, relu, residual=None):
     """norm(conv(x) + bias) [ReLU] [+ residual, ReLU].  The residual blocks' convolutions -- 3x3 stride 1, 3x3 stride 2 and
     the 1x1 stride-2 shortcut -- run on the fused HIP implicit GEMM when the map width is a multiple of 4 (folded batch
     norm / ReLU / residual inside its epilogue; for instance norm the epilogue leaves per-tile partial sums and one more
     read+write pass normalises); the 7x7 stem and the final 1x1 stay on the library with a fused HIP epilogue pass."""
     b, _, hh, ww = x.shape
-    s1 = conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
-    s2 = conv.stride == (2, 2) and hh % 2 == 0 and ww % 2 == 0 and \
-        ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
-    stride = 2 if s2 else 1
-    fused = (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous()
+    fused = _fusable(conv, x)
+    stride = conv.stride[0] if fused else 1
     if isinstance(norm, nn.BatchNorm2d):
         if norm.training:
             raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')

@@ -223,3 +223,26 @@ def test_stride2_refusals(rpe):
     pc5 = ops.PackedConv(torch.zeros(32, 16, 1, 5, device='cuda'))
     with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):          # only 3x3 and 1x1 have a stride-2 kernel
         ops.conv_fused(torch.zeros(1, 16, 8, 12, device='cuda'), pc5, ops.CONV_LINEAR, torch.empty(1, 32, 4, 6, device='cuda'), stride=2)
+
+
+@pytest.mark.parametrize('c,h,w,b', [(64, 32, 40, 2), (128, 22, 24, 3)])
+def test_loader_side_instance_norm_matches_f64(rpe, c, h, w, b):
+    """conv2 of a fnet residual block reads conv1's RAW output and normalises it (+ReLU) while staging it: the result must
+    equal the convolution of the explicitly normalised tensor; zero padding applies after the normalisation."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(c + h)
+    x, w1, w2 = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, c, 3, 3, s=0.05)
+    b1, b2 = _rand(rng, c, s=0.5), _rand(rng, c, s=0.5)
+    pre = F.conv2d(x.double(), w1.double(), b1.double(), padding=1)
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    y = ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)
+    ref = F.conv2d(y, w2.double(), b2.double(), padding=1)
+    p1, p2 = ops.PackedConv(w1.cuda(), b1.cuda()), ops.PackedConv(w2.cuda(), b2.cuda())
+    stats = ops.conv_stats_buffer(b, c, h, w, 'cuda')
+    raw1 = ops.conv_fused(x.cuda(), p1, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), stats=stats)
+    mi = ops.instnorm_finalize(stats, h * w, eps=1e-5)
+    assert (mi[..., 0].cpu().double() - mean[:, :, 0, 0]).abs().max() < 1e-5
+    assert ((mi[..., 1].cpu().double() - 1 / torch.sqrt(var + 1e-5)[:, :, 0, 0]).abs() * torch.sqrt(var + 1e-5)[:, :, 0, 0]).max() < 1e-5
+    got = ops.conv_fused(raw1, p2, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), pre_norm=mi)
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert (got.cpu().double() - ref).abs().max() < _tol(y.float(), w2) + _tol(x, w1) * inv * float(w2.abs().sum((1, 2, 3)).max())
