@@ -1,0 +1,149 @@
+// The encoders' first layer (core/RAFT/core/extractor.py BasicEncoder.conv1 + norm1 + relu1; input normalisation of
+// core/RAFT/core/raft.py RAFT.forward: image = 2 * (image / 255) - 1): a 7x7 stride-2 pad-3 convolution of the three image
+// channels to 64, as an implicit GEMM on the f32 matrix cores that reads the RAW 0..255 image.
+//
+// K = 3*7*7 = 147 has no 16-channel chunks to stage, so the operand is built the other way round: a workgroup stages the
+// normalised input PATCH of its 32 x 8 output pixels once (3 x 21 x 69 floats, zero outside the image = the reference's
+// zero padding of the normalised image) and every MFMA B-operand element is a 4-byte LDS read of
+// patch[ci][2*ty + dy][2*tx + dx]; the k -> (ci, dy, dx) offsets come from a 148-entry table.  Weights ([k][64], 38 KB)
+// sit in LDS for the whole workgroup.  Epilogue as the residual blocks': bias, folded batch norm (cnet) or per-tile
+// partial sums for rpe_instnorm_apply (fnet), ReLU.
+#include "rpe_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define SK 148                                  // 147 taps + 1 zero row (the MFMA consumes k in pairs)
+#define SPX 32
+#define SPY 8
+#define PROWS (2 * SPY + 5)                     // 21
+#define PCOLS (2 * SPX + 5)                     // 69
+#define PSTR 72                                 // row stride of the staged patch
+
+struct StemP {
+    const float* x; int H, W, Ho, Wo;           // (b,3,H,W) raw image; output map
+    float div, mul, sub;                        // xn = mul * (x / div) - sub
+    const float* wk;                            // [SK][64]
+    const float* bias; const float* scale;      // v = acc * scale[co] + bias[co]   (scale may be null)
+    int relu;
+    float* out; float* stats;                   // (b,64,Ho,Wo); [b][64][tiles][2] or null
+};
+
+__device__ __forceinline__ float half_wave_sum_s(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
+    __shared__ __attribute__((aligned(16))) float As[SK][64];
+    __shared__ float patch[3][PROWS][PSTR];
+    __shared__ int koff[SK];
+    __shared__ float red[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int bz = blockIdx.z;
+    const int tiles_x = (P.Wo + SPX - 1) / SPX;
+    const int x0 = (blockIdx.x % tiles_x) * SPX, y0 = (blockIdx.x / tiles_x) * SPY;
+    const size_t hw_in = (size_t)P.H * P.W;
+    const float* xb = P.x + (size_t)bz * 3 * hw_in;
+    // ---- stage weights, tap table and the normalised input patch
+    for (int i = tid; i < SK * 64 / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)P.wk)[i];
+    for (int k = tid; k < SK; k += 256) {
+        const int kk = k < 147 ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
+        koff[k] = (ci * PROWS + dy) * PSTR + dx;
+    }
+    for (int i = tid; i < 3 * PROWS * PCOLS; i += 256) {
+        const int ci = i / (PROWS * PCOLS), r = (i / PCOLS) % PROWS, c = i % PCOLS;
+        const int yi = 2 * y0 - 3 + r, xi = 2 * x0 - 3 + c;
+        float v = 0.0f;
+        if (yi >= 0 && yi < P.H && xi >= 0 && xi < P.W)
+            v = rn_sub(rn_mul(P.mul, rn_div(xb[ci * hw_in + (size_t)yi * P.W + xi], P.div)), P.sub);     // 2 * (x / 255) - 1, as torch rounds it
+        patch[ci][r][c] = v;
+    }
+    __syncthreads();
+    // ---- 64 (co) x 256 (px) per workgroup; wave wv owns output rows 2*wv, 2*wv+1 of the patch (32 px each)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const float* pbase = &patch[0][0][0];
+    const int lane0 = (2 * (2 * wv)) * PSTR + 2 * l31, lane1 = (2 * (2 * wv + 1)) * PSTR + 2 * l31;
+#pragma unroll 2
+    for (int j = 0; j < SK / 2; ++j) {
+        const int k = 2 * j + lh;
+        const int ko = koff[k];
+        const float a0 = As[k][l31], a1 = As[k][32 + l31];
+        const float b0 = pbase[ko + lane0], b1 = pbase[ko + lane1];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // ---- epilogue (C/D layout: col = lane&31 = tx, row = (r&3) + 8*(r>>2) + 4*lh)
+    const size_t hw = (size_t)P.Ho * P.Wo;
+    float* ob = P.out + (size_t)bz * 64 * hw;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float sc = P.scale ? P.scale[co] : 1.0f, bi = P.bias ? P.bias[co] : 0.0f;
+            float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int y = y0 + 2 * wv + jj, x = x0 + l31;
+                if (y >= P.Ho || x >= P.Wo) continue;
+                float v = acc[i][jj][r] * sc + bi;
+                ssum += v; ssq += v * v;
+                if (P.relu) v = v < 0.0f ? 0.0f : v;
+                ob[(size_t)co * hw + (size_t)y * P.Wo + x] = v;
+            }
+            if (P.stats) {
+                ssum = half_wave_sum_s(ssum); ssq = half_wave_sum_s(ssq);
+                if (l31 == 31) { red[wv][co][0] = ssum; red[wv][co][1] = ssq; }
+            }
+        }
+    if (P.stats) {
+        __syncthreads();
+        if (tid < 64) {
+            const float a = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
+            const float q = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
+            float* st = P.stats + (((size_t)bz * 64 + tid) * gridDim.x + blockIdx.x) * 2;
+            st[0] = a; st[1] = q;
+        }
+    }
+}
+
+// weight (64, 3, 7, 7) -> [k = (ci*7 + dy)*7 + dx][co], row 147 zero
+__global__ void k_stem_pack(const float* __restrict__ w, float* __restrict__ wk) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= SK * 64) return;
+    const int k = e / 64, co = e % 64;
+    wk[e] = k < 147 ? w[co * 147 + k] : 0.0f;
+}
+
+extern "C" int rpe_stem_tiles(int h, int w) {
+    if (h <= 0 || w <= 0 || (h & 1) || (w & 1)) return 0;
+    return ceil_div(w / 2, SPX) * ceil_div(h / 2, SPY);
+}
+
+extern "C" int rpe_stem_pack(const float* weight, float* packed, void* stream) {
+    if (!weight || !packed) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_stem_pack, dim3(ceil_div(SK * 64, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_stem_conv(const float* image, int b, int h, int w, float div, float mul, float sub, const float* packed, const float* bias,
+                             const float* scale, int relu, float* out, float* stats, void* stream) {
+    if (!image || !packed || !out || b <= 0 || h <= 0 || w <= 0) return RPE_E_BADARG;
+    if ((h & 1) || (w & 1) || (((uintptr_t)packed) & 15)) return RPE_E_UNSUPPORTED;
+    StemP P;
+    P.x = image; P.H = h; P.W = w; P.Ho = h / 2; P.Wo = w / 2; P.div = div; P.mul = mul; P.sub = sub; P.wk = packed; P.bias = bias; P.scale = scale;
+    P.relu = relu; P.out = out; P.stats = stats;
+    hipLaunchKernelGGL(k_stem7x7, dim3(rpe_stem_tiles(h, w), 1, b), dim3(256), 0, (hipStream_t)stream, P);
+    return rpe_check_launch();
+}

@@ -415,3 +415,27 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):
     check(lib().rpe_instnorm_apply(ptr(x), ptr(stats), stats.shape[2], b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
                                    stream_ptr()), 'rpe_instnorm_apply')
     return out
+
+
+class PackedStem:
+    """The (64,3,7,7) first-layer weight in rpe_stem_conv's layout."""
+
+    def __init__(self, weight):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        if tuple(w.shape) != (64, 3, 7, 7):
+            raise _lib.RpeError('PackedStem: weight must be (64,3,7,7)')
+        self.packed = torch.empty(148 * 64, dtype=torch.float32, device=w.device)
+        check(lib().rpe_stem_pack(ptr(w), ptr(self.packed), stream_ptr()), 'rpe_stem_pack')
+
+
+def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.0, mul=2.0, sub=1.0):
+    """conv7x7/2(mul * (image / div) - sub) * scale + bias [ReLU] on the raw (b,3,h,w) image.  Returns out, or (out, stats)."""
+    _nchw(image, 'image')
+    b, c, hh, ww = image.shape
+    if c != 3:
+        raise _lib.RpeError('stem_conv: image must have 3 channels')
+    out = torch.empty(b, 64, hh // 2, ww // 2, dtype=torch.float32, device=image.device)
+    st = torch.empty(b, 64, lib().rpe_stem_tiles(hh, ww), 2, dtype=torch.float32, device=image.device) if stats else None
+    check(lib().rpe_stem_conv(ptr(image), b, hh, ww, float(div), float(mul), float(sub), ptr(ps.packed), ptr(bias), ptr(scale), int(bool(relu)),
+                              ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
+    return (out, st) if stats else out

@@ -158,8 +158,32 @@ class BasicEncoder(nn.Module):
         self.in_planes = dim
         return nn.Sequential(l1, l2)
 
-    def forward(self, x):
-        x = conv_norm_act(self.conv1, self.norm1, x.contiguous(), relu=True)
+    def _stem(self, image):
+        """conv1 + norm1 + ReLU on the RAW 0..255 image: the normalisation 2*(x/255)-1 happens while the kernel stages its
+        input patch (rpe_stem_conv)."""
+        key = (self.conv1.weight._version, self.conv1.weight.data_ptr())
+        if getattr(self, '_stem_packed', None) is None or self._stem_packed[0] != key:
+            self._stem_packed = (key, ops.PackedStem(self.conv1.weight))
+        ps = self._stem_packed[1]
+        if isinstance(self.norm1, nn.BatchNorm2d):
+            if self.norm1.training:
+                raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')
+            scale, shift = _bn_affine(self.conv1, self.norm1)
+            return ops.stem_conv(image, ps, bias=shift, scale=scale, relu=True)
+        pre, stats = ops.stem_conv(image, ps, bias=self.conv1.bias.detach(), relu=False, stats=True)
+        return ops.instnorm_apply(pre, stats, eps=self.norm1.eps, relu=True)
+
+    def forward(self, x, raw255=False):
+        """``raw255``: x is the raw 0..255 image (RAFT.forward's normalisation is then done inside the first kernel)."""
+        x = x.contiguous()
+        if raw255:
+            hh, ww = x.shape[-2:]
+            if hh % 2 == 0 and ww % 2 == 0 and ((hh // 2) * (ww // 2)) % 4 == 0 and isinstance(self.norm1, (nn.BatchNorm2d, nn.InstanceNorm2d)):
+                x = self._stem(x)
+            else:
+                x = conv_norm_act(self.conv1, self.norm1, 2 * (x / 255.0) - 1.0, relu=True)
+        else:
+            x = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         x = self.layer3(self.layer2(self.layer1(x)))
         return self.conv2(x)
 
@@ -353,12 +377,12 @@ class RAFT(nn.Module):
     @torch.no_grad()
     def encode_features(self, images):
         """fnet on raw 0..255 images (normalised like forward does)."""
-        return self.fnet(2 * (images / 255.0) - 1.0).float()
+        return self.fnet(images, raw255=True).float()
 
     @torch.no_grad()
     def encode_context(self, images):
         """cnet on raw 0..255 images: (N,256,H/8,W/8) = (hidden | context) pre-activations."""
-        return self.cnet(2 * (images / 255.0) - 1.0)
+        return self.cnet(images, raw255=True)
 
     @torch.no_grad()
     def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None, cnet=None):

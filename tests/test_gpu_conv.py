@@ -246,3 +246,28 @@ def test_loader_side_instance_norm_matches_f64(rpe, c, h, w, b):
     got = ops.conv_fused(raw1, p2, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), pre_norm=mi)
     inv = float((1 / torch.sqrt(var + 1e-5)).max())
     assert (got.cpu().double() - ref).abs().max() < _tol(y.float(), w2) + _tol(x, w1) * inv * float(w2.abs().sum((1, 2, 3)).max())
+
+
+@pytest.mark.parametrize('h,w,b', [(64, 80, 2), (44, 72, 1), (352, 384, 1)])
+def test_stem_conv_matches_f64(rpe, h, w, b):
+    """The encoders' first layer on the raw 0..255 image: 7x7 stride 2 pad 3 of 2*(x/255)-1 (zero padding of the normalised
+    image), with the folded-batch-norm + ReLU epilogue and with the instance-norm partial sums."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(h + w)
+    img = torch.from_numpy(rng.integers(0, 256, size=(b, 3, h, w)).astype(np.float32))
+    wt, bias = _rand(rng, 64, 3, 7, 7, s=0.1), _rand(rng, 64, s=0.3)
+    scale, shift = _rand(rng, 64).abs() + 0.5, _rand(rng, 64, s=0.3)
+    xn = (2 * (img / 255.0) - 1.0)
+    conv = F.conv2d(xn.double(), wt.double(), None, stride=2, padding=3)
+    ps = ops.PackedStem(wt.cuda())
+    tol = _tol(xn, wt) * 2
+    got = ops.stem_conv(img.cuda(), ps, bias=shift.cuda(), scale=scale.cuda(), relu=True)
+    ref = (conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]).clamp_min(0)
+    assert got.shape == ref.shape and (got.cpu().double() - ref).abs().max() < tol * 2.5
+    pre = conv + bias.double()[None, :, None, None]
+    raw, stats = ops.stem_conv(img.cuda(), ps, bias=bias.cuda(), relu=False, stats=True)
+    assert (raw.cpu().double() - pre).abs().max() < tol
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    out = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True)
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert (out.cpu().double() - ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)).abs().max() < (tol + 2e-6) * inv * 2
