@@ -257,7 +257,7 @@ int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw
  * image (b,3,h,w), h and w even; xn = mul * (x / div) - sub is applied while the input patch is staged (zero padding of the
  * NORMALISED image, as the reference).  v = conv * scale[co] + bias[co] (scale NULL = 1; folded batch norm for cnet);
  * optional ReLU; stats (b,64,rpe_stem_tiles(h,w),2) receives per-tile partial sums of v, v*v for rpe_instnorm_apply (fnet).
- * packed = rpe_stem_pack of the (64,3,7,7) weight: 148*64 floats. */
+ * packed = rpe_stem_pack of the (64,3,7,7) weight: 64*164 floats. */
 int rpe_stem_tiles(int h, int w);
 int rpe_stem_pack(const float *weight, float *packed, void *stream);
 int rpe_stem_conv(const float *image, int b, int h, int w, float div, float mul, float sub, const float *packed,

@@ -5,23 +5,26 @@
 // K = 3*7*7 = 147 has no 16-channel chunks to stage, so the operand is built the other way round: a workgroup stages the
 // normalised input PATCH of its 32 x 8 output pixels once (3 x 21 x 69 floats, zero outside the image = the reference's
 // zero padding of the normalised image) and every MFMA B-operand element is a 4-byte LDS read of
-// patch[ci][2*ty + dy][2*tx + dx]; the k -> (ci, dy, dx) offsets come from a 148-entry table.  Weights ([k][64], 38 KB)
-// sit in LDS for the whole workgroup.  Epilogue as the residual blocks': bias, folded batch norm (cnet) or per-tile
+// patch[ci][2*ty + dy][2*tx + dx]; the k -> (ci, dy, dx) offsets come from a 160-entry table.  Weights ([64][164], k
+// contiguous, 42 KB) sit in LDS for the whole workgroup; within a 16-tap block lane half lh of k2-step j takes k = 8*lh + j,
+// so a lane's eight weights and eight tap offsets are two ds_read_b128 each.  Epilogue as the residual blocks': bias, folded batch norm (cnet) or per-tile
 // partial sums for rpe_instnorm_apply (fnet), ReLU.
 #include "rpe_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define SK 148                                  // 147 taps + 1 zero row (the MFMA consumes k in pairs)
+#define SK 160                                  // 147 taps padded to ten 16-tap blocks (zero weights beyond 146)
+#define SKA 164                                 // weight row stride: 16 consecutive rows tile the 64 LDS banks for ds_read_b128
 #define SPX 32
 #define SPY 8
 #define PROWS (2 * SPY + 5)                     // 21
 #define PCOLS (2 * SPX + 5)                     // 69
 #define PSTR 72                                 // row stride of the staged patch
+#define SNP 5                                   // patches per workgroup (weights are staged once for all of them)
 
 struct StemP {
     const float* x; int H, W, Ho, Wo;           // (b,3,H,W) raw image; output map
     float div, mul, sub;                        // xn = mul * (x / div) - sub
-    const float* wk;                            // [SK][64]
+    const float* wk;                            // [64][SKA]
     const float* bias; const float* scale;      // v = acc * scale[co] + bias[co]   (scale may be null)
     int relu;
     float* out; float* stats;                   // (b,64,Ho,Wo); [b][64][tiles][2] or null
@@ -37,29 +40,48 @@ __device__ __forceinline__ float half_wave_sum_s(float v) {
 }
 
 __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
-    __shared__ __attribute__((aligned(16))) float As[SK][64];
+    __shared__ __attribute__((aligned(16))) float As[64][SKA];
     __shared__ float patch[3][PROWS][PSTR];
-    __shared__ int koff[SK];
+    __shared__ __attribute__((aligned(16))) int koff[SK];
     __shared__ float red[4][64][2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int bz = blockIdx.z;
     const int tiles_x = (P.Wo + SPX - 1) / SPX;
-    const int x0 = (blockIdx.x % tiles_x) * SPX, y0 = (blockIdx.x / tiles_x) * SPY;
+    const int ntiles = tiles_x * ((P.Ho + SPY - 1) / SPY);
     const size_t hw_in = (size_t)P.H * P.W;
     const float* xb = P.x + (size_t)bz * 3 * hw_in;
-    // ---- stage weights, tap table and the normalised input patch
-    for (int i = tid; i < SK * 64 / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)P.wk)[i];
+    // ---- stage weights and tap table once; then SNP patches one after the other
+    for (int i = tid; i < 64 * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)P.wk)[i];
     for (int k = tid; k < SK; k += 256) {
         const int kk = k < 147 ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
         koff[k] = (ci * PROWS + dy) * PSTR + dx;
     }
-    for (int i = tid; i < 3 * PROWS * PCOLS; i += 256) {
-        const int ci = i / (PROWS * PCOLS), r = (i / PCOLS) % PROWS, c = i % PCOLS;
-        const int yi = 2 * y0 - 3 + r, xi = 2 * x0 - 3 + c;
-        float v = 0.0f;
-        if (yi >= 0 && yi < P.H && xi >= 0 && xi < P.W)
-            v = rn_sub(rn_mul(P.mul, rn_div(xb[ci * hw_in + (size_t)yi * P.W + xi], P.div)), P.sub);     // 2 * (x / 255) - 1, as torch rounds it
-        patch[ci][r][c] = v;
+    for (int pi = 0; pi < SNP; ++pi) {
+    const int tile = blockIdx.x * SNP + pi;
+    if (tile >= ntiles) break;                               // (uniform)
+    const int x0 = (tile % tiles_x) * SPX, y0 = (tile / tiles_x) * SPY;
+    if (pi) __syncthreads();                                 // every wave is done reading the previous patch
+    {   // all loads of the patch first (clamped addresses, no branches), then normalise + store: as a load-use-store loop
+        // the 17 round trips per thread serialise and cost twice the MFMA time of the workgroup
+        constexpr int NI = (3 * PROWS * PCOLS + 255) / 256;
+        float raw[NI]; unsigned okm = 0;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u;
+            const int ci = i / (PROWS * PCOLS), rem = i - ci * (PROWS * PCOLS), r = rem / PCOLS, c = rem - r * PCOLS;
+            const int yi = 2 * y0 - 3 + r, xi = 2 * x0 - 3 + c;
+            const bool ok = (i < 3 * PROWS * PCOLS) & (yi >= 0) & (yi < P.H) & (xi >= 0) & (xi < P.W);
+            raw[u] = xb[ok ? ci * hw_in + (size_t)yi * P.W + xi : 0];
+            okm |= ok ? (1u << u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u;
+            if (i >= 3 * PROWS * PCOLS) break;
+            const int ci = i / (PROWS * PCOLS), rem = i - ci * (PROWS * PCOLS), r = rem / PCOLS, c = rem - r * PCOLS;
+            const float v = rn_sub(rn_mul(P.mul, rn_div(raw[u], P.div)), P.sub);          // 2 * (x / 255) - 1, as torch rounds it
+            patch[ci][r][c] = (okm >> u) & 1 ? v : 0.0f;
+        }
     }
     __syncthreads();
     // ---- 64 (co) x 256 (px) per workgroup; wave wv owns output rows 2*wv, 2*wv+1 of the patch (32 px each)
@@ -72,16 +94,24 @@ __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const float* pbase = &patch[0][0][0];
     const int lane0 = (2 * (2 * wv)) * PSTR + 2 * l31, lane1 = (2 * (2 * wv + 1)) * PSTR + 2 * l31;
-#pragma unroll 2
-    for (int j = 0; j < SK / 2; ++j) {
-        const int k = 2 * j + lh;
-        const int ko = koff[k];
-        const float a0 = As[k][l31], a1 = As[k][32 + l31];
-        const float b0 = pbase[ko + lane0], b1 = pbase[ko + lane1];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int blk = 0; blk < SK / 16; ++blk) {
+        const int kb = 16 * blk + 8 * lh;
+        f32x4 a0[2], a1[2]; i32x4 ko[2];
+        a0[0] = *(const f32x4*)&As[l31][kb];      a0[1] = *(const f32x4*)&As[l31][kb + 4];
+        a1[0] = *(const f32x4*)&As[32 + l31][kb]; a1[1] = *(const f32x4*)&As[32 + l31][kb + 4];
+        ko[0] = *(const i32x4*)&koff[kb];         ko[1] = *(const i32x4*)&koff[kb + 4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = ko[j >> 2][j & 3];
+            const float b0 = pbase[o + lane0], b1 = pbase[o + lane1];
+            const float fa0 = a0[j >> 2][j & 3], fa1 = a1[j >> 2][j & 3];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, b1, acc[1][1], 0, 0, 0);
+        }
     }
     // ---- epilogue (C/D layout: col = lane&31 = tx, row = (r&3) + 8*(r>>2) + 4*lh)
     const size_t hw = (size_t)P.Ho * P.Wo;
@@ -112,17 +142,18 @@ __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
         if (tid < 64) {
             const float a = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
             const float q = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
-            float* st = P.stats + (((size_t)bz * 64 + tid) * gridDim.x + blockIdx.x) * 2;
+            float* st = P.stats + (((size_t)bz * 64 + tid) * ntiles + tile) * 2;
             st[0] = a; st[1] = q;
         }
     }
+    }
 }
 
-// weight (64, 3, 7, 7) -> [k = (ci*7 + dy)*7 + dx][co], row 147 zero
+// weight (64, 3, 7, 7) -> [co][k = (ci*7 + dy)*7 + dx], rows padded to SKA floats, zero beyond k = 146
 __global__ void k_stem_pack(const float* __restrict__ w, float* __restrict__ wk) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= SK * 64) return;
-    const int k = e / 64, co = e % 64;
+    if (e >= 64 * SKA) return;
+    const int co = e / SKA, k = e % SKA;
     wk[e] = k < 147 ? w[co * 147 + k] : 0.0f;
 }
 
@@ -133,7 +164,7 @@ extern "C" int rpe_stem_tiles(int h, int w) {
 
 extern "C" int rpe_stem_pack(const float* weight, float* packed, void* stream) {
     if (!weight || !packed) return RPE_E_BADARG;
-    hipLaunchKernelGGL(k_stem_pack, dim3(ceil_div(SK * 64, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed);
+    hipLaunchKernelGGL(k_stem_pack, dim3(ceil_div(64 * SKA, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed);
     return rpe_check_launch();
 }
 
@@ -144,6 +175,6 @@ extern "C" int rpe_stem_conv(const float* image, int b, int h, int w, float div,
     StemP P;
     P.x = image; P.H = h; P.W = w; P.Ho = h / 2; P.Wo = w / 2; P.div = div; P.mul = mul; P.sub = sub; P.wk = packed; P.bias = bias; P.scale = scale;
     P.relu = relu; P.out = out; P.stats = stats;
-    hipLaunchKernelGGL(k_stem7x7, dim3(rpe_stem_tiles(h, w), 1, b), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(k_stem7x7, dim3(ceil_div(rpe_stem_tiles(h, w), SNP), 1, b), dim3(256), 0, (hipStream_t)stream, P);
     return rpe_check_launch();
 }

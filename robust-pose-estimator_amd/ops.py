@@ -424,7 +424,7 @@ class PackedStem:
         w = _nchw(weight.detach().contiguous(), 'weight')
         if tuple(w.shape) != (64, 3, 7, 7):
             raise _lib.RpeError('PackedStem: weight must be (64,3,7,7)')
-        self.packed = torch.empty(148 * 64, dtype=torch.float32, device=w.device)
+        self.packed = torch.empty(64 * 164, dtype=torch.float32, device=w.device)
         check(lib().rpe_stem_pack(ptr(w), ptr(self.packed), stream_ptr()), 'rpe_stem_pack')
 
 
