@@ -252,16 +252,21 @@ int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, 
  * next rpe_conv_fused, which then normalises its input on the fly (no separate pass for norm1 + ReLU of a ResidualBlock). */
 int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw, float eps, float *mean_inv, void *stream);
 
-/* ---- the encoders' first layer (core/RAFT/core/extractor.py BasicEncoder.conv1/norm1/relu1 with the input normalisation
- * of core/RAFT/core/raft.py: image = 2 * (image / 255) - 1): 7x7 stride-2 pad-3 convolution 3 -> 64 channels on the RAW
- * image (b,3,h,w), h and w even; xn = mul * (x / div) - sub is applied while the input patch is staged (zero padding of the
- * NORMALISED image, as the reference).  v = conv * scale[co] + bias[co] (scale NULL = 1; folded batch norm for cnet);
- * optional ReLU; stats (b,64,rpe_stem_tiles(h,w),2) receives per-tile partial sums of v, v*v for rpe_instnorm_apply (fnet).
- * packed = rpe_stem_pack of the (64,3,7,7) weight: 64*164 floats. */
-int rpe_stem_tiles(int h, int w);
-int rpe_stem_pack(const float *weight, float *packed, void *stream);
-int rpe_stem_conv(const float *image, int b, int h, int w, float div, float mul, float sub, const float *packed,
-                  const float *bias, const float *scale, int relu, float *out, float *stats, void *stream);
+/* ---- 7x7 convolutions of few input channels as patch-staged implicit GEMMs (csrc/stem.hip):
+ *   cin = 3, stride 2: the encoders' first layer (core/RAFT/core/extractor.py BasicEncoder.conv1/norm1/relu1) on the RAW
+ *                      0..255 image with RAFT.forward's normalisation image = 2 * (image / 255) - 1 (core/RAFT/core/raft.py)
+ *                      applied while the input patch is staged (zero padding of the NORMALISED image, as the reference);
+ *   cin = 2, stride 1: the motion encoder's convf1 on the flow (core/RAFT/core/update.py), div = mul = 1, sub = 0.
+ * xn = mul * (x / div) - sub;  v = conv7x7(xn; pad 3) * scale[co] + bias[co] (scale NULL = 1: folded batch norm for cnet);
+ * optional ReLU; stats (b,cout,rpe_stem_tiles(h,w,stride),2) receives per-tile partial sums of v, v*v for
+ * rpe_instnorm_apply (fnet).  cout % 64 == 0; stride 2 needs even h, w.  packed = rpe_stem_pack of the (cout,cin,7,7)
+ * weight (rpe_stem_packed_floats floats). */
+int rpe_stem_tiles(int h, int w, int stride);
+size_t rpe_stem_packed_floats(int cout, int cin);
+int rpe_stem_pack(const float *weight, int cout, int cin, float *packed, void *stream);
+int rpe_stem_conv(const float *image, int b, int cin, int h, int w, int stride, float div, float mul, float sub,
+                  const float *packed, int cout, const float *bias, const float *scale, int relu, float *out,
+                  float *stats, void *stream);
 
 /* ---- input side: what the reference's datasets do on the CPU before a frame reaches
  * PoseEstimator (dataset/stereo_dataset.py:12-16,35-40, dataset/video_dataset.py:59-63, dataset/transforms.py:20-39).

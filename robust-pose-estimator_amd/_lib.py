@@ -65,9 +65,10 @@ SIGNATURES = {
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
     'rpe_instnorm_finalize': (_i, [_vp, _i, _i, _i, _i, _c.c_float, _vp, _vp]),
-    'rpe_stem_tiles': (_i, [_i, _i]),
-    'rpe_stem_pack': (_i, [_vp, _vp, _vp]),
-    'rpe_stem_conv': (_i, [_vp, _i, _i, _i, _c.c_float, _c.c_float, _c.c_float, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'rpe_stem_tiles': (_i, [_i, _i, _i]),
+    'rpe_stem_packed_floats': (_sz, [_i, _i]),
+    'rpe_stem_pack': (_i, [_vp, _i, _i, _vp, _vp]),
+    'rpe_stem_conv': (_i, [_vp, _i, _i, _i, _i, _i, _c.c_float, _c.c_float, _c.c_float, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     'rpe_mask_specularities': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop_mask': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

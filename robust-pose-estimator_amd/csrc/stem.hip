@@ -12,22 +12,28 @@
 #include "rpe_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define SK 160                                  // 147 taps padded to ten 16-tap blocks (zero weights beyond 146)
-#define SKA 164                                 // weight row stride: 16 consecutive rows tile the 64 LDS banks for ds_read_b128
 #define SPX 32
 #define SPY 8
-#define PROWS (2 * SPY + 5)                     // 21
-#define PCOLS (2 * SPX + 5)                     // 69
-#define PSTR 72                                 // row stride of the staged patch
-#define SNP 5                                   // patches per workgroup (weights are staged once for all of them)
+// The same kernel serves the motion encoder's convf1 (core/RAFT/core/update.py: 7x7 stride 1 on the 2 flow channels -> 128,
+// bias + ReLU): template <CIN, STRIDE>, 64 output channels per workgroup (blockIdx.y picks the channel tile).
+template <int CIN, int STRIDE> struct StemGeo {
+    static constexpr int TAPS = CIN * 49;
+    static constexpr int SK = (TAPS + 15) / 16 * 16;            // taps padded to 16-tap blocks (zero weights beyond): 160 / 112
+    static constexpr int SKA = SK + 4;                          // weight row stride 164 / 116: 16 consecutive rows tile the 64 banks
+    static constexpr int PROWS = STRIDE * SPY + 7 - STRIDE;     // 21 / 14
+    static constexpr int PCOLS = STRIDE * SPX + 7 - STRIDE;     // 69 / 38
+    static constexpr int PSTR = (PCOLS + 7) / 8 * 8;            // 72 / 40
+    static constexpr int SNP = CIN == 3 ? 5 : 1;                // patches per workgroup (weights staged once for all): the stem has
+                                                                // 15 360 patches per launch, convf1 only 768 x 2 channel tiles
+};
 
 struct StemP {
-    const float* x; int H, W, Ho, Wo;           // (b,3,H,W) raw image; output map
+    const float* x; int H, W, Ho, Wo, cout;     // (b,CIN,H,W) input; output map; total output channels
     float div, mul, sub;                        // xn = mul * (x / div) - sub
     const float* wk;                            // [64][SKA]
     const float* bias; const float* scale;      // v = acc * scale[co] + bias[co]   (scale may be null)
     int relu;
-    float* out; float* stats;                   // (b,64,Ho,Wo); [b][64][tiles][2] or null
+    float* out; float* stats;                   // (b,cout,Ho,Wo); [b][cout][tiles][2] or null
 };
 
 __device__ __forceinline__ float half_wave_sum_s(float v) {
@@ -39,21 +45,24 @@ __device__ __forceinline__ float half_wave_sum_s(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
+template <int CIN, int STRIDE>
+__global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
+    typedef StemGeo<CIN, STRIDE> G;
+    constexpr int SK = G::SK, SKA = G::SKA, PROWS = G::PROWS, PCOLS = G::PCOLS, PSTR = G::PSTR, TAPS = G::TAPS, SNP = G::SNP;
     __shared__ __attribute__((aligned(16))) float As[64][SKA];
-    __shared__ float patch[3][PROWS][PSTR];
+    __shared__ float patch[CIN][PROWS][PSTR];
     __shared__ __attribute__((aligned(16))) int koff[SK];
     __shared__ float red[4][64][2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int bz = blockIdx.z;
+    const int bz = blockIdx.z, cbase = blockIdx.y * 64;
     const int tiles_x = (P.Wo + SPX - 1) / SPX;
     const int ntiles = tiles_x * ((P.Ho + SPY - 1) / SPY);
     const size_t hw_in = (size_t)P.H * P.W;
-    const float* xb = P.x + (size_t)bz * 3 * hw_in;
+    const float* xb = P.x + (size_t)bz * CIN * hw_in;
     // ---- stage weights and tap table once; then SNP patches one after the other
-    for (int i = tid; i < 64 * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)P.wk)[i];
+    for (int i = tid; i < 64 * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)(P.wk + (size_t)cbase * SKA))[i];
     for (int k = tid; k < SK; k += 256) {
-        const int kk = k < 147 ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
+        const int kk = k < TAPS ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
         koff[k] = (ci * PROWS + dy) * PSTR + dx;
     }
     for (int pi = 0; pi < SNP; ++pi) {
@@ -63,21 +72,21 @@ __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
     if (pi) __syncthreads();                                 // every wave is done reading the previous patch
     {   // all loads of the patch first (clamped addresses, no branches), then normalise + store: as a load-use-store loop
         // the 17 round trips per thread serialise and cost twice the MFMA time of the workgroup
-        constexpr int NI = (3 * PROWS * PCOLS + 255) / 256;
+        constexpr int NI = (CIN * PROWS * PCOLS + 255) / 256;
         float raw[NI]; unsigned okm = 0;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int i = tid + 256 * u;
             const int ci = i / (PROWS * PCOLS), rem = i - ci * (PROWS * PCOLS), r = rem / PCOLS, c = rem - r * PCOLS;
-            const int yi = 2 * y0 - 3 + r, xi = 2 * x0 - 3 + c;
-            const bool ok = (i < 3 * PROWS * PCOLS) & (yi >= 0) & (yi < P.H) & (xi >= 0) & (xi < P.W);
+            const int yi = STRIDE * y0 - 3 + r, xi = STRIDE * x0 - 3 + c;
+            const bool ok = (i < CIN * PROWS * PCOLS) & (yi >= 0) & (yi < P.H) & (xi >= 0) & (xi < P.W);
             raw[u] = xb[ok ? ci * hw_in + (size_t)yi * P.W + xi : 0];
             okm |= ok ? (1u << u) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int i = tid + 256 * u;
-            if (i >= 3 * PROWS * PCOLS) break;
+            if (i >= CIN * PROWS * PCOLS) break;
             const int ci = i / (PROWS * PCOLS), rem = i - ci * (PROWS * PCOLS), r = rem / PCOLS, c = rem - r * PCOLS;
             const float v = rn_sub(rn_mul(P.mul, rn_div(raw[u], P.div)), P.sub);          // 2 * (x / 255) - 1, as torch rounds it
             patch[ci][r][c] = (okm >> u) & 1 ? v : 0.0f;
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const float* pbase = &patch[0][0][0];
-    const int lane0 = (2 * (2 * wv)) * PSTR + 2 * l31, lane1 = (2 * (2 * wv + 1)) * PSTR + 2 * l31;
+    const int lane0 = (STRIDE * (2 * wv)) * PSTR + STRIDE * l31, lane1 = (STRIDE * (2 * wv + 1)) * PSTR + STRIDE * l31;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int blk = 0; blk < SK / 16; ++blk) {
@@ -115,13 +124,13 @@ __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
     }
     // ---- epilogue (C/D layout: col = lane&31 = tx, row = (r&3) + 8*(r>>2) + 4*lh)
     const size_t hw = (size_t)P.Ho * P.Wo;
-    float* ob = P.out + (size_t)bz * 64 * hw;
+    float* ob = P.out + ((size_t)bz * P.cout + cbase) * hw;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float sc = P.scale ? P.scale[co] : 1.0f, bi = P.bias ? P.bias[co] : 0.0f;
+            const float sc = P.scale ? P.scale[cbase + co] : 1.0f, bi = P.bias ? P.bias[cbase + co] : 0.0f;
             float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -142,39 +151,47 @@ __global__ __launch_bounds__(256) void k_stem7x7(StemP P) {
         if (tid < 64) {
             const float a = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
             const float q = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
-            float* st = P.stats + (((size_t)bz * 64 + tid) * ntiles + tile) * 2;
+            float* st = P.stats + (((size_t)bz * P.cout + cbase + tid) * ntiles + tile) * 2;
             st[0] = a; st[1] = q;
         }
     }
     }
 }
 
-// weight (64, 3, 7, 7) -> [co][k = (ci*7 + dy)*7 + dx], rows padded to SKA floats, zero beyond k = 146
-__global__ void k_stem_pack(const float* __restrict__ w, float* __restrict__ wk) {
+// weight (cout, cin, 7, 7) -> [co][k = (ci*7 + dy)*7 + dx], rows padded to ska floats, zero beyond the last tap
+__global__ void k_stem_pack(const float* __restrict__ w, float* __restrict__ wk, int cout, int taps, int ska) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 64 * SKA) return;
-    const int co = e / SKA, k = e % SKA;
-    wk[e] = k < 147 ? w[co * 147 + k] : 0.0f;
+    if (e >= cout * ska) return;
+    const int co = e / ska, k = e % ska;
+    wk[e] = k < taps ? w[co * taps + k] : 0.0f;
 }
 
-extern "C" int rpe_stem_tiles(int h, int w) {
-    if (h <= 0 || w <= 0 || (h & 1) || (w & 1)) return 0;
-    return ceil_div(w / 2, SPX) * ceil_div(h / 2, SPY);
+static int stem_ska(int cin) { return (cin * 49 + 15) / 16 * 16 + 4; }
+static bool stem_ok(int cin, int stride, int cout) { return ((cin == 3 && stride == 2) || (cin == 2 && stride == 1)) && cout > 0 && cout % 64 == 0; }
+
+extern "C" int rpe_stem_tiles(int h, int w, int stride) {
+    if (h <= 0 || w <= 0 || (stride != 1 && stride != 2) || (stride == 2 && ((h & 1) || (w & 1)))) return 0;
+    return ceil_div(w / stride, SPX) * ceil_div(h / stride, SPY);
 }
 
-extern "C" int rpe_stem_pack(const float* weight, float* packed, void* stream) {
-    if (!weight || !packed) return RPE_E_BADARG;
-    hipLaunchKernelGGL(k_stem_pack, dim3(ceil_div(64 * SKA, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed);
+extern "C" size_t rpe_stem_packed_floats(int cout, int cin) { return (cout > 0 && (cin == 2 || cin == 3)) ? (size_t)cout * stem_ska(cin) : 0; }
+
+extern "C" int rpe_stem_pack(const float* weight, int cout, int cin, float* packed, void* stream) {
+    if (!weight || !packed || cout <= 0 || (cin != 2 && cin != 3)) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_stem_pack, dim3(ceil_div((int64_t)cout * stem_ska(cin), 256)), dim3(256), 0, (hipStream_t)stream, weight, packed, cout,
+                       cin * 49, stem_ska(cin));
     return rpe_check_launch();
 }
 
-extern "C" int rpe_stem_conv(const float* image, int b, int h, int w, float div, float mul, float sub, const float* packed, const float* bias,
-                             const float* scale, int relu, float* out, float* stats, void* stream) {
+extern "C" int rpe_stem_conv(const float* image, int b, int cin, int h, int w, int stride, float div, float mul, float sub, const float* packed,
+                             int cout, const float* bias, const float* scale, int relu, float* out, float* stats, void* stream) {
     if (!image || !packed || !out || b <= 0 || h <= 0 || w <= 0) return RPE_E_BADARG;
-    if ((h & 1) || (w & 1) || (((uintptr_t)packed) & 15)) return RPE_E_UNSUPPORTED;
+    if (!stem_ok(cin, stride, cout) || (stride == 2 && ((h & 1) || (w & 1))) || (((uintptr_t)packed) & 15)) return RPE_E_UNSUPPORTED;
     StemP P;
-    P.x = image; P.H = h; P.W = w; P.Ho = h / 2; P.Wo = w / 2; P.div = div; P.mul = mul; P.sub = sub; P.wk = packed; P.bias = bias; P.scale = scale;
-    P.relu = relu; P.out = out; P.stats = stats;
-    hipLaunchKernelGGL(k_stem7x7, dim3(ceil_div(rpe_stem_tiles(h, w), SNP), 1, b), dim3(256), 0, (hipStream_t)stream, P);
+    P.x = image; P.H = h; P.W = w; P.Ho = h / stride; P.Wo = w / stride; P.cout = cout; P.div = div; P.mul = mul; P.sub = sub; P.wk = packed;
+    P.bias = bias; P.scale = scale; P.relu = relu; P.out = out; P.stats = stats;
+    dim3 grid(ceil_div(rpe_stem_tiles(h, w, stride), cin == 3 ? StemGeo<3, 2>::SNP : StemGeo<2, 1>::SNP), cout / 64, b);
+    if (cin == 3) hipLaunchKernelGGL((k_stem7x7<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((k_stem7x7<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, P);
     return rpe_check_launch();
 }

@@ -418,24 +418,28 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):
 
 
 class PackedStem:
-    """The (64,3,7,7) first-layer weight in rpe_stem_conv's layout."""
+    """A (cout, cin, 7, 7) weight (cin 3: encoder stem, stride 2; cin 2: convf1, stride 1) in rpe_stem_conv's layout."""
 
     def __init__(self, weight):
         w = _nchw(weight.detach().contiguous(), 'weight')
-        if tuple(w.shape) != (64, 3, 7, 7):
-            raise _lib.RpeError('PackedStem: weight must be (64,3,7,7)')
-        self.packed = torch.empty(64 * 164, dtype=torch.float32, device=w.device)
-        check(lib().rpe_stem_pack(ptr(w), ptr(self.packed), stream_ptr()), 'rpe_stem_pack')
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        if tuple(w.shape[2:]) != (7, 7) or self.cin not in (2, 3) or self.cout % 64:
+            raise _lib.RpeError('PackedStem: weight must be (64k, 2|3, 7, 7)')
+        self.stride = 2 if self.cin == 3 else 1
+        self.packed = torch.empty(lib().rpe_stem_packed_floats(self.cout, self.cin), dtype=torch.float32, device=w.device)
+        check(lib().rpe_stem_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_stem_pack')
 
 
 def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.0, mul=2.0, sub=1.0):
-    """conv7x7/2(mul * (image / div) - sub) * scale + bias [ReLU] on the raw (b,3,h,w) image.  Returns out, or (out, stats)."""
+    """conv7x7(mul * (image / div) - sub) * scale + bias [ReLU]; stride and channel counts come from ``ps``.
+    Returns out, or (out, stats)."""
     _nchw(image, 'image')
     b, c, hh, ww = image.shape
-    if c != 3:
-        raise _lib.RpeError('stem_conv: image must have 3 channels')
-    out = torch.empty(b, 64, hh // 2, ww // 2, dtype=torch.float32, device=image.device)
-    st = torch.empty(b, 64, lib().rpe_stem_tiles(hh, ww), 2, dtype=torch.float32, device=image.device) if stats else None
-    check(lib().rpe_stem_conv(ptr(image), b, hh, ww, float(div), float(mul), float(sub), ptr(ps.packed), ptr(bias), ptr(scale), int(bool(relu)),
-                              ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
+    if c != ps.cin:
+        raise _lib.RpeError(f'stem_conv: image must have {ps.cin} channels')
+    st_ = ps.stride
+    out = torch.empty(b, ps.cout, hh // st_, ww // st_, dtype=torch.float32, device=image.device)
+    st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 2, dtype=torch.float32, device=image.device) if stats else None
+    check(lib().rpe_stem_conv(ptr(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), ptr(ps.packed), ps.cout, ptr(bias), ptr(scale),
+                              int(bool(relu)), ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
     return (out, st) if stats else out

@@ -232,7 +232,7 @@ class BasicMotionEncoder(nn.Module):
         if packed is not None:
             cor = ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, packed['cor_buf'](corr))
             ops.conv_fused(cor, packed['convc2'], ops.CONV_RELU, cat_buf[:, :192])
-            flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)           # 7x7 on 2 channels: not a GEMM
+            flo = ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0)   # 7x7 on 2 channels
             ops.conv_fused(flo, packed['convf2'], ops.CONV_RELU, cat_buf[:, 192:])
             ops.conv_fused(cat_buf, packed['conv'], ops.CONV_RELU, hx[:, 128:254], out2=rhx[:, 128:254])
         else:
@@ -289,11 +289,13 @@ class BasicUpdateBlock(nn.Module):
             return None
         e, fh = self.encoder, self.flow_head
         mods = (e.convc1, e.convc2, e.convf2, e.conv, fh.conv1)
-        key = tuple(p._version for m in mods for p in m.parameters()) + tuple(p.data_ptr() for m in mods for p in m.parameters()) + \
+        keymods = mods + (e.convf1,)
+        key = tuple(p._version for m in keymods for p in m.parameters()) + tuple(p.data_ptr() for m in keymods for p in m.parameters()) + \
             (id(self.gate_weights()),)
         if getattr(self, '_packed', None) is None or self._packed[0] != key:
             W = self.gate_weights()
             P = {n: ops.PackedConv(m.weight, m.bias) for n, m in zip(('convc1', 'convc2', 'convf2', 'conv', 'fh1'), mods)}
+            P['convf1'] = ops.PackedStem(e.convf1.weight)
             for n in ('zr1', 'q1', 'zr2', 'q2'):
                 P[n] = ops.PackedConv(W[n][0])                # bias is part of the context term (context_terms)
             scratch = {}

@@ -271,3 +271,14 @@ def test_stem_conv_matches_f64(rpe, h, w, b):
     out = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True)
     inv = float((1 / torch.sqrt(var + 1e-5)).max())
     assert (out.cpu().double() - ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)).abs().max() < (tol + 2e-6) * inv * 2
+
+
+@pytest.mark.parametrize('h,w,b', [(64, 80, 3), (44, 48, 2), (13, 37, 1)])
+def test_convf1_patch_kernel_matches_f64(rpe, h, w, b):
+    """The motion encoder's 7x7 convolution of the two flow channels (stride 1, 128 outputs, bias + ReLU) on the patch-staged kernel."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(h * w)
+    flow, wt, bias = _rand(rng, b, 2, h, w, s=5.0), _rand(rng, 128, 2, 7, 7, s=0.1), _rand(rng, 128, s=0.3)
+    ref = F.conv2d(flow.double(), wt.double(), bias.double(), padding=3).clamp_min(0)
+    got = ops.stem_conv(flow.cuda(), ops.PackedStem(wt.cuda()), bias=bias.cuda(), relu=True, div=1.0, mul=1.0, sub=0.0)
+    assert got.shape == ref.shape and (got.cpu().double() - ref).abs().max() < _tol(flow, wt)
