@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 a0h1, a1h1, b0h1, b1h1, a0h2, a1h2, b0h2, b1h2;
     const bool hi_rows = T == 1 || m0 + wm * WT + 32 < P.cout;
+    const bool wave_rows = m0 + wm * WT < P.cout;                // false: this wave's 64 output rows lie beyond cout (cout = 192 on 128-row tiles)
     auto read_h1 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * WT + l31][8 * lh];
         const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : S2 ? wn * WT + l31 + (dx == 0 ? 0 : dx < 0 ? BN : BN + 1) : 4 + wn * WT + l31 + dx][8 * lh];
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
         float fb0[4], fb1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fb0[j] = v0 ? b0[j] : 0.0f; fb1[j] = v1 ? b1[j] : 0.0f; }   // column mask at use, not at the read
+        if (!ENC && !wave_rows) return;                          // (wave-uniform; the wave still loads, stores and synchronises)
         if (T == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
@@ -538,7 +540,8 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
         else hipLaunchKernelGGL((k_conv_igemm<1, 2, true, 2, false, true>), g2, dim3(256), 0, s, P);
         return rpe_check_launch();
     }
-    bool wide = (d->cout % 128) != 0;                // 64-row tiles waste less when cout is 64, 126, 192
+    bool wide = (d->cout % 128) != 0 && (d->cout % 128) <= 96;   // 64-row tiles for cout 64 / 96 / 192; 126 runs on one 128-row tile
+                                                     // (192 on 128-row tiles with two idle waves was measured: 1.47 vs 1.20 ms)
     int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
     const bool half_tile = (d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3 && d->mode <= RPE_CONV_RELU;   // cout = 96
     const bool enc = d->scale || d->residual || d->stats || d->pre_norm || half_tile;
