@@ -372,7 +372,8 @@ extern "C" int rpe_affine_act(const float* x, const float* scale, const float* s
 extern "C" int rpe_conv3x3_to2(const float* x, const float* weight, const float* bias, int b, int c, int h, int w,
                                const float* add, float* out, void* stream) {
     if (!x || !weight || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0) return RPE_E_BADARG;
-    if ((w & 3) == 0 && vec_ok(x) && vec_ok(out) && (!add || vec_ok(add)))
+    // (the four-pixel kernel has a quarter of the workgroups: small launches -- one frame of sequential tracking -- keep the one-pixel one)
+    if ((w & 3) == 0 && vec_ok(x) && vec_ok(out) && (!add || vec_ok(add)) && (long long)ceil_div((size_t)h * w / 4, 64) * b >= 256)
         hipLaunchKernelGGL(k_conv3x3_to2_x4, dim3(ceil_div((size_t)h * w / 4, 64), b), dim3(64 * TO2_WAVES), 0, (hipStream_t)stream, x, weight, bias,
                            c, h, w, add, out);
     else

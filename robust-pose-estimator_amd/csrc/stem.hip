@@ -23,8 +23,6 @@ template <int CIN, int STRIDE> struct StemGeo {
     static constexpr int PROWS = STRIDE * SPY + 7 - STRIDE;     // 21 / 14
     static constexpr int PCOLS = STRIDE * SPX + 7 - STRIDE;     // 69 / 38
     static constexpr int PSTR = (PCOLS + 7) / 8 * 8;            // 72 / 40
-    static constexpr int SNP = CIN == 3 ? 5 : 1;                // patches per workgroup (weights staged once for all): the stem has
-                                                                // 15 360 patches per launch, convf1 only 768 x 2 channel tiles
 };
 
 struct StemP {
@@ -32,7 +30,7 @@ struct StemP {
     float div, mul, sub;                        // xn = mul * (x / div) - sub
     const float* wk;                            // [64][SKA]
     const float* bias; const float* scale;      // v = acc * scale[co] + bias[co]   (scale may be null)
-    int relu;
+    int relu, snp;                              // snp: patches per workgroup (weights are staged once for all of them)
     float* out; float* stats;                   // (b,cout,Ho,Wo); [b][cout][tiles][2] or null
 };
 
@@ -48,7 +46,8 @@ __device__ __forceinline__ float half_wave_sum_s(float v) {
 template <int CIN, int STRIDE>
 __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     typedef StemGeo<CIN, STRIDE> G;
-    constexpr int SK = G::SK, SKA = G::SKA, PROWS = G::PROWS, PCOLS = G::PCOLS, PSTR = G::PSTR, TAPS = G::TAPS, SNP = G::SNP;
+    constexpr int SK = G::SK, SKA = G::SKA, PROWS = G::PROWS, PCOLS = G::PCOLS, PSTR = G::PSTR, TAPS = G::TAPS;
+    const int SNP = P.snp;
     __shared__ __attribute__((aligned(16))) float As[64][SKA];
     __shared__ float patch[CIN][PROWS][PSTR];
     __shared__ __attribute__((aligned(16))) int koff[SK];
@@ -190,7 +189,11 @@ extern "C" int rpe_stem_conv(const float* image, int b, int cin, int h, int w, i
     StemP P;
     P.x = image; P.H = h; P.W = w; P.Ho = h / stride; P.Wo = w / stride; P.cout = cout; P.div = div; P.mul = mul; P.sub = sub; P.wk = packed;
     P.bias = bias; P.scale = scale; P.relu = relu; P.out = out; P.stats = stats;
-    dim3 grid(ceil_div(rpe_stem_tiles(h, w, stride), cin == 3 ? StemGeo<3, 2>::SNP : StemGeo<2, 1>::SNP), cout / 64, b);
+    // several patches per workgroup share one staging of the weights -- when the launch still fills the chip that way
+    // (bench: 15 360 stem patches; one frame of sequential tracking: 640)
+    const long long patches = (long long)rpe_stem_tiles(h, w, stride) * (cout / 64) * b;
+    P.snp = patches >= 5 * 2048 ? 5 : patches >= 2 * 2048 ? 2 : 1;
+    dim3 grid(ceil_div(rpe_stem_tiles(h, w, stride), P.snp), cout / 64, b);
     if (cin == 3) hipLaunchKernelGGL((k_stem7x7<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL((k_stem7x7<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, P);
     return rpe_check_launch();

@@ -343,10 +343,11 @@ class PackedConv:
 
 
 def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
-               residual=None, stats=None, stride=1, pre_norm=None):
+               residual=None, stats=None, stride=1, pre_norm=None, prepare=False):
     """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.
     ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the partial sums
-    instnorm_apply needs."""
+    instnorm_apply needs.  ``prepare=True`` returns a zero-argument launcher instead of launching: the GRU loop runs the same
+    nine convolutions on the same buffers twelve times, and at batch 1 the Python argument checking costs more than the kernels."""
     d = _lib.ConvDesc()
     b, cin, hh, ww = x.shape
     if cin != pc.cin:
@@ -385,6 +386,16 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.gate_channels = b, cin, pc.cout, hh, ww, pc.kh, pc.kw, mode, gate_channels
     d.stride = stride
     import ctypes
+    if prepare:                                    # the checked descriptor, to be launched again and again on the same buffers
+        fn, ref, keep = lib().rpe_conv_fused, ctypes.byref(d), (d, x, pc, out, out2, add, hidden, zgate, scale, bias, residual, stats, pre_norm)
+
+        def launch():
+            st = fn(ref, stream_ptr())
+            if st != 0:
+                check(st, 'rpe_conv_fused')
+            return keep[3]
+        launch.keep = keep
+        return launch
     check(lib().rpe_conv_fused(ctypes.byref(d), stream_ptr()), 'rpe_conv_fused')
     return out
 
@@ -430,7 +441,7 @@ class PackedStem:
         check(lib().rpe_stem_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_stem_pack')
 
 
-def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.0, mul=2.0, sub=1.0):
+def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.0, mul=2.0, sub=1.0, out=None):
     """conv7x7(mul * (image / div) - sub) * scale + bias [ReLU]; stride and channel counts come from ``ps``.
     Returns out, or (out, stats)."""
     _nchw(image, 'image')
@@ -438,7 +449,10 @@ def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.
     if c != ps.cin:
         raise _lib.RpeError(f'stem_conv: image must have {ps.cin} channels')
     st_ = ps.stride
-    out = torch.empty(b, ps.cout, hh // st_, ww // st_, dtype=torch.float32, device=image.device)
+    if out is None:
+        out = torch.empty(b, ps.cout, hh // st_, ww // st_, dtype=torch.float32, device=image.device)
+    elif tuple(_nchw(out, 'out').shape) != (b, ps.cout, hh // st_, ww // st_):
+        raise _lib.RpeError('stem_conv: out has the wrong shape')
     st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 2, dtype=torch.float32, device=image.device) if stats else None
     check(lib().rpe_stem_conv(ptr(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), ptr(ps.packed), ps.cout, ptr(bias), ptr(scale),
                               int(bool(relu)), ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')

@@ -101,7 +101,11 @@ def _fusable(conv, x):
     s2 = conv.stride == (2, 2) and hh % 2 == 0 and ww % 2 == 0 and \
         ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
     stride = 2 if s2 else 1
-    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous()
+    # launches of fewer than ~one workgroup per CU (sequential tracking: layer3 of a 2-3 image batch) stay on the library:
+    # the encoder instantiations have no small-tile variant
+    wide = conv.out_channels % 128 != 0 and conv.out_channels % 128 <= 96
+    tiles = -(-(hh // stride) * (ww // stride) // (128 if (s2 or not wide) else 256)) * -(-conv.out_channels // (128 if (s2 or not wide) else 64))
+    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous() and tiles * x.shape[0] >= 256
 
 
 def conv_norm_act(conv, norm, x, relu, residual=None):
@@ -230,11 +234,24 @@ class BasicMotionEncoder(nn.Module):
         def cv(m, x):
             return F.conv2d(x, m.weight, None, m.stride, m.padding)
         if packed is not None:
-            cor = ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, packed['cor_buf'](corr))
-            ops.conv_fused(cor, packed['convc2'], ops.CONV_RELU, cat_buf[:, :192])
-            flo = ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0)   # 7x7 on 2 channels
-            ops.conv_fused(flo, packed['convf2'], ops.CONV_RELU, cat_buf[:, 192:])
-            ops.conv_fused(cat_buf, packed['conv'], ops.CONV_RELU, hx[:, 128:254], out2=rhx[:, 128:254])
+            key = (corr.data_ptr(), cat_buf.data_ptr(), hx.data_ptr(), rhx.data_ptr(), tuple(corr.shape))
+            calls = packed.get('_enc_calls')
+            if calls is None or calls[0] != key:                      # descriptors checked once per buffer set (the 12 iterations reuse it)
+                cor = packed['cor_buf'](corr)
+                flo = packed['flo_buf'](corr)
+                calls = (key, cor, flo,
+                         ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, cor, prepare=True),
+                         ops.conv_fused(cor, packed['convc2'], ops.CONV_RELU, cat_buf[:, :192], prepare=True),
+                         ops.conv_fused(flo, packed['convf2'], ops.CONV_RELU, cat_buf[:, 192:], prepare=True),
+                         ops.conv_fused(cat_buf, packed['conv'], ops.CONV_RELU, hx[:, 128:254], out2=rhx[:, 128:254], prepare=True))
+                packed['_enc_calls'] = calls
+            _, cor, flo_buf, c1, c2, f2, cv_ = calls
+            c1(); c2()
+            if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= 512:    # enough 32x8 patches to fill the chip
+                ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
+            else:
+                ops.bias_act(cv(self.convf1, flow), self.convf1.bias, out=flo_buf)
+            f2(); cv_()
         else:
             cor = ops.bias_act(cv(self.convc1, corr), self.convc1.bias)
             ops.bias_act(cv(self.convc2, cor), self.convc2.bias, out=cat_buf, out_offset=0)
@@ -307,6 +324,7 @@ class BasicUpdateBlock(nn.Module):
                 return scratch[k]
             P['cor_buf'] = lambda like: buf('cor', like, 256)
             P['fh_buf'] = lambda like: buf('fh', like, 256)
+            P['flo_buf'] = lambda like: buf('flo', like, 128)
             self._packed = (key, P)
         return self._packed[1]
 
@@ -321,10 +339,19 @@ class BasicUpdateBlock(nn.Module):
         if P is not None:
             # each GRU half = two implicit-GEMM convolutions whose epilogues are the gates:
             #   z = s(convz hx + ctx), r*h -> rhx ;  h <- (1-z) h + z tanh(convq rhx + ctx)   (in place on hx[:, :c])
-            for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
-                ops.conv_fused(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c)
-                ops.conv_fused(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf)
-            t = ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx))
+            key = (hx.data_ptr(), rhx.data_ptr(), z_buf.data_ptr(), tuple(ctx[k].data_ptr() for k in ('zr1', 'q1', 'zr2', 'q2')), tuple(hx.shape))
+            calls = P.get('_gru_calls')
+            if calls is None or calls[0] != key:
+                seq = []
+                for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
+                    seq.append(ops.conv_fused(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
+                                              prepare=True))
+                    seq.append(ops.conv_fused(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
+                seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+                P['_gru_calls'] = calls = (key, seq)
+            for launch in calls[1][:-1]:
+                launch()
+            t = calls[1][-1]()
             return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)  # coords1 + delta_flow
         W = self.gate_weights()
         # horizontal half: z = s(convz1 hx), r = s(convr1 hx), q = tanh(convq1 [r*h, x]), h = (1-z) h + z q
