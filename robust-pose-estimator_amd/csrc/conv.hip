@@ -384,34 +384,61 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     }
     float* red = &As[0][0][0];                                   // [WN][BM][2] partial statistics (LDS is free now:
                                                                  // nothing reads the tiles after the last barrier)
+    // Four channel rows x T column blocks per batch: the residual loads of a batch are issued back to back from clamped
+    // in-range addresses (per-element validity branches made the compiler emit load - wait - store per element), then
+    // the arithmetic, then stores under the lane mask.
+    const float* resb = P.res ? P.res + (size_t)bz * P.rbs : nullptr;
+    const float* addb = P.add ? P.add + (size_t)bz * P.abs_ : nullptr;
+    float* outb = P.out + (size_t)bz * P.obs;
+    float* out2b = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < T; ++i) {
+        const int row0 = wm * WT + i * 32 + 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = m0 + row;
-            const bool cok = co < P.cout;
-            const float sc = (P.scale && cok) ? P.scale[co] : 1.0f, bi = (P.bias && cok) ? P.bias[co] : 0.0f;
-            float ssum = 0.0f, ssq = 0.0f;
+        for (int rb = 0; rb < 16; rb += 4) {
+            size_t e[T][4]; bool ok[T][4]; float rv[T][4], av[T][4], sc[4], bi[4];
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                const int px = n0 + wn * WT + j * 32 + l31;
-                if (!cok || px >= hw) continue;
-                float v = acc[i][j][r];
-                if (P.scale) v *= sc;
-                if (P.add) v += P.add[(size_t)bz * P.abs_ + (size_t)co * hw + px];
-                v += bi;
-                ssum += v; ssq += v * v;
-                if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;
-                const size_t e = (size_t)co * hw + px;
-                if (P.res) { v = P.res[(size_t)bz * P.rbs + e] + v; v = v < 0.0f ? 0.0f : v; }
-                P.out[(size_t)bz * P.obs + e] = v;
-                if (P.out2) P.out2[(size_t)bz * P.o2bs + e] = v;
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + row0 + r + 8 * (rb >> 2);
+                const bool cok = co < P.cout;
+                sc[r] = P.scale ? P.scale[cok ? co : 0] : 1.0f;
+                bi[r] = P.bias ? P.bias[cok ? co : 0] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    const int px = n0 + wn * WT + j * 32 + l31;
+                    ok[j][r] = cok && px < hw;
+                    e[j][r] = ok[j][r] ? (size_t)co * hw + px : 0;
+                }
             }
-            if (P.stats) {                                       // sum over the 32 lanes that share this channel row
-                ssum = half_wave_sum(ssum); ssq = half_wave_sum(ssq);
-                if (l31 == 31) { red[(wn * BM + row) * 2] = ssum; red[(wn * BM + row) * 2 + 1] = ssq; }
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rv[j][r] = resb ? resb[e[j][r]] : 0.0f;
+                    av[j][r] = addb ? addb[e[j][r]] : 0.0f;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    float v = acc[i][j][rb + r];
+                    if (P.scale) v *= sc[r];
+                    v += av[j][r];
+                    v += bi[r];
+                    if (ok[j][r]) { ssum += v; ssq += v * v; }
+                    if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;
+                    if (resb) { v = rv[j][r] + v; v = v < 0.0f ? 0.0f : v; }
+                    if (ok[j][r]) { outb[e[j][r]] = v; if (out2b) out2b[e[j][r]] = v; }
+                }
+                if (P.stats) {                                   // sum over the 32 lanes that share this channel row
+                    ssum = half_wave_sum(ssum); ssq = half_wave_sum(ssq);
+                    const int row = row0 + r + 8 * (rb >> 2);
+                    if (l31 == 31) { red[(wn * BM + row) * 2] = ssum; red[(wn * BM + row) * 2 + 1] = ssq; }
+                }
             }
         }
+    }
     if (P.stats) {                                               // combine the WN waves that cover the same channels
         __syncthreads();
         if (tid < BM && m0 + tid < P.cout) {
