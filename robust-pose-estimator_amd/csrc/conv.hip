@@ -347,36 +347,50 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int mode = P.mode, cg = P.cgate;
     if (!ENC) {
+        const float* addb0 = P.add ? P.add + (size_t)bz * P.abs_ : nullptr;
+        const float* hb = P.h ? P.h + (size_t)bz * P.hbs : nullptr;
+        const float* zb = P.z ? P.z + (size_t)bz * P.zbs : nullptr;
+        float* outb0 = P.out + (size_t)bz * P.obs;
+        float* out2b0 = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
 #pragma unroll
         for (int i = 0; i < T; ++i)
 #pragma unroll
             for (int j = 0; j < T; ++j) {
                 const int nl = wn * WT + j * 32 + l31;               // column of the tile -> pixel
                 const int px = VERT ? (vy0 + nl / VTX) * W + vx0 + nl % VTX : n0 + nl;
-                if (VERT ? (vy0 + nl / VTX >= P.H || vx0 + nl % VTX >= W) : px >= hw) continue;
+                const bool pok = VERT ? (vy0 + nl / VTX < P.H && vx0 + nl % VTX < W) : px < hw;
+                const int co0 = m0 + wm * WT + i * 32 + 4 * lh;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + wm * WT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (co >= P.cout) continue;
-                    float v = acc[i][j][r];
-                    if (P.add) v += P.add[(size_t)bz * P.abs_ + (size_t)co * hw + px];
-                    if (P.bias) v += P.bias[co];
+                for (int rb = 0; rb < 16; rb += 4) {                 // four rows per batch: loads together, then arithmetic, then masked stores
+                    size_t e[4]; bool ok[4]; float av[4], bv[4], xv[4], yv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + r + 8 * (rb >> 2);
+                        ok[r] = pok && co < P.cout;
+                        e[r] = ok[r] ? (size_t)co * hw + px : 0;
+                        bv[r] = P.bias ? P.bias[ok[r] ? co : 0] : 0.0f;
+                        av[r] = addb0 ? addb0[e[r]] : 0.0f;
+                    }
+                    const bool rrows = co0 + 8 * (rb >> 2) >= cg;    // (GATE_ZR; uniform per batch when cg % 4 == 0)
                     if (mode == RPE_CONV_GATE_ZR) {
-                        const float sg = sigmoid_f(v);
-                        if (co < cg) P.out[(size_t)bz * P.obs + (size_t)co * hw + px] = sg;
-                        else {
-                            const size_t e = (size_t)(co - cg) * hw + px;
-                            P.out2[(size_t)bz * P.o2bs + e] = sg * P.h[(size_t)bz * P.hbs + e];
-                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xv[r] = hb[(rrows && ok[r]) ? e[r] - (size_t)cg * hw : 0];
                     } else if (mode == RPE_CONV_GATE_H) {
-                        const size_t e = (size_t)co * hw + px;
-                        const float zv = P.z[(size_t)bz * P.zbs + e], hv = P.h[(size_t)bz * P.hbs + e];
-                        P.out[(size_t)bz * P.obs + e] = (1.0f - zv) * hv + zv * tanhf(v);
-                    } else {
-                        if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;        // NaN stays NaN, like torch.relu
-                        const size_t e = (size_t)co * hw + px;
-                        P.out[(size_t)bz * P.obs + e] = v;
-                        if (P.out2) P.out2[(size_t)bz * P.o2bs + e] = v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { xv[r] = zb[e[r]]; yv[r] = hb[e[r]]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][rb + r] + av[r] + bv[r];
+                        if (mode == RPE_CONV_GATE_ZR) {
+                            const float sg = sigmoid_f(v);
+                            if (ok[r]) { if (rrows) out2b0[e[r] - (size_t)cg * hw] = sg * xv[r]; else outb0[e[r]] = sg; }
+                        } else if (mode == RPE_CONV_GATE_H) {
+                            if (ok[r]) outb0[e[r]] = (1.0f - xv[r]) * yv[r] + xv[r] * tanhf(v);
+                        } else {
+                            if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;    // NaN stays NaN, like torch.relu
+                            if (ok[r]) { outb0[e[r]] = v; if (out2b0) out2b0[e[r]] = v; }
+                        }
                     }
                 }
             }
