@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             for (int t = 0; t < KW; ++t, ++step) {
                 const int curA = step & 1;
                 const bool last = (g + 1 == G) && (t + 1 == KW);
-                if (!last) load_a();                              // weights first: their wait must not cover the
+                load_a();                                         // weights first: their wait must not cover the
                 if (t == 0) load_b(R);                            // input loads issued after them (in-order return)
                 read_h2(curA, curB, t - PW);
                 SCHED_FENCE();                                    // (keep the order written here: left alone, the
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
         read_h1(0, 0, 0);
         auto body = [&](int g, RB& Rload, const RB& Rstore) {   // Rload: free (its tile is in LDS); Rstore: group g+1
             const int cur = g & 1;
-            if (g + 1 < G) load_a();
+            load_a();
             load_b(Rload);
             read_h2(cur, cur, 0);
             SCHED_FENCE();
@@ -539,7 +539,9 @@ static inline int conv_cop(int cout) { return (cout + 127) / 128 * 128; }
 
 extern "C" size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw) {
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
-    return (size_t)((cin + CK - 1) / CK) * kh * kw * CK * conv_cop(cout);
+    // one zero step of padding: the kernel fetches the weights of step s+1 unconditionally (a load under a branch spoils
+    // the compiler's s_waitcnt placement on every path)
+    return ((size_t)((cin + CK - 1) / CK) * kh * kw + 1) * CK * conv_cop(cout);
 }
 
 extern "C" int rpe_conv_pack(const float* weight, int cout, int cin, int kh, int kw, float* packed, void* stream) {

@@ -73,7 +73,7 @@ def test_bad_arguments_return_status_without_a_gpu(rpe):
     # fused convolutions: descriptor validation and the layout of the ctypes mirror
     from rpe_amd import _lib
     assert ctypes.sizeof(_lib.ConvDesc) == 192
-    assert L.rpe_conv_packed_floats(256, 256, 1, 5) == 16 * 5 * 16 * 256 and L.rpe_conv_packed_floats(126, 324, 1, 1) == 21 * 16 * 128
+    assert L.rpe_conv_packed_floats(256, 256, 1, 5) == (16 * 5 + 1) * 16 * 256 and L.rpe_conv_packed_floats(126, 324, 1, 1) == (21 + 1) * 16 * 128
     assert L.rpe_conv_packed_floats(0, 4, 3, 3) == 0
     assert L.rpe_conv_fused(None, null) == -1 and L.rpe_conv_pack(null, 8, 8, 3, 3, one, null) == -1
     d = _lib.ConvDesc(x=16, packed=16, out=16, b=1, cin=16, cout=16, h=8, w=10, kh=3, kw=3, mode=0)
