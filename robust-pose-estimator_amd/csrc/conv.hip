@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 a0h1, a1h1, b0h1, b1h1, a0h2, a1h2, b0h2, b1h2;
     const bool hi_rows = T == 1 || m0 + wm * WT + 32 < P.cout;
-    const bool wave_rows = m0 + wm * WT < P.cout;                // false: this wave's 64 output rows lie beyond cout (cout = 192 on 128-row tiles)
+    // (update-block kernels) false: this wave's output rows lie beyond cout.  Scalar on purpose: as a per-lane condition it
+    // puts an exec-mask save/branch around every MFMA group of every step.
+    const bool wave_rows = ENC || __builtin_amdgcn_readfirstlane(m0 + wm * WT) < P.cout;                // false: this wave's 64 output rows lie beyond cout (cout = 192 on 128-row tiles)
     auto read_h1 = [&](int bufA, int bufB, int dx) {
         const float* arow = &As[bufA][wm * WT + l31][8 * lh];
         const float* brow = &Bs[bufB][VERT ? wn * WT + l31 + VTX * dx : S2 ? wn * WT + l31 + (dx == 0 ? 0 : dx < 0 ? BN : BN + 1) : 4 + wn * WT + l31 + dx][8 * lh];
