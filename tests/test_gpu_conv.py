@@ -282,3 +282,29 @@ def test_convf1_patch_kernel_matches_f64(rpe, h, w, b):
     ref = F.conv2d(flow.double(), wt.double(), bias.double(), padding=3).clamp_min(0)
     got = ops.stem_conv(flow.cuda(), ops.PackedStem(wt.cuda()), bias=bias.cuda(), relu=True, div=1.0, mul=1.0, sub=0.0)
     assert got.shape == ref.shape and (got.cpu().double() - ref).abs().max() < _tol(flow, wt)
+
+
+def test_random_shapes_against_library(rpe):
+    """Forty seeded random problems (channel counts that are no multiple of anything, maps that end inside tiles, every
+    supported kernel shape and stride, small and large launches) against the library's f32 convolution on the same GPU."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(20261002)
+    kinds = [(1, 1, 1), (3, 3, 1), (1, 5, 1), (5, 1, 1), (1, 3, 1), (7, 3, 1), (3, 3, 2), (1, 1, 2)]
+    for case in range(40):
+        kh, kw, stride = kinds[int(rng.integers(len(kinds)))]
+        cin, cout = int(rng.integers(1, 200)), int(rng.integers(1, 300))
+        h, w = int(rng.integers(2, 40)) * (2 if stride == 2 else 1), int(rng.integers(1, 24)) * 4
+        if stride == 2 and ((h // 2) * (w // 2)) % 4:
+            h += 2 if ((h // 2 + 1) * (w // 2)) % 4 == 0 else 0
+        b = int(rng.choice([1, 2, 5, 40]))
+        x = torch.from_numpy(rng.normal(size=(b, cin, h, w)).astype(np.float32)).cuda()
+        wt = torch.from_numpy((rng.normal(size=(cout, cin, kh, kw)) * 0.1).astype(np.float32)).cuda()
+        bias = torch.from_numpy(rng.normal(size=(cout,)).astype(np.float32)).cuda()
+        relu = bool(rng.integers(2))
+        ref = F.conv2d(x, wt, bias, stride=stride, padding=(kh // 2, kw // 2))
+        ref = ref.clamp_min(0) if relu else ref
+        out = torch.full_like(ref, float('nan'))
+        ops.conv_fused(x, ops.PackedConv(wt, bias), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, stride=stride)
+        tol = 1e-5 * np.sqrt(cin * kh * kw) * float(x.abs().max()) * float(wt.abs().max()) + 1e-5
+        err = float((out - ref).abs().max())
+        assert err < tol, (case, kh, kw, stride, cin, cout, h, w, b, err, tol)
