@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the per-frame stereo pose solve on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts N rank processes itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               (the driver's form: one rank per GPU over RCCL)
+    python bench.py --mode sequence [--gpus N]               (sharded tracker over a synthetic sequence, incl. the all-gather)
 
 A "step" = one pass of the whole hot path (``PoseNet.infer`` of the reference, core/pose/pose_net.py:60-85)
 over one batch of ``--batch`` synthetic 640x512 stereo frame pairs per GPU: batch-2B RAFT with 12 GRU
@@ -55,11 +56,14 @@ def lookup_algorithmic_bytes(pairs, h8, w8, levels=4, r=4):
     return pairs * (nq * levels * ((2 * r + 2) ** 2 + (2 * r + 1) ** 2) * 4 + nq * 8)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--mode', default='batch', choices=['batch', 'sequence'],
+                    help='batch: PoseNet.infer on --batch frame pairs per GPU per step (the headline metric); '
+                         'sequence: the sharded frame-to-frame tracker over a synthetic sequence, all-gather included')
     ap.add_argument('--batch', type=int, default=16, help='frame pairs per step per GPU (RAFT batch = 2x)')
     ap.add_argument('--height', type=int, default=512)
     ap.add_argument('--width', type=int, default=640)
@@ -67,20 +71,138 @@ def main():
     ap.add_argument('--solver', default='lbfgs', choices=['lbfgs', 'gn'])
     ap.add_argument('--solver-iters', type=int, default=8)
     ap.add_argument('--cpu-frames', type=int, default=8, help='frames timed on the CPU oracle (0 = skip)')
-    args = ap.parse_args()
+    ap.add_argument('--seq-frames', type=int, default=24, help='--mode sequence: frames per GPU (weak scaling)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the batch-1 latency / tracker / Gauss-Newton lines')
+    return ap.parse_args(argv)
 
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N rank processes (one per GPU, RCCL over xGMI) through
+    torch.distributed.run as a CHILD process and relay its exit code.  The parent never touches the GPU
+    (``device_count`` does not initialise HIP on this image), so nothing is exec'ed over an initialised runtime."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible', file=sys.stderr)
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL on ROCm
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU', file=sys.stderr)
+        sys.exit(2)
+    import torch.distributed as dist
+    distributed = world > 1 or args.mode == 'sequence'      # sequence mode runs its all-gather under RCCL even at N = 1
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    rccl_ranks = None
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            os.environ['MASTER_PORT'] = str(free_port())
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # backend "nccl" IS RCCL on ROCm
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                              # a real collective: every rank must have joined
+        rccl_ranks = int(ones.item())
 
     import rpe_amd  # noqa: F401  (raises if librpe_hip.so is missing: no fallback)
+    if args.mode == 'sequence':
+        res = run_sequence(args, rank, world, dev, dist)
+    else:
+        res = run_batch(args, rank, world, dev, dist if distributed else None)
+    if rank == 0:
+        res['rccl_ranks'] = rccl_ranks
+        print(json.dumps(res), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def timed_region(step, steps, warmup, dev, dist):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    out = None
+    for _ in range(warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def run_sequence(args, rank, world, dev, dist):
+    """BASELINE config 4: a stereo sequence sharded over the ranks in contiguous blocks with a one-frame halo
+    (rpe_amd.sharding, scripts/infer_trajectory.py:57,71-97 + core/pose/pose_estimator.py:81-91 of the reference),
+    every rank walking its block one frame at a time, ONE all-gather of the relative poses, then gate + prefix product.
+    A step = tracking the whole sequence once; value = frames/s over the whole job."""
+    from rpe_amd import pose_estimator, pose_net, sharding, synth
+    H, W, Fg = args.height, args.width, args.seq_frames
+    F = Fg * world
+    cfg = synth.model_config(H, W, iters=args.raft_iters, lbgfs_iters=20, solver=args.solver)   # infer_f2f.yaml:11
+    model = synth.init_synthetic_weights(pose_net.PoseNet(cfg), seed=1234).eval().to(dev)
+    slam = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=20, conf_weighing=True)
+    blocks = sharding.block_partition(F - 1, world)
+    s, e = blocks[rank]
+    cache = {}
+    for t in range(s, e + 1):                               # this rank's frames incl. the halo, resident in HBM
+        fr = synth.stereo_frames(seed=5000 + t, n=1, h=H, w=W)
+        cache[t] = (fr['image2l'].to(dev), fr['image2r'].to(dev), fr['mask2'].to(dev))
+    K = synth.intrinsics(H, W)
+    make = lambda: pose_estimator.PoseEstimator(slam, K, 7.2 * 250.0, model, (W, H)).to(dev)
+    get = lambda t: (cache[t][0], cache[t][1], cache[t][2].clone())
+    tracker = sharding.SequenceTracker(make, get)
+    import warnings
+
+    def step():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')                 # unrelated synthetic frames: many pairs fail the |log| gate
+            return tracker.track(F, rank, world)
+    elapsed, (poses, rel, ok) = timed_region(step, args.steps, args.warmup, dev, dist)
+    return {
+        'metric': 'sequence tracking frames/sec (640x512, frame-to-frame, L-BFGS 20), frames sharded over ranks + RCCL all-gather',
+        'value': F * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / max(1, args.steps), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference',
+        'data': 'synthetic (independent seeded stereo frames used as a sequence, seeded random-init weights)',
+        'config': {'workload': f'SequenceTracker.track, {F} frames of {W}x{H} ({Fg} per GPU, contiguous blocks + 1-frame halo), '
+                               f'batch 1 per frame, {args.raft_iters} GRU iters, {args.solver} x20 solve, one all-gather of (frames,8) f32',
+                   'frames': F, 'frames_per_gpu': Fg, 'parallelism': f'sequence blocks x{world}'},
+        'poses_finite': bool(torch.isfinite(poses).all()), 'pairs_accepted': int(ok.sum()), 'poses_shape': list(poses.shape),
+    }
+
+
+def run_batch(args, rank, world, dev, dist):
+    import rpe_amd
     from rpe_amd import pose_head, pose_net, synth  # noqa: F401
 
     H, W, B = args.height, args.width, args.batch
@@ -94,7 +216,6 @@ def main():
 
     # HIP-event timing of the correlation lookup inside the timed region (the kernel runs on torch's current stream)
     lookup_events = []
-    raft = model.flow
     real_lookup = rpe_amd.ops.CorrPyramid.lookup
     timing = {'on': False}
 
@@ -161,73 +282,133 @@ def main():
         gpu_in['mask2'].copy_(mask2_init)          # infer() mutates mask2 in place, as the reference does
         return model.infer(**gpu_in, ret_details=True)
 
-    def barrier():
-        if distributed:
-            dist.barrier()
+    def timed_step():
+        timing['on'] = True
+        try:
+            return step()
+        finally:
+            timing['on'] = False
 
-    out = step()                                   # set-up pass (untimed, not a warm-up step): MIOpen picks its
+    step()                                         # set-up pass (untimed, not a warm-up step): MIOpen picks its
     torch.cuda.synchronize()                       # conv algorithms on first use, like a compile step
     for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    timing['on'] = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timing['on'] = False
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        step()
+    elapsed, out = timed_region(timed_step, args.steps, 0, dev, dist)
 
-    if rank == 0:
-        pose, _, depth2, weights, time_flow, stereo_flow2 = out
-        info = model.pose_head.problem.last_info.cpu()
-        lk_ms = [a.elapsed_time(b) for a, b in lookup_events]
-        lk_avg_s = sum(lk_ms) / max(1, len(lk_ms)) / 1e3
-        alg = lookup_algorithmic_bytes(2 * B, H // 8, W // 8)
-        achieved = alg / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
-        traffic = None                              # HBM bytes per launch from separate rocprofv3 --pmc passes
-        try:                                        # (profiles/pmc_traffic.json), valid for the default workload only
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['k_corr_lookup']
-            if (B, H, W) == (16, 512, 640):
-                traffic = pmc['traffic_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
-        res = {
-            'metric': 'stereo-pair pose solves/sec (640x512, 8 solver iters)',
-            'value': world * B * args.steps / elapsed,
-            'unit': 'pose solves/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / max(1, args.steps),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference',
-            'data': 'synthetic (seeded rendered stereo pairs, seeded random-init weights)',
-            'config': {'workload': f'PoseNet.infer, {W}x{H} stereo frame pairs, {B} per GPU per step (RAFT batch {2 * B}), '
-                                   f'{args.raft_iters} GRU iters, {args.solver} x{args.solver_iters} SE(3) solve, weight heads on',
-                       'frames_per_gpu': B, 'height': H, 'width': W, 'raft_iters': args.raft_iters,
-                       'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
-            'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
-                         'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
-            'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
-            'roofline_conv': conv_roofline(conv_events, args.steps),
-            'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
-            'valid_fraction': float(gpu_in['mask2'].float().mean()),
-            'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
-        }
-        if args.cpu_frames > 0 and world == 1:        # CPU baseline on rank 0 at N = 1 only
-            res['cpu_baseline'] = cpu_baseline(cfg, model, frames, args.cpu_frames, pose)
-        print(json.dumps(res))
-    barrier()
-    if distributed:
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    pose, _, depth2, weights, time_flow, stereo_flow2 = out
+    info = model.pose_head.problem.last_info.cpu()
+    lk_ms = [a.elapsed_time(b) for a, b in lookup_events]
+    lk_avg_s = sum(lk_ms) / max(1, len(lk_ms)) / 1e3
+    alg = lookup_algorithmic_bytes(2 * B, H // 8, W // 8)
+    achieved = alg / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
+    traffic = None                              # HBM bytes per launch from separate rocprofv3 --pmc passes
+    try:                                        # (profiles/pmc_traffic.json), valid for the default workload only
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['k_corr_lookup']
+        if (B, H, W) == (16, 512, 640):
+            traffic = pmc['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
+    res = {
+        'metric': 'stereo-pair pose solves/sec (640x512, 8 solver iters)',
+        'value': world * B * args.steps / elapsed,
+        'unit': 'pose solves/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / max(1, args.steps),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference',
+        'data': 'synthetic (seeded rendered stereo pairs, seeded random-init weights)',
+        'config': {'workload': f'PoseNet.infer, {W}x{H} stereo frame pairs, {B} per GPU per step (RAFT batch {2 * B}), '
+                               f'{args.raft_iters} GRU iters, {args.solver} x{args.solver_iters} SE(3) solve, weight heads on',
+                   'frames_per_gpu': B, 'height': H, 'width': W, 'raft_iters': args.raft_iters,
+                   'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
+        'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
+                     'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
+        'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
+        'roofline_conv': conv_roofline(conv_events, args.steps),
+        'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
+        'valid_fraction': float(gpu_in['mask2'].float().mean()),
+        'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
+    }
+    if world == 1 and not args.no_extras:             # deployment numbers, measured after the timed region on rank 0
+        res.update(deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_events, timing))
+    if args.cpu_frames > 0 and world == 1:            # CPU baseline on rank 0 at N = 1 only
+        res['cpu_baseline'] = cpu_baseline(cfg, model, frames, args.cpu_frames, pose)
+    return res
+
+
+def deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_events, timing):
+    """What the reference really deploys is batch 1, one frame after the other (scripts/infer_trajectory.py:57,71-77):
+    ``latency_batch1_ms`` = median PoseNet.infer latency of ONE frame pair; ``tracker_fps`` = PoseEstimator over a
+    24-frame sequence (L-BFGS 20 as configuration/infer_f2f.yaml:11, streaming reuse of the previous frame's encoder
+    outputs); ``gn_ms_per_step`` / ``roofline_pose_solve_gn`` = the headline step with the Gauss-Newton solver mode."""
+    import warnings
+    from rpe_amd import pose_estimator, synth
+    H, W, B = args.height, args.width, args.batch
+    out = {}
+    one = {k: v[:1].contiguous() for k, v in gpu_in.items()}
+    m1 = mask2_init[:1].clone()
+    lat = []
+    for i in range(13):
+        one['mask2'].copy_(m1)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        model.infer(**one)
+        torch.cuda.synchronize()
+        if i >= 3:
+            lat.append(time.perf_counter() - t)
+    out['latency_batch1_ms'] = 1e3 * sorted(lat)[len(lat) // 2]
+    # sequential tracker
+    F = 24
+    seq = [(frames['image2l'][i % B:i % B + 1].to(dev), frames['image2r'][i % B:i % B + 1].to(dev), frames['mask2'][i % B:i % B + 1].to(dev))
+           for i in range(F)]
+    slam = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=20, conf_weighing=True, reuse_features=True)
+    keep = model.pose_head.problem.lbgfs_iters
+    model.pose_head.problem.lbgfs_iters = 20
+    try:
+        for rep in range(2):
+            est = pose_estimator.PoseEstimator(slam, frames['K'][0], 7.2 * 250.0, model, (W, H)).to(dev)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for l, r, m in seq:
+                    est(l, r, m.clone())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+    finally:
+        model.pose_head.problem.lbgfs_iters = keep
+    out['tracker_fps'] = F / dt
+    out['tracker_config'] = f'PoseEstimator, {F} frames one at a time, {W}x{H}, 12 GRU iters, L-BFGS 20, encoder outputs of frame t reused at t+1'
+    # Gauss-Newton mode of the same step
+    if args.solver != 'gn':
+        prob = model.pose_head.problem
+        prob.solver = 'gn'
+        try:
+            n0 = len(solve_events)
+
+            def gstep():
+                gpu_in['mask2'].copy_(mask2_init)
+                timing['on'] = True
+                try:
+                    return model.infer(**gpu_in)
+                finally:
+                    timing['on'] = False
+            gstep()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                gstep()
+            torch.cuda.synchronize()
+            out['gn_ms_per_step'] = 1e3 * (time.perf_counter() - t) / 3
+            r = pose_roofline(solve_events[n0 + 1:], B, H, W, args.solver_iters)
+            r['kernels'] = r['kernels'] + ' (Gauss-Newton: 21-entry Hessian per evaluation)'
+            out['roofline_pose_solve_gn'] = r
+        finally:
+            prob.solver = 'lbfgs'
+    return out
 
 
 def pose_roofline(events, frames, h, w, iters):

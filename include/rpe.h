@@ -208,9 +208,10 @@ int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int
  *   v = conv(x)[co][p] * scale[co] + add[co][p] + bias[co]           (scale, add, bias: each may be NULL)
  *   RPE_CONV_LINEAR : y = v;  RPE_CONV_RELU : y = max(v, 0);  then, if residual != NULL, y = max(residual + y, 0)
  *                     (the encoder's ResidualBlock tail, core/RAFT/core/extractor.py); out = y (and out2 = y when
- *                     out2 != NULL).  If stats != NULL the kernel also writes per-tile partial sums of v and v*v,
- *                     stats[b][cout][rpe_conv_stats_tiles(cout,h,w)][2], for rpe_instnorm_apply (instance norm in one
- *                     further read + write pass instead of three).
+ *                     out2 != NULL).  If stats != NULL the kernel also writes per-tile moments of v,
+ *                     stats[b][cout][rpe_conv_stats_tiles(cout,h,w,stride)][3] = (count, mean, sum of squared deviations
+ *                     from that mean; taken about a pivot so that |mean| >> std loses no digits), for rpe_instnorm_apply
+ *                     (instance norm in one further read + write pass instead of three).
  *   RPE_CONV_GATE_ZR: cout = 2*gate_channels; co <  gate_channels: out[co]  = sigmoid(v)                 (z)
  *                                             co >= gate_channels: out2[co-gate_channels] = sigmoid(v) * hidden[co-gate_channels]  (r*h)
  *   RPE_CONV_GATE_H : out[co] = (1 - zgate[co]) * hidden[co] + zgate[co] * tanh(v);  out may alias hidden.        */
@@ -241,10 +242,12 @@ size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
 /* weight (cout, cin, kh, kw) contiguous -> packed (tap-major 16-channel steps, output channels padded to 128) */
 int rpe_conv_pack(const float *weight, int cout, int cin, int kh, int kw, float *packed, void *stream);
 int rpe_conv_fused(const rpe_conv_desc *desc, void *stream);
-/* number of pixel tiles (= partial-sum slots per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input) */
+/* number of pixel tiles (= moment records per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input);
+ * the launcher and this function share one tile-width rule */
 int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
 /* Instance norm (torch.nn.InstanceNorm2d, affine=False; fnet of core/RAFT/core/extractor.py) of x (b,c,hw) given the
- * partial sums rpe_conv_fused left in `partials` (b,c,tiles,2):
+ * per-tile (count, mean, M2) records rpe_conv_fused / rpe_stem_conv left in `partials` (b,c,tiles,3), merged in f64 with
+ * the parallel-variance formula:
  *   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y,0); if (residual) y = max(residual + y, 0).  out may alias x. */
 int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                        const float *residual, float *out, void *stream);
@@ -258,7 +261,7 @@ int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw
  *                      applied while the input patch is staged (zero padding of the NORMALISED image, as the reference);
  *   cin = 2, stride 1: the motion encoder's convf1 on the flow (core/RAFT/core/update.py), div = mul = 1, sub = 0.
  * xn = mul * (x / div) - sub;  v = conv7x7(xn; pad 3) * scale[co] + bias[co] (scale NULL = 1: folded batch norm for cnet);
- * optional ReLU; stats (b,cout,rpe_stem_tiles(h,w,stride),2) receives per-tile partial sums of v, v*v for
+ * optional ReLU; stats (b,cout,rpe_stem_tiles(h,w,stride),3) receives per-tile (count, mean, M2) of v for
  * rpe_instnorm_apply (fnet).  cout % 64 == 0; stride 2 needs even h, w.  packed = rpe_stem_pack of the (cout,cin,7,7)
  * weight (rpe_stem_packed_floats floats). */
 int rpe_stem_tiles(int h, int w, int stride);

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             }
         return;
     }
-    float* red = &As[0][0][0];                                   // [WN][BM][2] partial statistics (LDS is free now:
+    float* red = &As[0][0][0];                                   // [WN][BM][3] partial statistics (sum d, sum d^2, pivot) (LDS is free now:
                                                                  // nothing reads the tiles after the last barrier)
     // Four channel rows x T column blocks per batch: the residual loads of a batch are issued back to back from clamped
     // in-range addresses (per-element validity branches made the compiler emit load - wait - store per element), then
@@ -435,14 +435,25 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float ssum = 0.0f, ssq = 0.0f;
+                float vv[T];
 #pragma unroll
                 for (int j = 0; j < T; ++j) {
                     float v = acc[i][j][rb + r];
                     if (P.scale) v *= sc[r];
                     v += av[j][r];
                     v += bi[r];
-                    if (ok[j][r]) { ssum += v; ssq += v * v; }
+                    vv[j] = v;
+                }
+                // Instance-norm statistics are taken about a PIVOT (this wave's first column of the channel row), not about
+                // zero: sum(v - p) and sum((v - p)^2) keep their digits when |mean| >> std (a large conv bias is pure shift;
+                // E[v^2] - mean^2 from f32 sums loses mean^2/var * 1e-7 of the variance).
+                const float piv = P.stats ? __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv[0]), 32)
+                                                                         : __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv[0]), 0)) : 0.0f;
+                float ssum = 0.0f, ssq = 0.0f;
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    float v = vv[j];
+                    if (ok[j][r]) { const float dv = v - piv; ssum += dv; ssq += dv * dv; }
                     if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;
                     if (resb) { v = rv[j][r] + v; v = v < 0.0f ? 0.0f : v; }
                     if (ok[j][r]) { outb[e[j][r]] = v; if (out2b) out2b[e[j][r]] = v; }
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
                 if (P.stats) {                                   // sum over the 32 lanes that share this channel row
                     ssum = half_wave_sum(ssum); ssq = half_wave_sum(ssq);
                     const int row = row0 + r + 8 * (rb >> 2);
-                    if (l31 == 31) { red[(wn * BM + row) * 2] = ssum; red[(wn * BM + row) * 2 + 1] = ssq; }
+                    if (l31 == 31) { red[(wn * BM + row) * 3] = ssum; red[(wn * BM + row) * 3 + 1] = ssq; red[(wn * BM + row) * 3 + 2] = piv; }
                 }
             }
         }
@@ -458,53 +469,65 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     if (P.stats) {                                               // combine the WN waves that cover the same channels
         __syncthreads();
         if (tid < BM && m0 + tid < P.cout) {
-            float a = 0.0f, q = 0.0f;
+            StatAcc A;
 #pragma unroll
-            for (int w2 = 0; w2 < WN; ++w2) { a += red[(w2 * BM + tid) * 2]; q += red[(w2 * BM + tid) * 2 + 1]; }
-            float* st = P.stats + (((size_t)bz * P.cout + m0 + tid) * gridDim.x + blockIdx.x) * 2;
-            st[0] = a; st[1] = q;
+            for (int w2 = 0; w2 < WN; ++w2) {
+                int nw = hw - (n0 + w2 * WT); nw = nw < 0 ? 0 : (nw > WT ? WT : nw);       // valid columns of wave w2
+                A.add_pivoted(nw, red[(w2 * BM + tid) * 3], red[(w2 * BM + tid) * 3 + 1], red[(w2 * BM + tid) * 3 + 2]);
+            }
+            float* st = P.stats + (((size_t)bz * P.cout + m0 + tid) * gridDim.x + blockIdx.x) * 3;
+            st[0] = (float)A.n; st[1] = (float)A.mean; st[2] = (float)A.m2;
         }
     }
 }
 
-// (mean, 1/sqrt(var + eps)) per (b, c) plane from the partial sums: what k_conv_igemm's loader-side normalisation reads.
-__global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restrict__ partials, int tiles, int hw, float eps, float* __restrict__ mi) {
-    const int plane = blockIdx.x;
-    double a = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < tiles; i += 64) { a += (double)partials[((size_t)plane * tiles + i) * 2]; q += (double)partials[((size_t)plane * tiles + i) * 2 + 1]; }
-    a = wave_sum(a); q = wave_sum(q);
-    if (threadIdx.x == 0) {
-        const double mean = a / hw;
-        double var = q / hw - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        mi[(size_t)plane * 2] = (float)mean; mi[(size_t)plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+// (mean, 1/sqrt(var + eps)) per (b, c) plane from the per-tile (n, mean, M2) records: what k_conv_igemm's loader-side
+// normalisation reads.  Tiles are combined in f64 with the parallel-variance formula, in a fixed order.
+__device__ __forceinline__ void plane_moments(const float* __restrict__ partials, int tiles, int plane, int nthreads, double* sh, double& mean, double& var) {
+    const float* pp = partials + (size_t)plane * tiles * 3;
+    double n = 0.0, a = 0.0;
+    for (int i = threadIdx.x; i < tiles; i += nthreads) { n += (double)pp[3 * i]; a += (double)pp[3 * i] * (double)pp[3 * i + 1]; }
+    n = wave_sum(n); a = wave_sum(a);
+    const int nw = nthreads >> 6, wv = threadIdx.x >> 6;
+    if (nw > 1) {
+        if ((threadIdx.x & 63) == 0) { sh[wv] = n; sh[4 + wv] = a; }
+        __syncthreads();
+        n = 0.0; a = 0.0;
+        for (int w = 0; w < nw; ++w) { n += sh[w]; a += sh[4 + w]; }
+        __syncthreads();
     }
+    mean = a / n;
+    double q = 0.0;
+    for (int i = threadIdx.x; i < tiles; i += nthreads) { const double d = (double)pp[3 * i + 1] - mean; q += (double)pp[3 * i + 2] + (double)pp[3 * i] * d * d; }
+    q = wave_sum(q);
+    if (nw > 1) {
+        if ((threadIdx.x & 63) == 0) sh[wv] = q;
+        __syncthreads();
+        q = 0.0;
+        for (int w = 0; w < nw; ++w) q += sh[w];
+    }
+    var = q / n;
+    var = var < 0.0 ? 0.0 : var;
 }
 
-// Instance norm from the per-tile partial sums k_conv_igemm left behind: one workgroup per (b, c) plane combines them
-// in f64 (mean, biased variance as E[x^2] - mean^2), then normalises in ONE read + write pass:
+__global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restrict__ partials, int tiles, int hw, float eps, float* __restrict__ mi) {
+    const int plane = blockIdx.x;
+    double mean, var;
+    plane_moments(partials, tiles, plane, 64, nullptr, mean, var);
+    if (threadIdx.x == 0) { mi[(size_t)plane * 2] = (float)mean; mi[(size_t)plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps)); }
+    (void)hw;
+}
+
+// Instance norm from the per-tile (n, mean, M2) records k_conv_igemm / k_stem7x7 left behind: one workgroup per (b, c)
+// plane combines them in f64 (biased variance), then normalises in ONE read + write pass:
 //   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y, 0); if (residual) y = max(residual + y, 0)
 __global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict__ x, const float* __restrict__ partials, int tiles, int hw,
                                                         float eps, int relu, const float* __restrict__ residual, float* __restrict__ out) {
     const int plane = blockIdx.x;
-    __shared__ double rs[4], rq[4];
-    __shared__ float s_mean, s_inv;
-    double a = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < tiles; i += blockDim.x) {
-        a += (double)partials[((size_t)plane * tiles + i) * 2]; q += (double)partials[((size_t)plane * tiles + i) * 2 + 1];
-    }
-    a = wave_sum(a); q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = a; rq[threadIdx.x >> 6] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double sa = rs[0] + rs[1] + rs[2] + rs[3], sq = rq[0] + rq[1] + rq[2] + rq[3];
-        const double mean = sa / hw;
-        double var = sq / hw - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        s_mean = (float)mean; s_inv = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-    const float mean = s_mean, inv = s_inv;
+    __shared__ double sh[8];
+    double dmean, dvar;
+    plane_moments(partials, tiles, plane, 256, sh, dmean, dvar);
+    const float mean = (float)dmean, inv = (float)(1.0 / sqrt(dvar + (double)eps));
     const float4* xp = (const float4*)(x + (size_t)plane * hw);
     const float4* rp = residual ? (const float4*)(residual + (size_t)plane * hw) : nullptr;
     float4* op = (float4*)(out + (size_t)plane * hw);
@@ -538,6 +561,9 @@ __global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp,
 }
 
 static inline int conv_cop(int cout) { return (cout + 127) / 128 * 128; }
+// Stride-1 launches use 64(co) x 256(px) tiles when cout is 64 / 96 / 192-like (cout % 128 in 1..96), else 128 x 128.
+// ONE definition: the launcher, rpe_conv_stats_tiles and the statistics consumers must agree on the pixel-tile width.
+static inline bool conv_wide(int cout) { return (cout % 128) != 0 && (cout % 128) <= 96; }
 
 extern "C" size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw) {
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
@@ -585,7 +611,7 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
         else hipLaunchKernelGGL((k_conv_igemm<1, 2, true, 2, false, true>), g2, dim3(256), 0, s, P);
         return rpe_check_launch();
     }
-    bool wide = (d->cout % 128) != 0 && (d->cout % 128) <= 96;   // 64-row tiles for cout 64 / 96 / 192; 126 runs on one 128-row tile
+    bool wide = conv_wide(d->cout);                  // 64-row tiles for cout 64 / 96 / 192; 126 runs on one 128-row tile
                                                      // (192 on 128-row tiles with two idle waves was measured: 1.47 vs 1.20 ms)
     int BM = wide ? 64 : 128, BN = wide ? 256 : 128;
     const bool half_tile = (d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3 && d->mode <= RPE_CONV_RELU;   // cout = 96
@@ -612,7 +638,7 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
 extern "C" int rpe_conv_stats_tiles(int cout, int h, int w, int stride) {
     if (cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2)) return 0;
     if (stride == 2) return ceil_div((int64_t)(h / 2) * (w / 2), 128);
-    return ceil_div((int64_t)h * w, (cout % 128) != 0 ? 256 : 128);
+    return ceil_div((int64_t)h * w, conv_wide(cout) ? 256 : 128);     // (a statistics launch is never a "small" 64x64 one)
 }
 
 extern "C" int rpe_instnorm_apply(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,

@@ -37,4 +37,21 @@ __device__ __forceinline__ float rn_div(float a, float b) {
     return a / b;
 }
 
+// Running (count, mean, M2 = sum of squared deviations) in f64 with the parallel-variance merge (Chan et al.): how the
+// convolution epilogues' per-wave / per-tile instance-norm statistics are combined without cancellation.
+struct StatAcc {
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    __device__ __forceinline__ void add(double nb, double mb, double m2b) {
+        if (nb <= 0.0) return;
+        const double nt = n + nb, d = mb - mean;
+        mean += d * nb / nt; m2 += m2b + d * d * n * nb / nt; n = nt;
+    }
+    // a block given as sums about a pivot p: s1 = sum(v - p), s2 = sum((v - p)^2) over nb values
+    __device__ __forceinline__ void add_pivoted(int nb, float s1, float s2, float p) {
+        if (nb <= 0) return;
+        const double m = (double)s1 / nb;
+        add((double)nb, (double)p + m, (double)s2 - (double)s1 * m);
+    }
+};
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

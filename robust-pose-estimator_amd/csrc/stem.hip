@@ -31,7 +31,7 @@ struct StemP {
     const float* wk;                            // [64][SKA]
     const float* bias; const float* scale;      // v = acc * scale[co] + bias[co]   (scale may be null)
     int relu, snp;                              // snp: patches per workgroup (weights are staged once for all of them)
-    float* out; float* stats;                   // (b,cout,Ho,Wo); [b][cout][tiles][2] or null
+    float* out; float* stats;                   // (b,cout,Ho,Wo); [b][cout][tiles][3] (n, mean, M2) or null
 };
 
 __device__ __forceinline__ float half_wave_sum_s(float v) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     __shared__ __attribute__((aligned(16))) float As[64][SKA];
     __shared__ float patch[CIN][PROWS][PSTR];
     __shared__ __attribute__((aligned(16))) int koff[SK];
-    __shared__ float red[4][64][2];
+    __shared__ float red[4][64][3];                          // per wave and channel: sum(v - p), sum((v - p)^2), pivot p
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int bz = blockIdx.z, cbase = blockIdx.y * 64;
     const int tiles_x = (P.Wo + SPX - 1) / SPX;
@@ -130,28 +130,38 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
         for (int r = 0; r < 16; ++r) {
             const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float sc = P.scale ? P.scale[cbase + co] : 1.0f, bi = P.bias ? P.bias[cbase + co] : 0.0f;
+            // statistics about a pivot (the wave's first output of this channel), see k_conv_igemm
+            const float v00 = acc[i][0][r] * sc + bi;
+            const float piv = P.stats ? __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, v00), 32)
+                                                                     : __builtin_amdgcn_readlane(__builtin_bit_cast(int, v00), 0)) : 0.0f;
             float ssum = 0.0f, ssq = 0.0f;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int y = y0 + 2 * wv + jj, x = x0 + l31;
                 if (y >= P.Ho || x >= P.Wo) continue;
                 float v = acc[i][jj][r] * sc + bi;
-                ssum += v; ssq += v * v;
+                const float dv = v - piv;
+                ssum += dv; ssq += dv * dv;
                 if (P.relu) v = v < 0.0f ? 0.0f : v;
                 ob[(size_t)co * hw + (size_t)y * P.Wo + x] = v;
             }
             if (P.stats) {
                 ssum = half_wave_sum_s(ssum); ssq = half_wave_sum_s(ssq);
-                if (l31 == 31) { red[wv][co][0] = ssum; red[wv][co][1] = ssq; }
+                if (l31 == 31) { red[wv][co][0] = ssum; red[wv][co][1] = ssq; red[wv][co][2] = piv; }
             }
         }
     if (P.stats) {
         __syncthreads();
         if (tid < 64) {
-            const float a = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
-            const float q = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
-            float* st = P.stats + (((size_t)bz * P.cout + cbase + tid) * ntiles + tile) * 2;
-            st[0] = a; st[1] = q;
+            StatAcc A;
+            int ncols = P.Wo - x0; ncols = ncols > SPX ? SPX : ncols;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                int nrows = P.Ho - (y0 + 2 * w2); nrows = nrows < 0 ? 0 : (nrows > 2 ? 2 : nrows);
+                A.add_pivoted(ncols * nrows, red[w2][tid][0], red[w2][tid][1], red[w2][tid][2]);
+            }
+            float* st = P.stats + (((size_t)bz * P.cout + cbase + tid) * ntiles + tile) * 3;
+            st[0] = (float)A.n; st[1] = (float)A.mean; st[2] = (float)A.m2;
         }
     }
     }

@@ -11,9 +11,18 @@ SOLVER_LBFGS, SOLVER_GN = 0, 1
 _DT = {torch.float32: 0, torch.float64: 1}
 
 
+def _on_current_device(t, name):
+    """Kernels are enqueued on the CURRENT device's stream: a tensor of another GPU would be written through a foreign
+    pointer.  One process drives one GPU here (torch.cuda.set_device(LOCAL_RANK)); anything else is refused."""
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.RpeError(f'{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()} '
+                            '(call torch.cuda.set_device first; multi-device use from one process is unsupported)')
+
+
 def _dev(t, dtype=None, name='tensor'):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.RpeError(f'{name}: expected a tensor on the GPU (the HIP path has no CPU fallback)')
+    _on_current_device(t, name)
     if dtype is not None and t.dtype != dtype:
         raise _lib.RpeError(f'{name}: expected dtype {dtype}, got {t.dtype}')
     return t if t.is_contiguous() else t.contiguous()
@@ -225,6 +234,7 @@ class CorrPyramid:
 def _nchw(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise _lib.RpeError(f'{name}: expected a contiguous float32 NCHW tensor on the GPU')
+    _on_current_device(t, name)
     return t
 
 
@@ -322,6 +332,7 @@ def _chan_slice(t, name):
     _, _, hh, ww = t.shape
     if t.stride(3) != 1 or t.stride(2) != ww or t.stride(1) != hh * ww:
         raise _lib.RpeError(f'{name}: expected a channel slice of a contiguous NCHW buffer')
+    _on_current_device(t, name)
     return ptr(t), t.stride(0)
 
 
@@ -345,7 +356,7 @@ class PackedConv:
 def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
                residual=None, stats=None, stride=1, pre_norm=None, prepare=False):
     """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.
-    ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the partial sums
+    ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the per-tile moments
     instnorm_apply needs.  ``prepare=True`` returns a zero-argument launcher instead of launching: the GRU loop runs the same
     nine convolutions on the same buffers twelve times, and at batch 1 the Python argument checking costs more than the kernels."""
     d = _lib.ConvDesc()
@@ -376,8 +387,8 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
         raise _lib.RpeError('conv_fused: out2 slice has too few channels')
     if stats is not None:
         tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride)
-        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 2)):
-            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},2) GPU tensor')
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 3)):
+            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},3) GPU tensor')
     d.stats = ptr(stats)
     if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
                                      and tuple(pre_norm.shape) == (b, cin, 2)):
@@ -401,8 +412,8 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
 
 
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
-    """Partial-sum buffer rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 2); hh, ww = input map."""
-    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 2, dtype=torch.float32, device=device)
+    """Per-tile (count, mean, M2) records rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 3); hh, ww = input map."""
+    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 3, dtype=torch.float32, device=device)
 
 
 def instnorm_finalize(stats, hw, eps=1e-5):
@@ -418,8 +429,8 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):
     _nchw(x, 'x')
     b, c, hh, ww = x.shape
     if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and tuple(stats.shape[:2]) == (b, c)
-            and stats.shape[3] == 2):
-        raise _lib.RpeError('instnorm_apply: stats must be the (b,c,tiles,2) buffer of conv_fused')
+            and stats.shape[3] == 3):
+        raise _lib.RpeError('instnorm_apply: stats must be the (b,c,tiles,3) buffer of conv_fused')
     if residual is not None and _nchw(residual, 'residual').shape != x.shape:
         raise _lib.RpeError('instnorm_apply: residual must have the shape of x')
     out = x if out is None else _nchw(out, 'out')
@@ -453,7 +464,7 @@ def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.
         out = torch.empty(b, ps.cout, hh // st_, ww // st_, dtype=torch.float32, device=image.device)
     elif tuple(_nchw(out, 'out').shape) != (b, ps.cout, hh // st_, ww // st_):
         raise _lib.RpeError('stem_conv: out has the wrong shape')
-    st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 2, dtype=torch.float32, device=image.device) if stats else None
+    st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 3, dtype=torch.float32, device=image.device) if stats else None
     check(lib().rpe_stem_conv(ptr(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), ptr(ps.packed), ps.cout, ptr(bias), ptr(scale),
                               int(bool(relu)), ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
     return (out, st) if stats else out

@@ -3,10 +3,14 @@
 core/pose/pose_net.py:21-22,47,65,129) and the upstream parameter names, so ``raft-things.pth`` /
 ``poseNet_*.pth`` state dicts load unchanged.
 
-What runs where (MI355X-first split):
-  * encoders and the update block's convolutions: dense contractions -> PyTorch-ROCm (MIOpen / MFMA)
-  * all-pairs correlation + pyramid, the per-iteration window lookup, the GRU gate arithmetic and the convex
-    up-sampling: hand-written HIP (csrc/corr.hip, csrc/raft_ops.hip) through the C ABI
+What runs where (MI355X-first split), all hand-written HIP through the C ABI:
+  * all-pairs correlation + pyramid and the per-iteration window lookup (csrc/corr.hip)
+  * every convolution of the update block with its bias / ReLU / concat / GRU-gate epilogue, the encoders' residual
+    blocks (3x3 stride 1 and 2, 1x1 stride-2 shortcut) with folded batch norm / instance-norm statistics, as f32-MFMA
+    implicit GEMMs (csrc/conv.hip); the 7x7 stems and convf1 (csrc/stem.hip)
+  * flow-head output layer, convex up-sampling, norm / bias passes (csrc/raft_ops.hip)
+  Left on PyTorch-ROCm (MIOpen): the encoders' final 1x1, the mask head (once per pass), and -- for map widths that
+  are not a multiple of 4 or launches too small to fill the chip -- the library route of the same layers.
 Exact re-associations used (results identical up to float rounding of the conv library):
   * convz/convr of each GRU half share their input, so their weights are stacked into one 256-channel conv
   * the GRU input is (h | inp | motion | flow) and the context `inp` is the same in all 12 iterations, so the
@@ -293,9 +297,16 @@ class BasicUpdateBlock(nn.Module):
             self._stacked = (key, W)
         return self._stacked[1]
 
-    def context_terms(self, inp):
-        """conv(inp; context channels) + bias of the four GRU convolutions: loop-invariant, computed once per pass."""
+    def context_terms(self, inp, out=None):
+        """conv(inp; context channels) + bias of the four GRU convolutions: loop-invariant, computed once per pass.
+        ``out`` = dict of persistent destination buffers (RAFT._workspace): the fused HIP convolution writes into them, so
+        the GRU loop's prepared launchers see the same addresses pass after pass."""
         W = self.gate_weights()
+        P = self.packed_convs(inp.shape[-1]) if out is not None else None
+        if P is not None:
+            for k in W:
+                ops.conv_fused(inp, P['ctx_' + k], ops.CONV_LINEAR, out[k])
+            return out
         pads = {'zr1': (0, 2), 'q1': (0, 2), 'zr2': (2, 0), 'q2': (2, 0)}
         return {k: F.conv2d(inp, W[k][1], W[k][2], padding=pads[k]) for k in W}
 
@@ -315,6 +326,7 @@ class BasicUpdateBlock(nn.Module):
             P['convf1'] = ops.PackedStem(e.convf1.weight)
             for n in ('zr1', 'q1', 'zr2', 'q2'):
                 P[n] = ops.PackedConv(W[n][0])                # bias is part of the context term (context_terms)
+                P['ctx_' + n] = ops.PackedConv(W[n][1], W[n][2])
             scratch = {}
 
             def buf(name, like, c):                            # per-shape scratch for intermediate activations
@@ -391,6 +403,7 @@ class RAFT(nn.Module):
         self.cnet = BasicEncoder(output_dim=256, norm_fn='batch', dropout=drop)
         self.update_block = BasicUpdateBlock(self.corr_levels, self.corr_radius, hidden_dim=128)
         self._pyr = None
+        self._ws = None
 
     def freeze_bn(self):
         for m in self.modules():
@@ -402,6 +415,25 @@ class RAFT(nn.Module):
         if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device:
             self._pyr = ops.CorrPyramid(b, h8, w8, self.corr_levels, self.corr_radius, device=device)
         return self._pyr
+
+    def _workspace(self, n, h8, w8, device):
+        """Activation buffers that live INSIDE a forward pass -- (h | motion | flow), (r*h | motion | flow), z, the motion
+        encoder's concat buffer, the lookup output and the four context terms -- allocated once per (batch, map, device):
+        the prepared launch descriptors of the GRU loop are keyed on these addresses, so they are built once and hit on
+        every later pass (and nothing from a previous pass stays pinned besides this one set).  Single-stream use, like
+        the rest of the module; tensors handed back to the caller (flows, hidden, context) are always fresh."""
+        key = (n, h8, w8, str(device))
+        if self._ws is None:
+            self._ws = {}
+        if key not in self._ws:
+            if len(self._ws) >= 2:                             # a tracker alternates between two shapes at most (batch n / 2n)
+                self._ws.pop(next(iter(self._ws)))
+            c = self.hidden_dim
+            e = lambda ch: torch.empty(n, ch, h8, w8, device=device)
+            self._ws[key] = dict(hx=e(2 * c), rhx=e(2 * c), z=e(c), cat=e(2 * c),
+                                 corr=e(self.corr_levels * (2 * self.corr_radius + 1) ** 2),
+                                 ctx=dict(zr1=e(2 * c), q1=e(c), zr2=e(2 * c), q2=e(c)))
+        return self._ws[key]
 
     @torch.no_grad()
     def encode_features(self, images):
@@ -431,17 +463,14 @@ class RAFT(nn.Module):
         if cnet is None:
             cnet = self.encode_context(image1)
         c = self.hidden_dim
-        hx = torch.empty(N, 2 * c, h8, w8, device=dev)        # (h | motion | flow); the context lives in ctx
-        rhx = torch.empty_like(hx)
-        z_buf = torch.empty(N, c, h8, w8, device=dev)
-        h_buf = torch.empty(N, c, h8, w8, device=dev)
-        cat_buf = torch.empty(N, 2 * c, h8, w8, device=dev)
+        ws = self._workspace(N, h8, w8, dev)
+        hx, rhx, z_buf, cat_buf, corr = ws['hx'], ws['rhx'], ws['z'], ws['cat'], ws['corr']   # hx = (h | motion | flow)
+        h_buf = torch.empty(N, c, h8, w8, device=dev)         # returned to the caller: fresh
         torch.tanh(cnet[:, :c], out=hx[:, :c])
         inp = torch.relu(cnet[:, c:])
-        ctx = self.update_block.context_terms(inp)
+        ctx = self.update_block.context_terms(inp, out=ws['ctx'])
         coords0 = coords_grid(N, h8, w8, dev)
         coords1 = coords0.clone()
-        corr = torch.empty(N, self.corr_levels * (2 * self.corr_radius + 1) ** 2, h8, w8, device=dev)
         flow_predictions = []
         for itr in range(iters):
             pyr.lookup(coords1, out=corr)

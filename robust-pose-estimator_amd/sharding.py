@@ -29,9 +29,9 @@ def block_partition(n_items, world):
 def gather_relative_poses(rel_local, ok_local, sizes, group=None):
     """all_gather of variable-length blocks: pad to the longest block, gather, strip the padding.
     rel_local (m_r,7) float32, ok_local (m_r,) bool.  Returns (rel (sum m,7), ok (sum m,)) on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():                      # no process group at all: a plain serial run
         return rel_local, ok_local
+    world = dist.get_world_size(group)                 # world 1 still goes through the collective (RCCL path under test)
     mmax = max(sizes)
     dev = rel_local.device
     pad = torch.zeros(mmax, 8, dtype=torch.float32, device=dev)
@@ -54,14 +54,18 @@ def failure_gate(rel, log, thr=1.0e-1):
     return torch.where(bad[..., None], ident, rel), ~bad
 
 
-def track_sharded(n_frames, run_block, chain_fn, rank=0, world=1, group=None, scale=250.0):
+def track_sharded(n_frames, run_block, chain_fn, rank=0, world=1, group=None, scale=None):
     """Sharded tracking of frames 0..n_frames-1.
 
     run_block(first_pair, last_pair) -> (rel (m,7) f32, ok (m,) bool) computes the GATED relative poses of
     pairs first_pair..last_pair-1, pair t being (frame t, frame t+1); it is responsible for the halo frame.
     chain_fn(rel (M,7), scale) -> (M,7) absolute poses: the prefix product P_k = P_{k-1} * inv(scale(rel_k)).
+    ``scale`` = the depth-clipping distance the relative poses were normalised by (1 / PoseEstimator.scale,
+    pose_estimator.py:40-43,90); required -- a default would silently disagree with a config's depth_clipping.
     Returns absolute poses (n_frames,7): identity for frame 0 followed by the chained poses.
     """
+    if scale is None:
+        raise ValueError('track_sharded: scale (the depth_clipping distance) is required')
     blocks = block_partition(max(n_frames - 1, 0), world)
     s, e = blocks[rank]
     rel_local, ok_local = run_block(s, e)
@@ -102,6 +106,12 @@ class SequenceTracker:
             oks.append(torch.tensor([est.success], device=rels[-1].device))
         return torch.cat(rels), torch.cat(oks)
 
-    def track(self, n_frames, rank=0, world=1, group=None, scale=250.0):
+    def track(self, n_frames, rank=0, world=1, group=None, scale=None):
+        """``scale`` defaults to the depth-clipping distance of the estimators this tracker builds."""
         from . import ops
+        est_scale = float(1.0 / self.make_estimator().scale)
+        if scale is None:
+            scale = est_scale
+        elif abs(scale - est_scale) > 1e-6 * est_scale:
+            raise ValueError(f'SequenceTracker.track: scale {scale} != the estimator\'s depth_clipping {est_scale}')
         return track_sharded(n_frames, self.run_block, lambda rel, s: ops.se3_chain(rel, scale=s), rank, world, group, scale)

@@ -1,6 +1,7 @@
 // Stand-alone consumer of the C ABI (no Python, no torch): build with
 //   hipcc --offload-arch=gfx950 -I include tests/abi/abi_smoke.cpp -L robust-pose-estimator_amd -lrpe_hip -o abi_smoke
-// Runs rpe_se3_exp/log round trips and a tiny pose solve with a known answer, prints "ABI_SMOKE_OK".
+// Runs rpe_se3_exp/log round trips, a tiny pose solve with a known answer, a correlation pyramid build + lookup and one
+// fused convolution checked against host loops, prints "ABI_SMOKE_OK".
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -60,6 +61,67 @@ int main() {
     // --- bad arguments are rejected with a status, not a crash
     if (rpe_pose_solve(nullptr, d_p1, d_p2, d_w, d_w, d_m, d_m, d_K, d_lw, 1, h, w, 0, 8, d_Tout, nullptr, nullptr, nullptr, d_ws, st) != RPE_E_BADARG) return 7;
     if (rpe_corr_lookup(d_ws, d_flow, 1, 8, 8, 4, 3, d_p1, st) != RPE_E_BADARG) return 8;       // radius 3 unsupported
+    // --- correlation pyramid: build + lookup at integer coordinates.  Level-0 window tap (i, j) of query q is then
+    //     <fmap1[:, q], fmap2[:, q + (i-4, j-4)]> / sqrt(C) (zero outside the map); channel index = i*9 + j with i the x offset
+    {
+        const int b = 1, C = 32, h8 = 16, w8 = 24, nq = h8 * w8, L = 4;
+        std::vector<float> f1((size_t)C * nq), f2((size_t)C * nq), co(2 * nq), out((size_t)L * 81 * nq);
+        for (size_t i = 0; i < f1.size(); ++i) { f1[i] = std::sin(0.013f * i + 0.5f); f2[i] = std::cos(0.007f * i); }
+        for (int q = 0; q < nq; ++q) { co[q] = (float)(q % w8); co[nq + q] = (float)(q / w8); }
+        float *d_f1, *d_f2, *d_co, *d_out; void* d_pyr;
+        const size_t pb = rpe_corr_pyramid_bytes(b, h8, w8, L);
+        if (pb == 0) return 9;
+        CK(hipMalloc(&d_f1, f1.size() * 4)); CK(hipMalloc(&d_f2, f2.size() * 4)); CK(hipMalloc(&d_co, co.size() * 4));
+        CK(hipMalloc(&d_out, out.size() * 4)); CK(hipMalloc(&d_pyr, pb));
+        CK(hipMemcpy(d_f1, f1.data(), f1.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_f2, f2.data(), f2.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_co, co.data(), co.size() * 4, hipMemcpyHostToDevice));
+        if (rpe_corr_build(d_f1, d_f2, b, C, h8, w8, L, d_pyr, st) != RPE_OK) return 10;
+        if (rpe_corr_lookup(d_pyr, d_co, b, h8, w8, L, 4, d_out, st) != RPE_OK) return 11;
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+        double cerr = 0;
+        for (int q = 0; q < nq; q += 7) for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) {
+            const int x = q % w8 + i - 4, y = q / w8 + j - 4;
+            double ref = 0;
+            if (x >= 0 && x < w8 && y >= 0 && y < h8) { for (int c = 0; c < C; ++c) ref += (double)f1[(size_t)c * nq + q] * f2[(size_t)c * nq + y * w8 + x]; ref /= std::sqrt((double)C); }
+            cerr = std::fmax(cerr, std::fabs(out[(size_t)(i * 9 + j) * nq + q] - ref));
+        }
+        std::printf("corr build+lookup max err %.3e\n", cerr);
+        if (!(cerr < 2e-5)) return 12;
+    }
+    // --- one fused convolution: 3x3, 16 -> 16 channels, bias + ReLU, against host loops
+    {
+        const int cin = 16, cout = 16, hh = 8, ww = 12, hw2 = hh * ww;
+        std::vector<float> x((size_t)cin * hw2), wt((size_t)cout * cin * 9), bias(cout), y((size_t)cout * hw2);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = std::sin(0.11f * i);
+        for (size_t i = 0; i < wt.size(); ++i) wt[i] = 0.1f * std::cos(0.23f * i + 0.1f);
+        for (int c = 0; c < cout; ++c) bias[c] = 0.05f * c - 0.3f;
+        float *d_x, *d_wt, *d_b, *d_y, *d_pk;
+        const size_t pf = rpe_conv_packed_floats(cout, cin, 3, 3);
+        CK(hipMalloc(&d_x, x.size() * 4)); CK(hipMalloc(&d_wt, wt.size() * 4)); CK(hipMalloc(&d_b, cout * 4)); CK(hipMalloc(&d_y, y.size() * 4));
+        CK(hipMalloc(&d_pk, pf * 4));
+        CK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_b, bias.data(), cout * 4, hipMemcpyHostToDevice));
+        if (rpe_conv_pack(d_wt, cout, cin, 3, 3, d_pk, st) != RPE_OK) return 13;
+        rpe_conv_desc d = {};
+        d.x = d_x; d.x_batch_stride = (long long)cin * hw2; d.packed = d_pk; d.bias = d_b; d.out = d_y; d.out_batch_stride = (long long)cout * hw2;
+        d.b = 1; d.cin = cin; d.cout = cout; d.h = hh; d.w = ww; d.kh = 3; d.kw = 3; d.mode = RPE_CONV_RELU; d.stride = 1;
+        if (rpe_conv_fused(&d, st) != RPE_OK) return 14;
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(y.data(), d_y, y.size() * 4, hipMemcpyDeviceToHost));
+        double verr = 0;
+        for (int co2 = 0; co2 < cout; ++co2) for (int yy = 0; yy < hh; ++yy) for (int xx = 0; xx < ww; ++xx) {
+            double a = bias[co2];
+            for (int ci = 0; ci < cin; ++ci) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+                const int y2 = yy + dy, x2 = xx + dx;
+                if (y2 < 0 || y2 >= hh || x2 < 0 || x2 >= ww) continue;
+                a += (double)wt[((size_t)(co2 * cin + ci) * 3 + dy + 1) * 3 + dx + 1] * x[(size_t)ci * hw2 + y2 * ww + x2];
+            }
+            verr = std::fmax(verr, std::fabs(y[(size_t)co2 * hw2 + yy * ww + xx] - (a > 0 ? a : 0)));
+        }
+        std::printf("conv_fused max err %.3e\n", verr);
+        if (!(verr < 1e-5)) return 15;
+    }
     std::printf("ABI_SMOKE_OK\n");
     return 0;
 }

@@ -133,7 +133,9 @@ def test_encoder_block_epilogues_match_f64(rpe, c, h, w, b):
     stats = ops.conv_stats_buffer(b, c, h, w, 'cuda')
     raw = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), stats=stats)
     assert (raw.cpu().double() - pre).abs().max() < _tol(x, wt)
-    ssum = stats[..., 0].sum(-1).cpu().double() / (h * w)
+    st = stats.cpu().double()                                              # per-tile (count, mean, M2)
+    assert float(st[..., 0].sum(-1).min()) == float(st[..., 0].sum(-1).max()) == h * w
+    ssum = (st[..., 0] * st[..., 1]).sum(-1) / (h * w)
     assert (ssum - mean[:, :, 0, 0]).abs().max() < 1e-5
     got2 = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True, residual=res.cuda())
     inv = float((1 / torch.sqrt(var + 1e-5)).max())
@@ -308,3 +310,52 @@ def test_random_shapes_against_library(rpe):
         tol = 1e-5 * np.sqrt(cin * kh * kw) * float(x.abs().max()) * float(wt.abs().max()) + 1e-5
         err = float((out - ref).abs().max())
         assert err < tol, (case, kh, kw, stride, cin, cout, h, w, b, err, tol)
+
+
+@pytest.mark.parametrize('cout,bias_val', [(64, 50.0), (64, -50.0), (96, 50.0), (128, -50.0), (112, 50.0)])
+def test_instance_norm_statistics_survive_large_means(rpe, cout, bias_val):
+    """Planes whose |mean| >> std (a conv bias of +-50, or a constant-plus-noise plane): E[x^2] - mean^2 from f32 sums
+    would lose mean^2/var * 1e-7 of the variance; the epilogue's pivoted moments must not.  Bar: 2e-5 relative after
+    normalisation.  cout = 112 also covers the tile-count rule for cout % 128 in 97..127 (128-pixel tiles with statistics)."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cout)
+    b, cin, h, w = 2, 64, 48, 64
+    x = _rand(rng, b, cin, h, w)
+    wt = _rand(rng, cout, cin, 3, 3, s=0.05)
+    wt[1] *= 1e-3                                                            # channel 1: a constant-plus-noise plane (std ~ 1e-3 around 50)
+    bias = torch.full((cout,), bias_val)
+    pc = ops.PackedConv(wt.cuda(), bias.cuda())
+    pre = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    eps = 1e-5
+    stats = ops.conv_stats_buffer(b, cout, h, w, 'cuda')
+    assert stats.shape[2] == -(-h * w // (256 if (cout % 128 != 0 and cout % 128 <= 96) else 128))
+    guard = torch.full((4096,), 7.0, device='cuda')                          # allocated right behind: an overrun would be caught below
+    raw = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'), stats=stats)
+    assert bool((guard == 7.0).all())
+    mi = ops.instnorm_finalize(stats, h * w, eps=eps).cpu().double()
+    inv_ref = 1.0 / torch.sqrt(var[:, :, 0, 0] + eps)
+    assert float(((mi[..., 0] - mean[:, :, 0, 0]).abs() / mean[:, :, 0, 0].abs()).max()) < 1e-6
+    assert float(((mi[..., 1] - inv_ref).abs() / inv_ref).max()) < 2e-5
+    # normalised output vs the f64 normalisation of the kernel's own raw tensor (f32 rounding of the raw values at |x| ~ 50
+    # is the reference's too: ulp(50)/std; it is excluded by normalising `raw` itself)
+    got = ops.instnorm_apply(raw.clone(), stats, eps=eps, relu=False).cpu().double()
+    want = (raw.cpu().double() - mean) / torch.sqrt(var + eps)
+    scale = want.abs().amax((2, 3), keepdim=True)
+    assert float(((got - want).abs() / scale).max()) < 2e-5
+
+
+def test_stem_statistics_survive_large_means(rpe):
+    from rpe_amd import ops
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy(rng.uniform(0, 255, size=(2, 3, 64, 96)).astype(np.float32))
+    wt = _rand(rng, 64, 3, 7, 7, s=0.05)
+    bias = torch.full((64,), 50.0)
+    ps = ops.PackedStem(wt.cuda())
+    raw, stats = ops.stem_conv(img.cuda(), ps, bias=bias.cuda(), relu=False, stats=True)
+    pre = F.conv2d(2 * (img.double() / 255) - 1, wt.double(), bias.double(), stride=2, padding=3)
+    mean, var = pre.mean((2, 3)), pre.var((2, 3), unbiased=False)
+    mi = ops.instnorm_finalize(stats, 32 * 48, eps=1e-5).cpu().double()
+    inv_ref = 1.0 / torch.sqrt(var + 1e-5)
+    assert float(((mi[..., 0] - mean).abs() / mean.abs()).max()) < 1e-6
+    assert float(((mi[..., 1] - inv_ref).abs() / inv_ref).max()) < 2e-5

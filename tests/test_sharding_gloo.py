@@ -51,7 +51,7 @@ def _worker(rank, world, port, n_frames, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import rpe_amd.sharding as sh
-    poses, rel, ok = sh.track_sharded(n_frames, _run_block, _chain, rank, world)
+    poses, rel, ok = sh.track_sharded(n_frames, _run_block, _chain, rank, world, scale=250.0)
     out[rank] = (poses, rel, ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -64,7 +64,7 @@ def test_two_ranks_reproduce_serial_trajectory(n_frames):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_frames, out), nprocs=world, join=True)
-    serial, rel_s, ok_s = sh.track_sharded(n_frames, _run_block, _chain, 0, 1)
+    serial, rel_s, ok_s = sh.track_sharded(n_frames, _run_block, _chain, 0, 1, scale=250.0)
     for r in range(world):
         poses, rel, ok = out[r]
         assert poses.shape == (n_frames, 7)
@@ -83,3 +83,49 @@ def test_block_partition():
         for w in (1, 2, 8):
             b = sh.block_partition(n, w)
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def _worker_single(rank, port, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    import rpe_amd.sharding as sh
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    poses, rel, ok = sh.track_sharded(6, _run_block, _chain, 0, 1, scale=250.0)
+    out['calls'] = len(calls)
+    out['poses'] = poses
+    dist.destroy_process_group()
+
+
+def test_world_size_one_group_still_runs_the_collective():
+    """With a process group of ONE rank the padded all-gather is executed (no world==1 shortcut): this is the path
+    `bench.py --mode sequence --gpus 1` and the nccl GPU test exercise under RCCL."""
+    import rpe_amd.sharding as sh
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_single, args=(_free_port(), out), nprocs=1, join=True)
+    assert out['calls'] == 1
+    serial, _, _ = sh.track_sharded(6, _run_block, _chain, 0, 1, scale=250.0)      # no process group: plain serial
+    assert torch.equal(out['poses'], serial)
+
+
+def test_scale_is_required():
+    import rpe_amd.sharding as sh
+    with pytest.raises(ValueError):
+        sh.track_sharded(3, _run_block, _chain, 0, 1)
+
+
+def test_bench_refuses_mismatched_world_size():
+    """bench.py --gpus N must never silently run one process: with WORLD_SIZE set by a launcher it has to agree with
+    --gpus, and without a launcher it starts the ranks itself (here: no GPU -> it must say so and exit non-zero)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and 'WORLD_SIZE=1' in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64'], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and 'GPU(s) are visible' in r.stderr
