@@ -3,219 +3,252 @@
 // Replaces CorrBlock of the reference's RAFT submodule (core/RAFT/core/corr.py: corr(), __init__ pyramid,
 // __call__ lookup; call sites core/pose/pose_net.py:47,65,129).
 //
-// Pyramid layout (private to this file).  For batch item b, query q1 (row-major over the h8 x w8 grid) and
-// level l the (h_l x w_l) correlation map is stored as 4x4 micro-tiles of f32 (64 B, two neighbours in x share
-// a 128-B line), micro-tiles row-major, zero-padded to whole tiles:
-//     off(y, x) = ((y>>2) * TXC_l + (x>>2)) * 16 + (y&3) * 4 + (x&3),   TXC_l = ceil(w_l/4), S_l = TXC_l*TYC_l*16
-//     level l region = [b][q1][S_l] f32, regions of the levels concatenated.
-// Why: the lookup reads a 10x10..11x11 window per (query, level).  Row-major maps make that 10 runs of 40 B,
-// each touching 1.3-1.6 lines; with micro-tiles every row piece is one aligned 16-B load and a window touches
-// ~(13/4)^2 = 10.6 sectors of 64 B instead of ~15.6 -- the kernel is bound by HBM sectors, not instructions.
-// Because padded entries are zero, zero padding of out-of-map taps needs checks at tile granularity only.
+// Pyramid layout (private to this file): GROUP-INTERLEAVED, SKEWED ROWS.
+//   A *group* = 8 queries that are neighbours in x: g = (q.y, q.x >> 3), k = q.x & 7.  For batch item b, group g
+//   and level l the eight (h_l x w_l) correlation maps of the group are stored together, query index fastest:
+//       slot(y, x', k),  x' = x + sk_l - (k >> l),  sk_l = 7 >> l          ("skew": query k's map is shifted left
+//       addr = base_l + ((b*ngroups + g) * h_l + y) * wp_l*8 + x'*8 + k      by the distance its window centre moves)
+//   with wp_l = (w_l + sk_l) rounded up to 4; slots whose x falls outside [0, w_l) hold zeros (they ARE the zero
+//   padding of grid_sample).  One 128-B line = 4 x' x 8 queries of one map row.
+// Why: a query reads a 10x10 (11x11) window of ITS OWN map per level, so nothing is shared between queries -- unless
+// the maps of neighbouring queries are interleaved.  Neighbouring queries have neighbouring window centres
+// (centre = q + flow, and flow is smooth), so after the skew the 8 windows of a group coincide: the group needs
+// ~10 rows x (10 + 3)/4 lines and every fetched line is used by all 8 queries.  Per query and level that is ~4 lines
+// instead of ~7 with per-query 8x4-pixel lines (and ~15 row-major): the lookup is bound by HBM lines.  Rows are whole
+// lines, so a loader pass over any subset of rows requests every line exactly once.  Flow that is NOT smooth inside a
+// group costs bandwidth, never correctness: a window that leaves the group's 12 x 16 staging box takes a per-tap
+// path straight from global memory.
 //
 // Kernels:
-//   k_permute_fmap2 : fmap2 (b,C,h8,w8) -> B' (b,C,S_0) in micro-tile order (zero padded columns)
-//   k_corr_gemm     : C[q1][n'] = sum_c fmap1[c][q1] * B'[c][n'] / sqrt(C)   f32 MFMA 32x32x2 (exact f32
-//                     fmaf chain), 128x128 block tile, 4 waves, LDS double buffer.  The GEMM output IS level 0.
-//   k_corr_pool     : levels 1..3 by successive 2x2 average pooling (same order of operations as
-//                     F.avg_pool2d: ((a+b)+c)+d then /4), one workgroup per query map, staged through LDS.
-//   k_corr_lookup   : wave = 64 consecutive queries x one level (coalesced stores of each of the 81 channels);
-//                     lane = one query: streams 11 footprint rows with 4 aligned 16-B loads each, aligns them
-//                     in registers, and emits the 81 bilinear taps.  Tap positions follow grid_sample's float32
-//                     arithmetic per tap (sampling.h), so the integer taps are the reference's.
+//   k_permute_fmap  : fmap (b,C,h8,w8) -> (b,C,N') in GEMM tile order, zero padded: fmap1 in group order (padded to
+//                     128 queries), fmap2 in 8x16-pixel patch order
+//   k_corr_build    : C[q][p] = sum_c fmap1[c][q] * fmap2[c][p] / sqrt(C), f32 MFMA 32x32x2 (exact f32 fmaf chain),
+//                     128 queries x 128 pixels (one 8x16 patch) per tile, 4 waves, LDS double buffer; a workgroup walks the
+//                     patches of one 8-row band, and the epilogue pools each tile to levels 1-3 (2x2 means in
+//                     F.avg_pool2d's order of operations; an 8x16 patch holds whole 8x8 blocks) and scatters all four
+//                     levels into the skewed layout -- no separate pooling pass, level 0 is never re-read
+//   k_corr_lookup   : wave = 8 groups x one level.  Loader role: 16-B pieces, 8 lanes per 128-B line, each needed line
+//                     requested once, staged in wave-private LDS (no workgroup barrier).  Consumer role: lane = query,
+//                     4-B LDS reads at its own column offset, 9 horizontal taps per row, 81 outputs with coalesced stores.
+//                     Tap positions follow grid_sample's float32 arithmetic per tap (sampling.h): integer taps are the
+//                     reference's bit for bit.
 #include "rpe_common.h"
 #include "sampling.h"
 
 #define MAX_LEVELS 4
 #define RADIUS 4
 #define WIN 9            // 2r+1
+#define GQ 8             // queries per group
 
 struct PyrGeom {
     int b, h8, w8, levels;
-    int h[MAX_LEVELS], w[MAX_LEVELS], txc[MAX_LEVELS], tyc[MAX_LEVELS];
-    long long S[MAX_LEVELS];        // floats per query map
-    long long base[MAX_LEVELS];     // float offset of the level region
-    long long total;                // floats
+    int gx, ngroups;                 // groups per query row, groups per batch item
+    int mp;                          // queries in group order, padded to the GEMM tile (128)
+    int nbands, npx, np;             // 8-row bands, 16-column patches per band, padded pixel count (nbands*npx*128)
+    int h[MAX_LEVELS], w[MAX_LEVELS], sk[MAX_LEVELS], wp[MAX_LEVELS];
+    long long base[MAX_LEVELS];      // float offset of the level region [b][group][y][x'][k]
+    long long total;                 // floats
 };
 
 static bool make_geom(int b, int h8, int w8, int levels, PyrGeom& G) {
     if (b <= 0 || h8 <= 0 || w8 <= 0 || levels <= 0 || levels > MAX_LEVELS) return false;
     G.b = b; G.h8 = h8; G.w8 = w8; G.levels = levels;
-    long long nq = (long long)h8 * w8, off = 0;
+    G.gx = (w8 + GQ - 1) / GQ; G.ngroups = G.gx * h8; G.mp = (G.ngroups * GQ + 127) / 128 * 128;
+    G.nbands = (h8 + 7) / 8; G.npx = (w8 + 15) / 16; G.np = G.nbands * G.npx * 128;
+    long long off = 0;
     int h = h8, w = w8;
-    for (int l = 0; l < levels; ++l) {
-        if (h < 2 || w < 2) return false;      // bilinear_sampler divides by (size-1)
-        G.h[l] = h; G.w[l] = w; G.txc[l] = (w + 3) / 4; G.tyc[l] = (h + 3) / 4;
-        G.S[l] = (long long)G.txc[l] * G.tyc[l] * 16;
-        G.base[l] = off;
-        off += (long long)b * nq * G.S[l];
-        h /= 2; w /= 2;
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        if (l < levels) {
+            if (h < 2 || w < 2) return false;      // bilinear_sampler divides by (size-1)
+            G.h[l] = h; G.w[l] = w; G.sk[l] = 7 >> l; G.wp[l] = (w + G.sk[l] + 3) / 4 * 4;
+            G.base[l] = off;
+            off += (long long)b * G.ngroups * h * G.wp[l] * GQ;
+            h /= 2; w /= 2;
+        } else { G.h[l] = G.w[l] = G.sk[l] = G.wp[l] = 0; G.base[l] = off; }
     }
-    for (int l = levels; l < MAX_LEVELS; ++l) { G.h[l] = G.w[l] = G.txc[l] = G.tyc[l] = 0; G.S[l] = 0; G.base[l] = off; }
     G.total = off;
     return true;
 }
 
+static size_t scratch_floats(const PyrGeom& G, int c) { return (size_t)G.b * c * ((size_t)G.mp + G.np); }
+
 extern "C" size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels) {
     PyrGeom G;
     if (!make_geom(b, h8, w8, levels, G)) return 0;
-    // + one S_0 row of B' per channel is separate scratch appended at the end: (b, C<=256, S_0)
-    return (size_t)G.total * 4 + (size_t)b * 256 * G.S[0] * 4 + 256;
+    // the permuted feature maps (GEMM operands, <= 256 channels) are scratch behind the pyramid
+    return ((size_t)G.total + scratch_floats(G, 256)) * 4 + 256;
 }
 
-__device__ __forceinline__ int tile_off(int y, int x, int txc) { return (((y >> 2) * txc + (x >> 2)) << 4) + ((y & 3) << 2) + (x & 3); }
-
 // ------------------------------------------------------------------------------------------------ build
-__global__ void k_permute_fmap2(const float* __restrict__ f2, float* __restrict__ Bp, int C, int h8, int w8, int txc, long long S0) {
-    // one thread per (c, n'); grid.y = b*C
-    long long np = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (np >= S0) return;
-    int t = (int)(np >> 4), r = (int)(np & 15);
-    int y = (t / txc) * 4 + (r >> 2), x = (t % txc) * 4 + (r & 3);
+// mode 0: group order  n' = (y*gx + x/8)*8 + x%8      (fmap1; padded to mp)
+// mode 1: patch order  n' = ((y/8)*npx + x/16)*128 + (y%8)*16 + x%16   (fmap2; padded to np)
+__global__ void k_permute_fmap(const float* __restrict__ f, float* __restrict__ out, int h8, int w8, int mode, int gx, int npx, int npad) {
+    const int np = blockIdx.x * blockDim.x + threadIdx.x;         // grid.y = b*C
+    if (np >= npad) return;
+    int y, x;
+    if (mode == 0) { const int g = np >> 3; y = g / gx; x = (g % gx) * 8 + (np & 7); }
+    else { const int t = np >> 7, r = np & 127; y = (t / npx) * 8 + (r >> 4); x = (t % npx) * 16 + (r & 15); }
     float v = 0.0f;
-    if (y < h8 && x < w8) v = f2[(size_t)blockIdx.y * h8 * w8 + (size_t)y * w8 + x];
-    Bp[(size_t)blockIdx.y * S0 + np] = v;
+    if (y < h8 && x < w8) v = f[(size_t)blockIdx.y * h8 * w8 + (size_t)y * w8 + x];
+    out[(size_t)blockIdx.y * npad + np] = v;
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define BM 128
 #define BN 128
 #define BK 16
+#define TP 136                      // row pitch of the staged half tile (floats)
 
-// A: (b, K, M) row-major (fmap1: K = channels, M = queries);  B: (b, K, N) row-major (B');  C: (b, M, N) row-major.
-// EDGE = false: every tile is full and 16-B aligned (M, N multiples of 128): no guards anywhere in the main loop.
-template <bool EDGE>
-__global__ __launch_bounds__(256) void k_corr_gemm(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                   int M, int N, int K, float scale) {
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
-    const int bz = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* Ab = A + (size_t)bz * K * M;
-    const float* Bb = B + (size_t)bz * K * N;
-    float* Cb = C + (size_t)bz * M * N;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    // loader mapping: thread -> (k = tid>>5 [+8], 4 consecutive columns at (tid&31)*4)
-    const int lk = tid >> 5, lc = (tid & 31) * 4;
-    const bool a_full = !EDGE || ((m0 + BM <= M) && (M % 4 == 0)), b_full = !EDGE || ((n0 + BN <= N) && (N % 4 == 0));
-
-    auto load4 = [&](const float* base, int ld, int k, int c0, int limit, bool full) -> float4 {
-        const float* p = base + (size_t)k * ld + c0;
-        if (!EDGE || full) return *(const float4*)p;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + 0 < limit) v.x = p[0];
-        if (c0 + 1 < limit) v.y = p[1];
-        if (c0 + 2 < limit) v.z = p[2];
-        if (c0 + 3 < limit) v.w = p[3];
-        return v;
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    constexpr int NL = BK / 8;                  // loader rows per thread (8 k-rows per sweep of the 256 threads)
-    float4 ra[NL], rb[NL];
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-        ra[u] = load4(Ab, M, lk + 8 * u, m0 + lc, M, a_full);
-        rb[u] = load4(Bb, N, lk + 8 * u, n0 + lc, N, b_full);
+// Scatter one level of a half tile (64 queries = 8 groups) into the skewed layout.
+//   src[q * pitch + yy * PW + xx]: the level-l values of this patch (R rows x PW columns per query)
+// Destination slots of the patch: x' in [x0, x0 + PW + SK) -- slot (x', k) holds x = x' - SK + (k >> L); it is written
+// with data when x lies in this patch, with zero when x is outside the map (the left edge by the first patch, the right
+// edge and the row padding up to wp by the last), and left to the neighbouring patch otherwise.
+template <int L>
+__device__ __forceinline__ void scatter_level(const float* __restrict__ src, int pitch, float* __restrict__ lvl, const PyrGeom& G, int bz,
+                                              int g0, int band, int px, int tid) {
+    constexpr int PW = 16 >> L, R = 8 >> L, SK = 7 >> L, S = PW + SK;
+    const int hl = G.h[L], wl = G.w[L], wp = G.wp[L];
+    const int x0 = px * PW, y0 = band * R;
+    const size_t rowf = (size_t)wp * 8;
+    for (int idx = tid; idx < 8 * R * S * 8; idx += 256) {       // (divisions by compile-time constants)
+        const int k = idx & 7, t = idx >> 3;
+        const int s = t % S, t2 = t / S;
+        const int yy = t2 % R, g = t2 / R;
+        const int y = y0 + yy, xs = x0 + s;                       // destination row and x'
+        const int Gi = g0 + g;
+        if (Gi >= G.ngroups || y >= hl || xs >= wp) continue;
+        const int x = xs - SK + (k >> L), xx = x - x0;
+        float v;
+        if (xx >= 0 && xx < PW && x < wl) v = src[(g * 8 + k) * pitch + yy * PW + xx];
+        else if (x < 0 || x >= wl) v = 0.0f;
+        else continue;                                            // inside the map but another patch's column
+        lvl[((size_t)bz * G.ngroups + Gi) * hl * rowf + (size_t)y * rowf + (size_t)xs * 8 + k] = v;
     }
-#pragma unroll
-    for (int u = 0; u < NL; ++u) { *(float4*)&As[0][lk + 8 * u][lc] = ra[u]; *(float4*)&Bs[0][lk + 8 * u][lc] = rb[u]; }
-    __syncthreads();
-
-    const int nk = K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int k1 = (kt + 1) * BK;
-#pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                ra[u] = load4(Ab, M, k1 + lk + 8 * u, m0 + lc, M, a_full);
-                rb[u] = load4(Bb, N, k1 + lk + 8 * u, n0 + lc, N, b_full);
+    if (px == G.npx - 1) {                                       // row padding right of the last patch's slots: zeros
+        const int xe = x0 + S, ne = wp - xe;                      // x' in [xe, wp): x >= x0 + PW >= w_l for every k
+        if (ne > 0) {
+            for (int idx = tid; idx < 8 * R * ne * 8; idx += 256) {
+                const int k = idx & 7, t = idx >> 3;
+                const int s = t % ne, t2 = t / ne;
+                const int yy = t2 % R, g = t2 / R;
+                const int y = y0 + yy, Gi = g0 + g;
+                if (Gi >= G.ngroups || y >= hl) continue;
+                lvl[((size_t)bz * G.ngroups + Gi) * hl * rowf + (size_t)y * rowf + (size_t)(xe + s) * 8 + k] = 0.0f;
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int kr = kk + (lane >> 5);
-            float a0 = As[cur][kr][wm * 64 + (lane & 31)];
-            float a1 = As[cur][kr][wm * 64 + 32 + (lane & 31)];
-            float b0 = Bs[cur][kr][wn * 64 + (lane & 31)];
-            float b1 = Bs[cur][kr][wn * 64 + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            const int nxt = cur ^ 1;
-#pragma unroll
-            for (int u = 0; u < NL; ++u) { *(float4*)&As[nxt][lk + 8 * u][lc] = ra[u]; *(float4*)&Bs[nxt][lk + 8 * u][lc] = rb[u]; }
-        }
-        __syncthreads();
     }
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (!EDGE || (row < M && col < N)) Cb[(size_t)row * N + col] = acc[i][j][r] * scale;
-            }
-        }
 }
 
-// Levels 1.. from level 0; one workgroup per (query, batch) map.
-__global__ __launch_bounds__(256) void k_corr_pool(float* __restrict__ pyr, PyrGeom G) {
-    extern __shared__ float lds[];            // two dense maps: level l (src) and level l+1 (dst)
-    const long long nq = (long long)G.h8 * G.w8;
-    const long long qb = (long long)blockIdx.y * nq + blockIdx.x;       // (b, q1) flattened
-    float* src = lds;
-    float* dst = lds + (size_t)G.h[0] * G.w[0];
-    // stage level 0 densely
-    {
-        const float* g0 = pyr + G.base[0] + qb * G.S[0];
-        const int h = G.h[0], w = G.w[0], txc = G.txc[0];
-        const int n4 = (int)(G.S[0] >> 2);                    // 16-B pieces: one micro-tile row each, contiguous in memory
-        for (int p = threadIdx.x; p < n4; p += blockDim.x) {
-            const float4 v = ((const float4*)g0)[p];
-            const int t = p >> 2, y = (t / txc) * 4 + (p & 3), x = (t % txc) * 4;
-            if (y < h) {
-                float* d = src + (size_t)y * w + x;
-                if (x + 3 < w) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
-                else { if (x < w) d[0] = v.x; if (x + 1 < w) d[1] = v.y; if (x + 2 < w) d[2] = v.z; }
-            }
-        }
-    }
-    __syncthreads();
-    for (int l = 1; l < G.levels; ++l) {
-        const int hs = G.h[l - 1], ws = G.w[l - 1], hd = G.h[l], wd = G.w[l], txc = G.txc[l];
-        float* gl = pyr + G.base[l] + qb * G.S[l];
-        const int Sl = (int)G.S[l];
-        (void)hs;
-        for (int p = threadIdx.x; p < Sl; p += blockDim.x) {           // every padded slot gets a value
-            int t = p >> 4, r = p & 15;
-            int y = (t / txc) * 4 + (r >> 2), x = (t % txc) * 4 + (r & 3);
-            float v = 0.0f;
-            if (y < hd && x < wd) {
-                const float* s = src + (size_t)(2 * y) * ws + 2 * x;
-                v = (((s[0] + s[1]) + s[ws]) + s[ws + 1]) * 0.25f;
-                dst[y * wd + x] = v;
-            }
-            gl[p] = v;
-        }
+// A: (b, K, mp) fmap1 in group order;  B: (b, K, np) fmap2 in patch order.  grid = (nbands, mp/128, b).
+__global__ __launch_bounds__(256, 2) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
+                                                    int K, float scale, PyrGeom G) {
+    // main loop: As[2][BK][BM] | Bs[2][BK][BN] (32 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
+    __shared__ __attribute__((aligned(16))) float smem[64 * TP + 64 * 33 + 64 * 9 + 64 * 3];
+    float (*As)[BK][BM] = (float (*)[BK][BM])smem;
+    float (*Bs)[BK][BN] = (float (*)[BK][BN])(smem + 2 * BK * BM);
+    float* T = smem;
+    float* T1 = smem + 64 * TP;
+    float* T2 = T1 + 64 * 33;
+    float* T3 = T2 + 64 * 9;
+    const int bz = blockIdx.z, band = blockIdx.x;
+    const int m0 = blockIdx.y * BM;
+    const int M = G.mp, N = G.np;
+    const float* Ab = A + (size_t)bz * K * M;
+    const float* Bb = B + (size_t)bz * K * N;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int lk = tid >> 5, lc = (tid & 31) * 4;                 // loader: (k = tid>>5 [+8], 4 consecutive columns)
+    static_assert(BK == 16, "two loader rows per thread");
+    const int nk = K / BK;
+
+    for (int px = 0; px < G.npx; ++px) {
+        const int n0 = (band * G.npx + px) * BN;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        float4 ra0, ra1, rb0, rb1;                                // (scalars: as arrays they are demoted to LDS)
+        ra0 = *(const float4*)(Ab + (size_t)lk * M + m0 + lc);        ra1 = *(const float4*)(Ab + (size_t)(lk + 8) * M + m0 + lc);
+        rb0 = *(const float4*)(Bb + (size_t)lk * N + n0 + lc);        rb1 = *(const float4*)(Bb + (size_t)(lk + 8) * N + n0 + lc);
+        __syncthreads();                                          // the previous patch's epilogue is done with smem
+        *(float4*)&As[0][lk][lc] = ra0; *(float4*)&As[0][lk + 8][lc] = ra1;
+        *(float4*)&Bs[0][lk][lc] = rb0; *(float4*)&Bs[0][lk + 8][lc] = rb1;
         __syncthreads();
-        float* tmp = src; src = dst; dst = tmp;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                const int k1 = (kt + 1) * BK + lk;
+                ra0 = *(const float4*)(Ab + (size_t)k1 * M + m0 + lc);    ra1 = *(const float4*)(Ab + (size_t)(k1 + 8) * M + m0 + lc);
+                rb0 = *(const float4*)(Bb + (size_t)k1 * N + n0 + lc);    rb1 = *(const float4*)(Bb + (size_t)(k1 + 8) * N + n0 + lc);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int kr = kk + (lane >> 5);
+                float a0 = As[cur][kr][wm * 64 + (lane & 31)];
+                float a1 = As[cur][kr][wm * 64 + 32 + (lane & 31)];
+                float b0 = Bs[cur][kr][wn * 64 + (lane & 31)];
+                float b1 = Bs[cur][kr][wn * 64 + 32 + (lane & 31)];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                const int nxt = cur ^ 1;
+                *(float4*)&As[nxt][lk][lc] = ra0; *(float4*)&As[nxt][lk + 8][lc] = ra1;
+                *(float4*)&Bs[nxt][lk][lc] = rb0; *(float4*)&Bs[nxt][lk + 8][lc] = rb1;
+            }
+            __syncthreads();
+        }
+        // ---- epilogue, one half (64 queries = the rows of the waves with wm == hh) at a time.
+        // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        for (int hh = 0; hh < 2; ++hh) {
+            if (hh) __syncthreads();                              // half 0's scatter has read T..T3
+            if (wm == hh) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            T[row * TP + col] = acc[i][j][r] * scale;
+                        }
+                    }
+            }
+            __syncthreads();
+            // 2x2 means in F.avg_pool2d's order: ((a + b) + c) + d, then * 0.25
+            for (int idx = tid; idx < 64 * 32; idx += 256) {      // level 1: 4 x 8 cells per query
+                const int q = idx >> 5, c1 = idx & 31;
+                const float* s = T + q * TP + (2 * (c1 >> 3)) * 16 + 2 * (c1 & 7);
+                T1[q * 33 + c1] = (((s[0] + s[1]) + s[16]) + s[17]) * 0.25f;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 64 * 8; idx += 256) {       // level 2: 2 x 4
+                const int q = idx >> 3, c2 = idx & 7;
+                const float* s = T1 + q * 33 + (2 * (c2 >> 2)) * 8 + 2 * (c2 & 3);
+                T2[q * 9 + c2] = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+            }
+            __syncthreads();
+            if (tid < 64 * 2) {                                   // level 3: 1 x 2
+                const int q = tid >> 1, c3 = tid & 1;
+                const float* s = T2 + q * 9 + 2 * c3;
+                T3[q * 3 + c3] = (((s[0] + s[1]) + s[4]) + s[5]) * 0.25f;
+            }
+            __syncthreads();
+            const int g0 = (m0 + hh * 64) >> 3;
+            scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
+            if (G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
+            if (G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
+            if (G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
+        }
     }
 }
 
@@ -257,140 +290,175 @@ __device__ __forceinline__ void make_taps(float c, int size, TapAxis& T) {
     }
 }
 
-// (m & a) | (~m & b) on the bit patterns: one v_bfi_b32
-__device__ __forceinline__ float bfi(unsigned m, float a, float b) {
-    return __uint_as_float((m & __float_as_uint(a)) | (~m & __float_as_uint(b)));
-}
-// element e (0..15) of the 16-wide register row held in four float4
-#define ROW_E(e) ((e) < 4 ? f0[(e) & 3] : (e) < 8 ? f1[(e) & 3] : (e) < 12 ? f2[(e) & 3] : f3[(e) & 3])
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// LDS staging geometry: per wave, 64 queries x (4 footprint rows x 64 B) with the query stride padded to 272 B
-// so that ds_read_b128 by lane = query is bank-conflict free (4*lane mod 64 distinct within each 16-lane group).
 #define LK_WAVES 4
 #ifndef LK_RPP
-#define LK_RPP 4                               // footprint rows staged per pass (4: rows 0-3, 4-7, 8-10;  2: six passes)
+#define LK_RPP 4                               // box rows staged per pass
 #endif
-#define LK_QSTRIDE (LK_RPP * 16 + 4)           // floats per query slot: RPP rows x 16 floats + 4 pad (68 / 36: conflict-free b128)
-#define LK_WAVE_FLOATS (64 * LK_QSTRIDE)
-#define LK_PASSES ((WIN + 2 + LK_RPP - 1) / LK_RPP)
-#define LK_NI (4 * LK_RPP)                     // loader instructions per pass: each serves 64 / (4 * RPP) queries
-#define LK_QPI (16 / LK_RPP)                   // queries per loader instruction
+#define LK_BOXW 16                             // x' slots per staged row (4 lines)
+#define LK_BOXH 12                             // box rows (LK_BOXH / LK_RPP passes)
+#define LK_GSTRIDE (LK_RPP * LK_BOXW * GQ + 8) // floats per group: +8 rotates the banks group to group (conflict-free 4-B reads
+                                               // when the groups of a wave sit at the same column offset -- the usual case)
+#define LK_WAVE_FLOATS (8 * LK_GSTRIDE)
+#define LK_NI (4 * LK_RPP)                     // loader instructions per pass: 8 groups x RPP rows x 4 lines x 8 pieces / 64 lanes
 
-// One workgroup = 4 waves = 256 consecutive queries of one (batch item, level).
-// Loader role (per pass, 16 instructions): instruction i serves queries 4i..4i+3 of the wave; lane L fetches the
-//   16-B piece (row (L>>2)&3, micro-tile L&3) of query 4i + (L>>4): 16 lanes cover one query's 4 rows x 64 B, the
-//   four pieces of a row sit in four neighbouring micro-tiles = one or two 128-B lines, and every line of the
-//   footprint is requested exactly once per wave (the first version re-fetched each line ~3x: 13.9 M line requests
-//   per launch at batch 32 against ~5 M distinct lines -- profiles/r01_lookup_pmc.txt).
-// Consumer role: lane = query; reads its rows back from LDS, aligns them in registers and emits the 81 taps with
-//   coalesced stores (64 consecutive queries per channel).
+__device__ __forceinline__ int group_min(int v) {
+    v = min(v, __shfl_xor(v, 1, 64)); v = min(v, __shfl_xor(v, 2, 64)); v = min(v, __shfl_xor(v, 4, 64));
+    return v;
+}
+__device__ __forceinline__ int group_max(int v) {
+    v = max(v, __shfl_xor(v, 1, 64)); v = max(v, __shfl_xor(v, 2, 64)); v = max(v, __shfl_xor(v, 4, 64));
+    return v;
+}
+
+// Consumer of one staged pass: box rows LK_RPP*pass .. +LK_RPP-1.  DEV = false: no tap of any lane of the wave deviates
+// (the usual case away from exactly-integer coordinates): 10 columns, two weights per tap on both axes.
+template <bool DEV>
+__device__ __forceinline__ void consume_pass(const float* __restrict__ mine, int pass, const TapAxis& X, const TapAxis& Y, int yoff, bool store_ok,
+                                             float* __restrict__ o, int nq, float (&hm2)[WIN], float (&hm1)[WIN]) {
+#pragma unroll
+    for (int rr = 0; rr < LK_RPP; ++rr) {
+        const int rb = LK_RPP * pass + rr;                               // box row (compile time)
+        float A[WIN + 2], hc[WIN];
+#pragma unroll
+        for (int c = 0; c < (DEV ? WIN + 2 : WIN + 1); ++c) A[c] = mine[rr * (LK_BOXW * GQ) + c * GQ];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) hc[i] = DEV ? A[i] * X.a0[i] + A[i + 1] * X.a1[i] + A[i + 2] * X.a2[i] : A[i] * X.a0[i] + A[i + 1] * X.a1[i];
+        // A lane whose window starts at box row yoff (0 or 1) finishes its window row j = rb - 2 - yoff with rows rb-2..rb.
+        const int ja = rb - 2, jb = rb - 3;                              // yoff = 0 / yoff = 1
+        const bool has_a = ja >= 0 && ja < WIN, has_b = jb >= 0 && jb < WIN;
+        if (has_a || has_b) {
+            const float w0 = yoff ? (has_b ? Y.a0[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a0[has_a ? ja : 0] : 0.0f);
+            const float w1 = yoff ? (has_b ? Y.a1[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a1[has_a ? ja : 0] : 0.0f);
+            const float w2 = DEV ? (yoff ? (has_b ? Y.a2[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a2[has_a ? ja : 0] : 0.0f)) : 0.0f;
+            const int jl = rb - 2 - yoff;
+            if (store_ok && jl >= 0 && jl < WIN) {
+                float* oj = o + (size_t)jl * nq;
+#pragma unroll
+                for (int i = 0; i < WIN; ++i)                           // channel i*9+j: x offset i-r, y offset j-r
+                    oj[(size_t)(i * WIN) * nq] = DEV ? hm2[i] * w0 + hm1[i] * w1 + hc[i] * w2 : hm2[i] * w0 + hm1[i] * w1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) { hm2[i] = hm1[i]; hm1[i] = hc[i]; }
+    }
+}
+
+// One workgroup = 4 independent waves; a wave = 8 consecutive groups (64 queries) of one (batch item, level).
 __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                              float* __restrict__ out, PyrGeom G) {
     __shared__ __attribute__((aligned(16))) float stage[LK_WAVES * LK_WAVE_FLOATS];
     const int l = blockIdx.y, bz = blockIdx.z;
     const int nq = G.h8 * G.w8;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool qok = q < nq;
-    const int qc = qok ? q : nq - 1;
-    const int hl = G.h[l], wl = G.w[l], txc = G.txc[l];
+    const int wave_g0 = (blockIdx.x * LK_WAVES + wv) * 8;             // first group of this wave
+    if (wave_g0 >= G.ngroups) return;                                 // (whole wave; there is no workgroup barrier below)
+    const int grp = lane >> 3, k = lane & 7;
+    const int Gi = wave_g0 + grp;
+    const int qy = Gi / G.gx, qx = (Gi % G.gx) * GQ + k;
+    const bool qok = Gi < G.ngroups && qx < G.w8;
+    const int q = qok ? qy * G.w8 + qx : 0;
+    const int hl = G.h[l], wl = G.w[l], wp = G.wp[l], sk = G.sk[l];
     const float inv = 1.0f / (float)(1 << l);
-    const float cx = coords[((size_t)bz * 2 + 0) * nq + qc] * inv;       // coords / 2**i  (exact)
-    const float cy = coords[((size_t)bz * 2 + 1) * nq + qc] * inv;
+    const float cx = coords[((size_t)bz * 2 + 0) * nq + q] * inv;     // coords / 2**i  (exact)
+    const float cy = coords[((size_t)bz * 2 + 1) * nq + q] * inv;
     TapAxis X, Y;
     make_taps(cx, wl, X);
     make_taps(cy, hl, Y);
-    const size_t S = (size_t)G.S[l];
-    const float* lvl = pyr + G.base[l] + (size_t)bz * nq * S;
-    float* o = out + ((size_t)bz * G.levels * WIN * WIN + (size_t)l * WIN * WIN) * nq + qc;
+    const float* lvl = pyr + G.base[l] + (size_t)bz * G.ngroups * hl * ((size_t)wp * GQ);
+    float* o = out + ((size_t)bz * G.levels * WIN * WIN + (size_t)l * WIN * WIN) * nq + q;
 
-    const int xb = (X.lo >> 2) << 2;          // aligned start column of the 16-wide register row
-    const int s = X.lo - xb;                  // 0..3
-    const int tx0 = xb >> 2;
-    // lane masks for the two register-shift stages; blended with v_bfi (kept as bit ops on purpose: written
-    // as selects the optimiser turns the shift into a dynamically indexed private array)
-    const unsigned m1 = 0u - (unsigned)(s & 1), m2 = 0u - (unsigned)((s >> 1) & 1);
-    // what the loader lanes need to know about a query: first row, first micro-tile column, whether the
-    // fourth micro-tile is used (columns s..s+10 reach it only for s >= 2)
-    // (packed into one word -> one ds_bpermute per loader instruction; far-outside values are clamped, they only
-    // have to stay outside the map)
-    const int cl_ylo = Y.lo < -30000 ? -30000 : (Y.lo > 30000 ? 30000 : Y.lo);
-    const int cl_tx0 = tx0 < -8000 ? -8000 : (tx0 > 8000 ? 8000 : tx0);
-    // the 4th micro-tile is touched only if columns s..s+9 (+1 when some x-tap deviates) reach it; the 11th row
-    // only if some y-tap deviates
-    const int need4 = (s + 9 + (X.dev ? 1 : 0)) >= 12 ? 1 : 0;
-    const int need_r10 = Y.dev ? 1 : 0;
-    const int my_packed = ((cl_ylo + 32768) << 16) | ((cl_tx0 + 8192) << 2) | (need_r10 << 1) | need4;
+    // ---- the group's staging box.  A lane whose window lies wholly outside its map (or whose coordinates are not
+    // finite) needs no data: its output is zero (all Y weights are cleared; staged data is always finite).
+    // (needw x needh = what is fetched; "fits" is tested against the full 11 x 11 because when any lane of the wave has a
+    // deviating tap every lane reads 11 columns / rows of its window -- with zero weights, but from staged memory)
+    const int needw = WIN + 1 + (X.dev ? 1 : 0), needh = WIN + 1 + (Y.dev ? 1 : 0);
+    const bool empty = !qok || X.lo + WIN + 1 < 0 || X.lo >= wl || Y.lo + WIN + 1 < 0 || Y.lo >= hl;
+    if (empty) {
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) { Y.a0[i] = 0.0f; Y.a1[i] = 0.0f; Y.a2[i] = 0.0f; }
+    }
+    const int sx = X.lo + sk - (k >> l);                              // window start in skewed columns
+    const int big = 0x3fffffff;
+    const int gminx = group_min(empty ? big : sx), gminy = group_min(empty ? big : Y.lo);
+    const bool gany = gminx != big;
+    const int gx0 = gany ? (gminx >> 2) << 2 : 0, gy0 = gany ? gminy : 0;
+    const int xoff_ = sx - gx0, yoff_ = Y.lo - gy0;
+    const bool fits = !empty && xoff_ + WIN + 2 <= LK_BOXW && yoff_ <= 1 && yoff_ + WIN + 2 <= LK_BOXH;
+    const bool slow = !empty && !fits;                               // rare: handled tap by tap below
+    const int gmaxx = group_max(fits ? xoff_ + needw - 1 : -1), gmaxy = group_max(fits ? yoff_ + needh - 1 : -1);
+    const int nlines = (gmaxx >> 2) + 1, nrows = gmaxy + 1;           // what the loader fetches (0 when no lane fits)
+    const int xoff = fits ? xoff_ : 0, yoff = fits ? yoff_ : 0;
+    const bool store_ok = qok && !slow;
+    const bool any_dev = __any((X.dev | Y.dev) != 0 && fits);
 
     float* wstage = stage + wv * LK_WAVE_FLOATS;
-    const int ld_row = (lane >> 2) & (LK_RPP - 1), ld_piece = lane & 3, ld_sub = lane / (4 * LK_RPP);   // loader role of this lane
-    const int q_wave0 = blockIdx.x * blockDim.x + wv * 64;                           // first query of this wave
+    const float* mine = wstage + grp * LK_GSTRIDE + xoff * GQ + k;    // this lane's column 0 of box row 0 of a pass
+    // loader role: lane -> (16-B piece of a line, line of the row, row/group selector)
+    const int ld_piece = lane & 7, ld_line = (lane >> 3) & 3, ld_hi = lane >> 5;
+    const size_t row_floats = (size_t)wp * GQ;
 
-    float hm2[WIN], hm1[WIN], hc[WIN];        // horizontally interpolated rows r-2, r-1, r
+    float hm2[WIN], hm1[WIN];
 #pragma unroll
     for (int i = 0; i < WIN; ++i) { hm2[i] = 0.0f; hm1[i] = 0.0f; }
 
 #pragma unroll
-    for (int pass = 0; pass < LK_PASSES; ++pass) {
-        // ---- loader: 16 coalesced 16-B loads per lane-group of 16
+    for (int pass = 0; pass < LK_BOXH / LK_RPP; ++pass) {
         f32x4 v[LK_NI];
-        unsigned okbits = 0;                    // which of the 16 pieces are inside the map: applied when they go to LDS (a
-                                                // select right after the load makes the compiler branch around every load
-                                                // and wait for each shuffle in turn)
-        int pks[LK_NI];
-#pragma unroll
-        for (int i = 0; i < LK_NI; ++i) pks[i] = __shfl(my_packed, LK_QPI * i + ld_sub, 64);   // all shuffles first: one LDS round trip
+        unsigned okbits = 0;
 #pragma unroll
         for (int i = 0; i < LK_NI; ++i) {
-            const int src = LK_QPI * i + ld_sub;                                          // query (within the wave) served
-            const int pk = pks[i];
-            const int ylo_s = (int)((unsigned)pk >> 16) - 32768, tx0_s = ((pk >> 2) & 0x3fff) - 8192, need4_s = pk & 1;
-            const int last_row = (pk & 2) ? WIN + 1 : WIN;                           // highest footprint row index needed
-            const int qs = q_wave0 + src;
-            const int yy = ylo_s + LK_RPP * pass + ld_row;
-            const int tx = tx0_s + ld_piece;
+            const int gr = 2 * i + ld_hi;                             // (group, row) pair served by this instruction half
+            const int g = (2 * i) / LK_RPP;                           // group: wave-uniform, compile time
+            const int row = gr % LK_RPP;
+            const int s_gx0 = __builtin_amdgcn_readlane(gx0, g * 8), s_gy0 = __builtin_amdgcn_readlane(gy0, g * 8);
+            const int s_nl = __builtin_amdgcn_readlane(nlines, g * 8), s_nr = __builtin_amdgcn_readlane(nrows, g * 8);
+            const int rbx = LK_RPP * pass + row;
+            const int y = s_gy0 + rbx, xs = s_gx0 + 4 * ld_line;
             // (bitwise &, not &&: short-circuit evaluation puts a branch in front of every load)
-            const bool ok = (qs < nq) & ((LK_RPP * pass + ld_row) <= last_row) & (yy >= 0) & (yy < hl) & (tx >= 0) & (tx < txc) &
-                            ((ld_piece < 3) | (need4_s != 0));
-            const float* p = lvl + (size_t)(ok ? qs : 0) * S + (ok ? ((((yy >> 2) * txc + tx) << 4) + ((yy & 3) << 2)) : 0);
-            v[i] = *(const f32x4*)p;
+            const bool ok = (rbx < s_nr) & (y >= 0) & (y < hl) & (ld_line < s_nl) & (xs >= 0) & (xs + 4 <= wp) & (wave_g0 + g < G.ngroups);
+            const size_t off = ok ? ((size_t)(wave_g0 + g) * hl + y) * row_floats + (size_t)xs * GQ + ld_piece * 4 : 0;
+            v[i] = *(const f32x4*)(lvl + off);
             okbits |= ok ? (1u << i) : 0u;
         }
-        __syncthreads();                                                             // previous pass fully consumed
+        __builtin_amdgcn_wave_barrier();                              // (compiler ordering only: the wave's LDS traffic is in order)
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < LK_NI; ++i)
-            *(f32x4*)(wstage + (LK_QPI * i + ld_sub) * LK_QSTRIDE + ld_row * 16 + ld_piece * 4) = ((okbits >> i) & 1) ? v[i] : zero;
-        __syncthreads();
-        // ---- consumer: lane = query
-        const float* mine = wstage + lane * LK_QSTRIDE;
+        for (int i = 0; i < LK_NI; ++i) {
+            const int gr = 2 * i + ld_hi, g = (2 * i) / LK_RPP, row = gr % LK_RPP;
+            *(f32x4*)(wstage + g * LK_GSTRIDE + row * (LK_BOXW * GQ) + ld_line * 32 + ld_piece * 4) = ((okbits >> i) & 1) ? v[i] : zero;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (any_dev) consume_pass<true>(mine, pass, X, Y, yoff, store_ok, o, nq, hm2, hm1);
+        else consume_pass<false>(mine, pass, X, Y, yoff, store_ok, o, nq, hm2, hm1);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- windows that do not fit the group's box (flow that jumps inside a group): bilinear taps straight from memory,
+    // same tap positions and the same (horizontal, then vertical) order of operations
+    if (__any(slow)) {
+        if (slow) {
+            const float* qmap = lvl + (size_t)Gi * hl * row_floats + (size_t)(sk - (k >> l)) * GQ + k;   // (y, x) -> qmap[y*row_floats + x*8]
+            for (int i = 0; i < WIN; ++i) {
+                const float px = rt_pos(rn_add(cx, (float)(i - RADIUS)), wl);
+                float pfx; const int fx = safe_floor(px, pfx);
+                const float wx1 = px - pfx, wx0 = (pfx + 1.0f) - px;
+                for (int j = 0; j < WIN; ++j) {
+                    const float py = rt_pos(rn_add(cy, (float)(j - RADIUS)), hl);
+                    float pfy; const int fy = safe_floor(py, pfy);
+                    const float wy1 = py - pfy, wy0 = (pfy + 1.0f) - py;
+                    float t[2][2];
 #pragma unroll
-        for (int rr = 0; rr < LK_RPP; ++rr) {
-            const int r = LK_RPP * pass + rr;
-            if (r >= WIN + 2) break;
-            const f32x4 f0 = *(const f32x4*)(mine + rr * 16 + 0), f1 = *(const f32x4*)(mine + rr * 16 + 4);
-            const f32x4 f2 = *(const f32x4*)(mine + rr * 16 + 8), f3 = *(const f32x4*)(mine + rr * 16 + 12);
-            // align in registers: A[k] = row[k + s], two blend stages (s&1, s&2)
-            float Bt[13], A[11];
+                    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int k = 0; k < 13; ++k) { const float u = ROW_E(k), w = ROW_E(k + 1); Bt[k] = bfi(m1, w, u); }
-#pragma unroll
-            for (int k = 0; k < 11; ++k) A[k] = bfi(m2, Bt[k + 2], Bt[k]);
-            // horizontal interpolation of this row for the 9 x-taps
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) hc[i] = A[i] * X.a0[i] + A[i + 1] * X.a1[i] + A[i + 2] * X.a2[i];
-            // rows (r-2, r-1, r) finish window row j = r-2
-            if (r >= 2) {
-                const int j = r - 2;
-                if (qok) {
-#pragma unroll
-                    for (int i = 0; i < WIN; ++i)                       // channel i*9+j: x offset i-r, y offset j-r
-                        o[(size_t)(i * WIN + j) * nq] = hm2[i] * Y.a0[j] + hm1[i] * Y.a1[j] + hc[i] * Y.a2[j];
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int yy = fy + dy, xx = fx + dx;
+                            const bool in = (yy >= 0) & (yy < hl) & (xx >= 0) & (xx < wl);
+                            t[dy][dx] = in ? qmap[(size_t)yy * row_floats + (size_t)xx * GQ] : 0.0f;
+                        }
+                    const float h0 = t[0][0] * wx0 + t[0][1] * wx1, h1 = t[1][0] * wx0 + t[1][1] * wx1;
+                    o[(size_t)(i * WIN + j) * nq] = h0 * wy0 + h1 * wy1;
                 }
             }
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) { hm2[i] = hm1[i]; hm1[i] = hc[i]; }
         }
     }
 }
@@ -414,38 +482,34 @@ __global__ void k_corr_taps(const float* __restrict__ coords, int32_t* x0, int32
     }
 }
 
+// dense (b*nq, h_l, w_l) copy of one level (tests / debugging)
 __global__ void k_corr_export(const float* __restrict__ pyr, float* __restrict__ dense, PyrGeom G, int l) {
-    const long long nq = (long long)G.h8 * G.w8;
-    const long long qb = blockIdx.x;                          // (b, q1) flattened
-    const int h = G.h[l], w = G.w[l];
-    const float* g = pyr + G.base[l] + qb * G.S[l];
+    const int nq = G.h8 * G.w8;
+    const long long qb = blockIdx.x;                          // (b, q) flattened, q row-major
+    const int bz = (int)(qb / nq), q = (int)(qb % nq);
+    const int qy = q / G.w8, qx = q % G.w8;
+    const int Gi = qy * G.gx + (qx >> 3), k = qx & 7;
+    const int h = G.h[l], w = G.w[l], wp = G.wp[l];
+    const float* g = pyr + G.base[l] + ((size_t)bz * G.ngroups + Gi) * h * ((size_t)wp * GQ) + (size_t)(G.sk[l] - (k >> l)) * GQ + k;
     for (int p = threadIdx.x; p < h * w; p += blockDim.x) {
         int y = p / w, x = p - y * w;
-        dense[qb * h * w + p] = g[tile_off(y, x, G.txc[l])];
+        dense[qb * h * w + p] = g[(size_t)y * wp * GQ + (size_t)x * GQ];
     }
-    (void)nq;
 }
 
 extern "C" int rpe_corr_build(const float* fmap1, const float* fmap2, int b, int c, int h8, int w8, int levels,
                               void* pyramid, void* stream) {
     PyrGeom G;
     if (!fmap1 || !fmap2 || !pyramid || c <= 0 || c > 256 || c % BK != 0 || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
+    if (((uintptr_t)pyramid) & 15) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     float* pyr = (float*)pyramid;
-    float* Bp = pyr + G.total;                               // scratch behind the pyramid (b, c, S_0)
-    const long long S0 = G.S[0];
-    const int nq = h8 * w8;
-    hipLaunchKernelGGL(k_permute_fmap2, dim3(ceil_div(S0, 256), b * c), dim3(256), 0, s, fmap2, Bp, c, h8, w8, G.txc[0], S0);
-    const bool edge = (nq % BM) || (S0 % BN) || ((uintptr_t)fmap1 % 16) || ((uintptr_t)pyramid % 16);
-    if (edge) hipLaunchKernelGGL(k_corr_gemm<true>, dim3(ceil_div(S0, BN), ceil_div(nq, BM), b), dim3(256), 0, s, fmap1, (const float*)Bp,
-                                 pyr + G.base[0], nq, (int)S0, c, 1.0f / sqrtf((float)c));
-    else hipLaunchKernelGGL(k_corr_gemm<false>, dim3(ceil_div(S0, BN), ceil_div(nq, BM), b), dim3(256), 0, s, fmap1, (const float*)Bp,
-                            pyr + G.base[0], nq, (int)S0, c, 1.0f / sqrtf((float)c));
-    if (levels > 1) {
-        size_t lds = ((size_t)G.h[0] * G.w[0] + (size_t)G.h[1] * G.w[1]) * sizeof(float);
-        if (lds > 160 * 1024) return RPE_E_UNSUPPORTED;
-        hipLaunchKernelGGL(k_corr_pool, dim3(nq, b), dim3(256), lds, s, pyr, G);
-    }
+    float* Ap = pyr + G.total;                               // scratch behind the pyramid: (b, c, mp) then (b, c, np)
+    float* Bp = Ap + (size_t)b * c * G.mp;
+    hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.mp, 256), b * c), dim3(256), 0, s, fmap1, Ap, h8, w8, 0, G.gx, G.npx, G.mp);
+    hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.np, 256), b * c), dim3(256), 0, s, fmap2, Bp, h8, w8, 1, G.gx, G.npx, G.np);
+    hipLaunchKernelGGL(k_corr_build, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, (const float*)Ap, (const float*)Bp, pyr, c,
+                       1.0f / sqrtf((float)c), G);
     return rpe_check_launch();
 }
 
@@ -453,8 +517,7 @@ extern "C" int rpe_corr_lookup(const void* pyramid, const float* coords, int b, 
                                float* out, void* stream) {
     PyrGeom G;
     if (!pyramid || !coords || !out || radius != RADIUS || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
-    const int nq = h8 * w8;
-    hipLaunchKernelGGL(k_corr_lookup, dim3(ceil_div(nq, 256), levels, b), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_corr_lookup, dim3(ceil_div(G.ngroups, 8 * LK_WAVES), levels, b), dim3(64 * LK_WAVES), 0, (hipStream_t)stream,
                        (const float*)pyramid, coords, out, G);
     return rpe_check_launch();
 }

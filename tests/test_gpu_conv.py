@@ -337,12 +337,17 @@ def test_instance_norm_statistics_survive_large_means(rpe, cout, bias_val):
     inv_ref = 1.0 / torch.sqrt(var[:, :, 0, 0] + eps)
     assert float(((mi[..., 0] - mean[:, :, 0, 0]).abs() / mean[:, :, 0, 0].abs()).max()) < 1e-6
     assert float(((mi[..., 1] - inv_ref).abs() / inv_ref).max()) < 2e-5
-    # normalised output vs the f64 normalisation of the kernel's own raw tensor (f32 rounding of the raw values at |x| ~ 50
-    # is the reference's too: ulp(50)/std; it is excluded by normalising `raw` itself)
+    # the apply pass: (x - mean) * inv with the f32 (mean, inv) the kernel derives; then against the f64 truth.  On the
+    # constant-plus-noise plane (channel 1: std ~ 1e-3 around 50) the f32 representation of the mean itself, ulp(50)/2 = 2e-6,
+    # is 2e-3 standard deviations -- the reference's float32 instance norm has the same floor -- so the truth comparison
+    # excludes that plane; its statistics were checked above.
     got = ops.instnorm_apply(raw.clone(), stats, eps=eps, relu=False).cpu().double()
+    own = (raw.cpu().double() - mi[..., 0][:, :, None, None]) * mi[..., 1][:, :, None, None]
+    scale = own.abs().amax((2, 3), keepdim=True)
+    assert float(((got - own).abs() / scale).max()) < 2e-5
     want = (raw.cpu().double() - mean) / torch.sqrt(var + eps)
-    scale = want.abs().amax((2, 3), keepdim=True)
-    assert float(((got - want).abs() / scale).max()) < 2e-5
+    keep = [c for c in range(cout) if c != 1]
+    assert float(((got - want).abs() / scale)[:, keep].max()) < 2e-5
 
 
 def test_stem_statistics_survive_large_means(rpe):

@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--pairs', type=int, default=32)
     ap.add_argument('--flow-std', type=float, default=3.0)
+    ap.add_argument('--jitter', type=float, default=0.0, help='per-query white noise on the lookup coordinates (px at 1/8 resolution)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
@@ -52,6 +53,8 @@ def main():
         # smooth flow field (low-pass noise) + a global shift, like a RAFT iterate
         lo = torch.randn(b, 2, 6, 8, device=dev) * a.flow_std
         coords = base + torch.nn.functional.interpolate(lo, size=(h8, w8), mode='bilinear', align_corners=True) - 2.3
+        if a.jitter > 0:
+            coords = coords + torch.randn_like(coords) * a.jitter
         out = torch.empty(b, 324, h8, w8, device=dev)
         if want('lookup'):
             med, mn = timeit(lambda: pyr.lookup(coords, out=out), a.reps)
