@@ -6,18 +6,19 @@
 // Pyramid layout (private to this file): GROUP-INTERLEAVED, SKEWED ROWS.
 //   A *group* = 8 queries that are neighbours in x: g = (q.y, q.x >> 3), k = q.x & 7.  For batch item b, group g
 //   and level l the eight (h_l x w_l) correlation maps of the group are stored together, query index fastest:
-//       slot(y, x', k),  x' = x + sk_l - (k >> l),  sk_l = 7 >> l          ("skew": query k's map is shifted left
+//       slot(y, x', k),  x' = x + sk_l - (k >> l),  sk_l = max(7 >> l, 1)  ("skew": query k's map is shifted left
 //       addr = base_l + ((b*ngroups + g) * h_l + y) * wp_l*8 + x'*8 + k      by the distance its window centre moves)
 //   with wp_l = (w_l + sk_l) rounded up to 4; slots whose x falls outside [0, w_l) hold zeros (they ARE the zero
-//   padding of grid_sample).  One 128-B line = 4 x' x 8 queries of one map row.
+//   padding of grid_sample; sk_l >= 1 makes slot x' = 0 of every row zero for every k, which gives the lookup's loader
+//   an all-zero 16-B piece at offset 0 of every level region).  One 128-B line = 4 x' x 8 queries of one map row.
 // Why: a query reads a 10x10 (11x11) window of ITS OWN map per level, so nothing is shared between queries -- unless
 // the maps of neighbouring queries are interleaved.  Neighbouring queries have neighbouring window centres
 // (centre = q + flow, and flow is smooth), so after the skew the 8 windows of a group coincide: the group needs
 // ~10 rows x (10 + 3)/4 lines and every fetched line is used by all 8 queries.  Per query and level that is ~4 lines
 // instead of ~7 with per-query 8x4-pixel lines (and ~15 row-major): the lookup is bound by HBM lines.  Rows are whole
 // lines, so a loader pass over any subset of rows requests every line exactly once.  Flow that is NOT smooth inside a
-// group costs bandwidth, never correctness: a window that leaves the group's 12 x 16 staging box takes a per-tap
-// path straight from global memory.
+// group costs bandwidth, never correctness: windows that do not fit one 12 x 16 staging box are served by further
+// rounds of the same loader / consumer with the box re-anchored on the lanes that are left.
 //
 // Kernels:
 //   k_permute_fmap  : fmap (b,C,h8,w8) -> (b,C,N') in GEMM tile order, zero padded: fmap1 in group order (padded to
@@ -60,7 +61,7 @@ static bool make_geom(int b, int h8, int w8, int levels, PyrGeom& G) {
     for (int l = 0; l < MAX_LEVELS; ++l) {
         if (l < levels) {
             if (h < 2 || w < 2) return false;      // bilinear_sampler divides by (size-1)
-            G.h[l] = h; G.w[l] = w; G.sk[l] = 7 >> l; G.wp[l] = (w + G.sk[l] + 3) / 4 * 4;
+            G.h[l] = h; G.w[l] = w; G.sk[l] = (7 >> l) > 1 ? (7 >> l) : 1; G.wp[l] = (w + G.sk[l] + 3) / 4 * 4;
             G.base[l] = off;
             off += (long long)b * G.ngroups * h * G.wp[l] * GQ;
             h /= 2; w /= 2;
@@ -109,34 +110,40 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int L>
 __device__ __forceinline__ void scatter_level(const float* __restrict__ src, int pitch, float* __restrict__ lvl, const PyrGeom& G, int bz,
                                               int g0, int band, int px, int tid) {
-    constexpr int PW = 16 >> L, R = 8 >> L, SK = 7 >> L, S = PW + SK;
+    constexpr int PW = 16 >> L, R = 8 >> L, SK = (7 >> L) > 1 ? (7 >> L) : 1, S = PW + SK;
     const int hl = G.h[L], wl = G.w[L], wp = G.wp[L];
     const int x0 = px * PW, y0 = band * R;
-    const size_t rowf = (size_t)wp * 8;
-    for (int idx = tid; idx < 8 * R * S * 8; idx += 256) {       // (divisions by compile-time constants)
-        const int k = idx & 7, t = idx >> 3;
-        const int s = t % S, t2 = t / S;
-        const int yy = t2 % R, g = t2 / R;
-        const int y = y0 + yy, xs = x0 + s;                       // destination row and x'
-        const int Gi = g0 + g;
-        if (Gi >= G.ngroups || y >= hl || xs >= wp) continue;
-        const int x = xs - SK + (k >> L), xx = x - x0;
-        float v;
-        if (xx >= 0 && xx < PW && x < wl) v = src[(g * 8 + k) * pitch + yy * PW + xx];
-        else if (x < 0 || x >= wl) v = 0.0f;
-        else continue;                                            // inside the map but another patch's column
-        lvl[((size_t)bz * G.ngroups + Gi) * hl * rowf + (size_t)y * rowf + (size_t)xs * 8 + k] = v;
+    const unsigned rowB = (unsigned)wp * 32;                      // bytes per pyramid row; a level of one batch item is < 4 GB
+    char* lv = (char*)lvl + (size_t)bz * G.ngroups * hl * rowB;
+    // Slot t = (g*R + yy)*S + s of query k = tid & 7 is visited by thread (t & 31) in iteration t >> 5, so that consecutive
+    // lanes store consecutive floats.  (row = g*R + yy, s) advance incrementally: no division in the loop.
+    const int k = tid & 7, kq = k >> L;
+    int s = (tid >> 3) % S, row = (tid >> 3) / S;
+    constexpr int NIT = (8 * R * S + 31) / 32;
+#pragma unroll 4
+    for (int it = 0; it < NIT; ++it) {
+        const int g = row / R, yy = row % R;                      // (R is a power of two)
+        const int y = y0 + yy, xs = x0 + s, Gi = g0 + g;
+        const int xx = s - SK + kq, x = x0 + xx;
+        const bool valid = (row < 8 * R) & (Gi < G.ngroups) & (y < hl) & (xs < wp);
+        const bool data = (xx >= 0) & (xx < PW) & (x < wl), zero = (x < 0) | (x >= wl);
+        if (valid & (data | zero)) {                              // else: inside the map but another patch's column
+            const float v = data ? src[(g * 8 + k) * pitch + yy * PW + xx] : 0.0f;
+            *(float*)(lv + (size_t)(((unsigned)(Gi * hl + y) * (unsigned)wp + (unsigned)xs) * 32u + (unsigned)k * 4u)) = v;
+        }
+        s += 32 % S; row += 32 / S;
+        if (s >= S) { s -= S; row += 1; }
     }
     if (px == G.npx - 1) {                                       // row padding right of the last patch's slots: zeros
         const int xe = x0 + S, ne = wp - xe;                      // x' in [xe, wp): x >= x0 + PW >= w_l for every k
         if (ne > 0) {
             for (int idx = tid; idx < 8 * R * ne * 8; idx += 256) {
-                const int k = idx & 7, t = idx >> 3;
-                const int s = t % ne, t2 = t / ne;
+                const int t = idx >> 3;
+                const int se = t % ne, t2 = t / ne;
                 const int yy = t2 % R, g = t2 / R;
                 const int y = y0 + yy, Gi = g0 + g;
                 if (Gi >= G.ngroups || y >= hl) continue;
-                lvl[((size_t)bz * G.ngroups + Gi) * hl * rowf + (size_t)y * rowf + (size_t)(xe + s) * 8 + k] = 0.0f;
+                *(float*)(lv + (size_t)(((unsigned)(Gi * hl + y) * (unsigned)wp + (unsigned)(xe + se)) * 32u + (unsigned)k * 4u)) = 0.0f;
             }
         }
     }
@@ -244,10 +251,13 @@ __global__ __launch_bounds__(256, 2) void k_corr_build(const float* __restrict__
             }
             __syncthreads();
             const int g0 = (m0 + hh * 64) >> 3;
-            scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
-            if (G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
-            if (G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
-            if (G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
+#ifndef CB_SCATTER_MASK
+#define CB_SCATTER_MASK 15                     // (kernel experiments: which levels the epilogue writes)
+#endif
+            if (CB_SCATTER_MASK & 1) scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
+            if ((CB_SCATTER_MASK & 2) && G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
+            if ((CB_SCATTER_MASK & 4) && G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
+            if ((CB_SCATTER_MASK & 8) && G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
         }
     }
 }
@@ -290,16 +300,32 @@ __device__ __forceinline__ void make_taps(float c, int size, TapAxis& T) {
     }
 }
 
+#ifndef LK_WAVES
 #define LK_WAVES 4
-#ifndef LK_RPP
-#define LK_RPP 4                               // box rows staged per pass
 #endif
-#define LK_BOXW 16                             // x' slots per staged row (4 lines)
+#ifndef LK_NT
+#define LK_NT 5                                // bit 0: non-temporal loads of the pyramid, bit 1: non-temporal stores of the output,
+                                               // bit 2: non-temporal stores in waves that retire every lane in their first round (full 256-B stores)
+#endif
+#ifndef LK_XCD
+#define LK_XCD 1                               // 1: workgroups of one XCD take a contiguous range of (batch, level, query) slices
+#endif
+#ifndef LK_MINW
+#define LK_MINW 2                              // waves per SIMD the register allocation must allow
+#endif
+#ifndef LK_RPP
+#define LK_RPP 4                               // box rows staged per pass (even)
+#endif
+#ifndef LK_PREFETCH
+#define LK_PREFETCH 0                          // 1: the next pass's loads are issued before the current pass is consumed
+#endif
+#define LK_BOXW 16                             // x' slots per staged row
 #define LK_BOXH 12                             // box rows (LK_BOXH / LK_RPP passes)
+#define LK_NPASS (LK_BOXH / LK_RPP)
 #define LK_GSTRIDE (LK_RPP * LK_BOXW * GQ + 8) // floats per group: +8 rotates the banks group to group (conflict-free 4-B reads
                                                // when the groups of a wave sit at the same column offset -- the usual case)
 #define LK_WAVE_FLOATS (8 * LK_GSTRIDE)
-#define LK_NI (4 * LK_RPP)                     // loader instructions per pass: 8 groups x RPP rows x 4 lines x 8 pieces / 64 lanes
+#define LK_NI (4 * LK_RPP)                     // loader instructions per pass: 8 groups x RPP rows x 16 slots x 2 halves / 64 lanes
 
 __device__ __forceinline__ int group_min(int v) {
     v = min(v, __shfl_xor(v, 1, 64)); v = min(v, __shfl_xor(v, 2, 64)); v = min(v, __shfl_xor(v, 4, 64));
@@ -310,32 +336,46 @@ __device__ __forceinline__ int group_max(int v) {
     return v;
 }
 
+// What a pass needs to know; the per-group words are wave-uniform (read once per round from a lane of each group).
+struct LkCtx {
+    const char* lvl;                             // this batch item's level region (bytes); its first 16 B are zeros (slot x' = 0)
+    float* wstage; const float* mine; char* outb; // wave's LDS stage; this lane's column 0 of box row 0; batch item's output (bytes)
+    unsigned row_bytes, obase, nq4;              // bytes per pyramid row; byte offset of (level, q) in outb; nq * 4
+    unsigned gbase[8];                           // byte offset of box (row 0, slot 0) of each group [may wrap: only used when valid]
+    unsigned gmask[8];                           // bits 0-11: box rows to fetch, bits 16-31: slots to fetch
+    int ld_x, ld_half, ld_hi, yoff;
+    bool store_ok, any_dev, nt_store;
+};
+
 // Consumer of one staged pass: box rows LK_RPP*pass .. +LK_RPP-1.  DEV = false: no tap of any lane of the wave deviates
 // (the usual case away from exactly-integer coordinates): 10 columns, two weights per tap on both axes.
-template <bool DEV>
-__device__ __forceinline__ void consume_pass(const float* __restrict__ mine, int pass, const TapAxis& X, const TapAxis& Y, int yoff, bool store_ok,
-                                             float* __restrict__ o, int nq, float (&hm2)[WIN], float (&hm1)[WIN]) {
+template <bool DEV, int PASS>
+__device__ __forceinline__ void consume_pass(const LkCtx& C, const TapAxis& X, const TapAxis& Y, float (&hm2)[WIN], float (&hm1)[WIN]) {
 #pragma unroll
     for (int rr = 0; rr < LK_RPP; ++rr) {
-        const int rb = LK_RPP * pass + rr;                               // box row (compile time)
+        constexpr int dummy = 0; (void)dummy;
+        const int rb = LK_RPP * PASS + rr;                               // box row (compile time)
         float A[WIN + 2], hc[WIN];
 #pragma unroll
-        for (int c = 0; c < (DEV ? WIN + 2 : WIN + 1); ++c) A[c] = mine[rr * (LK_BOXW * GQ) + c * GQ];
+        for (int c = 0; c < (DEV ? WIN + 2 : WIN + 1); ++c) A[c] = C.mine[rr * (LK_BOXW * GQ) + c * GQ];
 #pragma unroll
         for (int i = 0; i < WIN; ++i) hc[i] = DEV ? A[i] * X.a0[i] + A[i + 1] * X.a1[i] + A[i + 2] * X.a2[i] : A[i] * X.a0[i] + A[i + 1] * X.a1[i];
         // A lane whose window starts at box row yoff (0 or 1) finishes its window row j = rb - 2 - yoff with rows rb-2..rb.
         const int ja = rb - 2, jb = rb - 3;                              // yoff = 0 / yoff = 1
         const bool has_a = ja >= 0 && ja < WIN, has_b = jb >= 0 && jb < WIN;
         if (has_a || has_b) {
-            const float w0 = yoff ? (has_b ? Y.a0[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a0[has_a ? ja : 0] : 0.0f);
-            const float w1 = yoff ? (has_b ? Y.a1[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a1[has_a ? ja : 0] : 0.0f);
-            const float w2 = DEV ? (yoff ? (has_b ? Y.a2[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a2[has_a ? ja : 0] : 0.0f)) : 0.0f;
-            const int jl = rb - 2 - yoff;
-            if (store_ok && jl >= 0 && jl < WIN) {
-                float* oj = o + (size_t)jl * nq;
+            const float w0 = C.yoff ? (has_b ? Y.a0[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a0[has_a ? ja : 0] : 0.0f);
+            const float w1 = C.yoff ? (has_b ? Y.a1[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a1[has_a ? ja : 0] : 0.0f);
+            const float w2 = DEV ? (C.yoff ? (has_b ? Y.a2[has_b ? jb : 0] : 0.0f) : (has_a ? Y.a2[has_a ? ja : 0] : 0.0f)) : 0.0f;
+            const int jl = rb - 2 - C.yoff;
+            if (C.store_ok && jl >= 0 && jl < WIN) {
+                const unsigned oj = C.obase + (unsigned)jl * C.nq4;     // channel i*9+j: x offset i-r, y offset j-r
 #pragma unroll
-                for (int i = 0; i < WIN; ++i)                           // channel i*9+j: x offset i-r, y offset j-r
-                    oj[(size_t)(i * WIN) * nq] = DEV ? hm2[i] * w0 + hm1[i] * w1 + hc[i] * w2 : hm2[i] * w0 + hm1[i] * w1;
+                for (int i = 0; i < WIN; ++i) {
+                    const float val = DEV ? hm2[i] * w0 + hm1[i] * w1 + hc[i] * w2 : hm2[i] * w0 + hm1[i] * w1;
+                    float* dst = (float*)(C.outb + (size_t)(oj + (unsigned)(i * WIN) * C.nq4));
+                    if ((LK_NT & 2) || ((LK_NT & 4) && C.nt_store)) __builtin_nontemporal_store(val, dst); else *dst = val;
+                }
             }
         }
 #pragma unroll
@@ -343,14 +383,61 @@ __device__ __forceinline__ void consume_pass(const float* __restrict__ mine, int
     }
 }
 
+// The loads of pass PASS: instruction i serves (group g = 2i / RPP, rows (2i + ld_hi) % RPP); lanes outside what the group
+// needs read the zero piece at offset 0 instead (so what reaches LDS needs no select).
+template <int PASS>
+__device__ __forceinline__ void issue_loads(const LkCtx& C, f32x4 (&v)[LK_NI]) {
+#pragma unroll
+    for (int i = 0; i < LK_NI; ++i) {
+        const int g = (2 * i) / LK_RPP;                                  // wave-uniform, compile time
+        const int rbx = LK_RPP * PASS + (2 * i) % LK_RPP + C.ld_hi;      // box row of this lane
+        const unsigned m = C.gmask[g];
+        const bool ok = ((m >> rbx) & (m >> (16 + C.ld_x)) & 1u) != 0;
+        const unsigned off = C.gbase[g] + (unsigned)rbx * C.row_bytes + (unsigned)(C.ld_x * 32 + C.ld_half * 16);
+        const f32x4* src = (const f32x4*)(C.lvl + (size_t)(ok ? off : 0u));
+        v[i] = (LK_NT & 1) ? __builtin_nontemporal_load(src) : *src;
+    }
+}
+
+// One loader + consumer pass (PASS is a template parameter so that every row index is a compile-time constant: left to
+// `#pragma unroll` the six-pass variant stayed a loop and the weight arrays went to scratch).
+template <int PASS>
+__device__ __forceinline__ void lookup_pass(const LkCtx& C, const TapAxis& X, const TapAxis& Y, float (&hm2)[WIN], float (&hm1)[WIN],
+                                            f32x4 (&vcur)[LK_NI]) {
+    f32x4 vnext[LK_NI];
+    if constexpr (LK_PREFETCH && PASS + 1 < LK_NPASS) {
+        issue_loads<PASS + 1>(C, vnext);
+        __builtin_amdgcn_sched_barrier(0);                               // (keep them ahead of this pass's arithmetic)
+    }
+#pragma unroll
+    for (int i = 0; i < LK_NI; ++i) {
+        const int g = (2 * i) / LK_RPP, row = (2 * i) % LK_RPP;
+        *(f32x4*)(C.wstage + g * LK_GSTRIDE + (row + C.ld_hi) * (LK_BOXW * GQ) + C.ld_x * GQ + C.ld_half * 4) = vcur[i];
+    }
+    __builtin_amdgcn_wave_barrier();                                     // (compiler ordering only: the wave's LDS traffic is in order)
+    if (C.any_dev) consume_pass<true, PASS>(C, X, Y, hm2, hm1);
+    else consume_pass<false, PASS>(C, X, Y, hm2, hm1);
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (PASS + 1 < LK_NPASS) {
+        if constexpr (!LK_PREFETCH) issue_loads<PASS + 1>(C, vnext);
+        lookup_pass<PASS + 1>(C, X, Y, hm2, hm1, vnext);
+    }
+}
+
 // One workgroup = 4 independent waves; a wave = 8 consecutive groups (64 queries) of one (batch item, level).
-__global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
-                                                             float* __restrict__ out, PyrGeom G) {
+__global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                                      float* __restrict__ out, PyrGeom G) {
     __shared__ __attribute__((aligned(16))) float stage[LK_WAVES * LK_WAVE_FLOATS];
-    const int l = blockIdx.y, bz = blockIdx.z;
+    int bx = blockIdx.x, l = blockIdx.y, bz = blockIdx.z;
+    if (LK_XCD) {   // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous range of the grid
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z, L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned c = L & 7, sidx = L >> 3, q8 = total >> 3, r8 = total & 7;
+        const unsigned nl = c * q8 + (c < r8 ? c : r8) + sidx;
+        bx = nl % gridDim.x; l = (nl / gridDim.x) % gridDim.y; bz = nl / (gridDim.x * gridDim.y);
+    }
     const int nq = G.h8 * G.w8;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wave_g0 = (blockIdx.x * LK_WAVES + wv) * 8;             // first group of this wave
+    const int wave_g0 = (bx * LK_WAVES + wv) * 8;                     // first group of this wave
     if (wave_g0 >= G.ngroups) return;                                 // (whole wave; there is no workgroup barrier below)
     const int grp = lane >> 3, k = lane & 7;
     const int Gi = wave_g0 + grp;
@@ -364,13 +451,11 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
     TapAxis X, Y;
     make_taps(cx, wl, X);
     make_taps(cy, hl, Y);
-    const float* lvl = pyr + G.base[l] + (size_t)bz * G.ngroups * hl * ((size_t)wp * GQ);
-    float* o = out + ((size_t)bz * G.levels * WIN * WIN + (size_t)l * WIN * WIN) * nq + q;
 
-    // ---- the group's staging box.  A lane whose window lies wholly outside its map (or whose coordinates are not
-    // finite) needs no data: its output is zero (all Y weights are cleared; staged data is always finite).
-    // (needw x needh = what is fetched; "fits" is tested against the full 11 x 11 because when any lane of the wave has a
-    // deviating tap every lane reads 11 columns / rows of its window -- with zero weights, but from staged memory)
+    // ---- A lane whose window lies wholly outside its map (or whose coordinates are not finite) needs no data: its
+    // output is zero (all Y weights are cleared; staged data is always finite) and is stored in the first round.
+    // needw x needh = what is fetched for a lane; "fits" is tested against the full 11 x 11 because when any lane of the
+    // wave has a deviating tap every lane reads 11 columns / rows of its window (zero weights, but staged memory).
     const int needw = WIN + 1 + (X.dev ? 1 : 0), needh = WIN + 1 + (Y.dev ? 1 : 0);
     const bool empty = !qok || X.lo + WIN + 1 < 0 || X.lo >= wl || Y.lo + WIN + 1 < 0 || Y.lo >= hl;
     if (empty) {
@@ -379,87 +464,60 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_corr_lookup(const float* __re
     }
     const int sx = X.lo + sk - (k >> l);                              // window start in skewed columns
     const int big = 0x3fffffff;
-    const int gminx = group_min(empty ? big : sx), gminy = group_min(empty ? big : Y.lo);
-    const bool gany = gminx != big;
-    const int gx0 = gany ? (gminx >> 2) << 2 : 0, gy0 = gany ? gminy : 0;
-    const int xoff_ = sx - gx0, yoff_ = Y.lo - gy0;
-    const bool fits = !empty && xoff_ + WIN + 2 <= LK_BOXW && yoff_ <= 1 && yoff_ + WIN + 2 <= LK_BOXH;
-    const bool slow = !empty && !fits;                               // rare: handled tap by tap below
-    const int gmaxx = group_max(fits ? xoff_ + needw - 1 : -1), gmaxy = group_max(fits ? yoff_ + needh - 1 : -1);
-    const int nlines = (gmaxx >> 2) + 1, nrows = gmaxy + 1;           // what the loader fetches (0 when no lane fits)
-    const int xoff = fits ? xoff_ : 0, yoff = fits ? yoff_ : 0;
-    const bool store_ok = qok && !slow;
-    const bool any_dev = __any((X.dev | Y.dev) != 0 && fits);
 
-    float* wstage = stage + wv * LK_WAVE_FLOATS;
-    const float* mine = wstage + grp * LK_GSTRIDE + xoff * GQ + k;    // this lane's column 0 of box row 0 of a pass
-    // loader role: lane -> (16-B piece of a line, line of the row, row/group selector)
-    const int ld_piece = lane & 7, ld_line = (lane >> 3) & 3, ld_hi = lane >> 5;
-    const size_t row_floats = (size_t)wp * GQ;
+    LkCtx C;
+    C.row_bytes = (unsigned)wp * GQ * 4; C.nq4 = (unsigned)nq * 4;
+    C.lvl = (const char*)(pyr + G.base[l]) + (size_t)bz * G.ngroups * hl * C.row_bytes;       // (a level of one batch item is < 4 GB)
+    C.outb = (char*)(out + (size_t)bz * G.levels * WIN * WIN * nq);
+    C.obase = ((unsigned)l * WIN * WIN * nq + q) * 4;
+    C.wstage = stage + wv * LK_WAVE_FLOATS;
+    // loader role: lane -> (16-B piece: x' slot ld_x of the staged row, half ld_half; row selector ld_hi)
+    C.ld_x = (lane >> 1) & 15; C.ld_half = lane & 1; C.ld_hi = lane >> 5;
+    const unsigned my_rows = (unsigned)Gi * hl;                       // first pyramid row of this lane's group
 
-    float hm2[WIN], hm1[WIN];
+    // ---- Rounds.  Per group the staging box is anchored at the topmost pending window row and, among the lanes within one
+    // row of it, the leftmost window column: that lane always fits, so every round retires at least one lane per group.
+    // Smooth flow retires all 8 lanes of every group in the first round; lanes of a group whose windows are more than
+    // 5 columns / 1 row apart (flow discontinuities) take further rounds -- more traffic, same arithmetic.
+    bool pending = !empty;
+    bool first = true;
+    for (;;) {
+        const int gy0m = group_min(pending ? Y.lo : big);
+        const bool near_top = pending && Y.lo - gy0m <= 1;
+        const int gx0m = group_min(near_top ? sx : big);
+        const bool gany = gx0m != big;
+        const int gx0 = gany ? gx0m : 0, gy0 = gany ? gy0m : 0;
+        const int xoff_ = sx - gx0, yoff_ = Y.lo - gy0;
+        const bool fits = near_top && xoff_ >= 0 && xoff_ + WIN + 2 <= LK_BOXW;
+        const int nslots = group_max(fits ? xoff_ + needw : 0), nrows = group_max(fits ? yoff_ + needh : 0);   // what the loader fetches
+        // box rows / slots that exist in the map and are needed, as bit masks (empty when nothing fits)
+        int r_lo = -gy0 > 0 ? -gy0 : 0, r_hi = hl - gy0 < nrows ? hl - gy0 : nrows;
+        int x_lo = -gx0 > 0 ? -gx0 : 0, x_hi = wp - gx0 < nslots ? wp - gx0 : nslots;
+        r_lo = r_lo > 16 ? 16 : r_lo; x_lo = x_lo > 16 ? 16 : x_lo;
+        r_hi = r_hi < r_lo ? r_lo : r_hi; x_hi = x_hi < x_lo ? x_lo : x_hi;
+        const unsigned rmask = ((1u << r_hi) - 1u) & ~((1u << r_lo) - 1u), xmask = ((1u << x_hi) - 1u) & ~((1u << x_lo) - 1u);
+        const unsigned my_mask = (Gi < G.ngroups ? (rmask & 0xfffu) : 0u) | (xmask << 16);
+        const unsigned my_base = (my_rows + (unsigned)gy0) * C.row_bytes + (unsigned)gx0 * (GQ * 4);     // wraps when gy0/gx0 < 0: those pieces are masked
 #pragma unroll
-    for (int i = 0; i < WIN; ++i) { hm2[i] = 0.0f; hm1[i] = 0.0f; }
-
-#pragma unroll
-    for (int pass = 0; pass < LK_BOXH / LK_RPP; ++pass) {
-        f32x4 v[LK_NI];
-        unsigned okbits = 0;
-#pragma unroll
-        for (int i = 0; i < LK_NI; ++i) {
-            const int gr = 2 * i + ld_hi;                             // (group, row) pair served by this instruction half
-            const int g = (2 * i) / LK_RPP;                           // group: wave-uniform, compile time
-            const int row = gr % LK_RPP;
-            const int s_gx0 = __builtin_amdgcn_readlane(gx0, g * 8), s_gy0 = __builtin_amdgcn_readlane(gy0, g * 8);
-            const int s_nl = __builtin_amdgcn_readlane(nlines, g * 8), s_nr = __builtin_amdgcn_readlane(nrows, g * 8);
-            const int rbx = LK_RPP * pass + row;
-            const int y = s_gy0 + rbx, xs = s_gx0 + 4 * ld_line;
-            // (bitwise &, not &&: short-circuit evaluation puts a branch in front of every load)
-            const bool ok = (rbx < s_nr) & (y >= 0) & (y < hl) & (ld_line < s_nl) & (xs >= 0) & (xs + 4 <= wp) & (wave_g0 + g < G.ngroups);
-            const size_t off = ok ? ((size_t)(wave_g0 + g) * hl + y) * row_floats + (size_t)xs * GQ + ld_piece * 4 : 0;
-            v[i] = *(const f32x4*)(lvl + off);
-            okbits |= ok ? (1u << i) : 0u;
+        for (int g = 0; g < 8; ++g) {
+            C.gbase[g] = (unsigned)__builtin_amdgcn_readlane((int)my_base, g * 8);
+            C.gmask[g] = (unsigned)__builtin_amdgcn_readlane((int)my_mask, g * 8);
         }
-        __builtin_amdgcn_wave_barrier();                              // (compiler ordering only: the wave's LDS traffic is in order)
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int i = 0; i < LK_NI; ++i) {
-            const int gr = 2 * i + ld_hi, g = (2 * i) / LK_RPP, row = gr % LK_RPP;
-            *(f32x4*)(wstage + g * LK_GSTRIDE + row * (LK_BOXW * GQ) + ld_line * 32 + ld_piece * 4) = ((okbits >> i) & 1) ? v[i] : zero;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (any_dev) consume_pass<true>(mine, pass, X, Y, yoff, store_ok, o, nq, hm2, hm1);
-        else consume_pass<false>(mine, pass, X, Y, yoff, store_ok, o, nq, hm2, hm1);
-        __builtin_amdgcn_wave_barrier();
-    }
+        C.yoff = fits ? yoff_ : 0;
+        C.store_ok = qok && (fits || (first && empty));
+        C.any_dev = __any((X.dev | Y.dev) != 0 && fits);
+        C.nt_store = first && !__any(pending && !fits);
+        C.mine = C.wstage + grp * LK_GSTRIDE + (fits ? xoff_ : 0) * GQ + k;    // this lane's column 0 of box row 0 of a pass
 
-    // ---- windows that do not fit the group's box (flow that jumps inside a group): bilinear taps straight from memory,
-    // same tap positions and the same (horizontal, then vertical) order of operations
-    if (__any(slow)) {
-        if (slow) {
-            const float* qmap = lvl + (size_t)Gi * hl * row_floats + (size_t)(sk - (k >> l)) * GQ + k;   // (y, x) -> qmap[y*row_floats + x*8]
-            for (int i = 0; i < WIN; ++i) {
-                const float px = rt_pos(rn_add(cx, (float)(i - RADIUS)), wl);
-                float pfx; const int fx = safe_floor(px, pfx);
-                const float wx1 = px - pfx, wx0 = (pfx + 1.0f) - px;
-                for (int j = 0; j < WIN; ++j) {
-                    const float py = rt_pos(rn_add(cy, (float)(j - RADIUS)), hl);
-                    float pfy; const int fy = safe_floor(py, pfy);
-                    const float wy1 = py - pfy, wy0 = (pfy + 1.0f) - py;
-                    float t[2][2];
+        float hm2[WIN], hm1[WIN];
 #pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int yy = fy + dy, xx = fx + dx;
-                            const bool in = (yy >= 0) & (yy < hl) & (xx >= 0) & (xx < wl);
-                            t[dy][dx] = in ? qmap[(size_t)yy * row_floats + (size_t)xx * GQ] : 0.0f;
-                        }
-                    const float h0 = t[0][0] * wx0 + t[0][1] * wx1, h1 = t[1][0] * wx0 + t[1][1] * wx1;
-                    o[(size_t)(i * WIN + j) * nq] = h0 * wy0 + h1 * wy1;
-                }
-            }
-        }
+        for (int i = 0; i < WIN; ++i) { hm2[i] = 0.0f; hm1[i] = 0.0f; }
+        f32x4 v0[LK_NI];
+        issue_loads<0>(C, v0);
+        lookup_pass<0>(C, X, Y, hm2, hm1, v0);
+        pending = pending && !fits;
+        first = false;
+        if (!__any(pending)) break;
     }
 }
 
