@@ -102,6 +102,27 @@ int rpe_pose_solve_opts(const float *flow, const float *pcl1, const float *pcl2,
                         void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Backward of the declarative pose layer (training): replaces DeclarativeNodeLie.gradient /
+ * _get_objective_derivatives (core/optimization/declerative_node_lie.py:13-82,106-126; called from
+ * DeclarativeFunctionLie.backward :249-267), which differentiates the objective twice with autograd, by the closed
+ * forms of fY, fYY and fXY^T u (csrc/pose_backward.hip).  Inputs as rpe_pose_reduce; T (n,7) f64 = the layer's output
+ * pose (the reference uses its float32 vec7).
+ *   rpe_pose_backward_moments: out (n,48) f64 = [g2u(6) | g3u(6) | H(6x6 row-major)]: tangent gradients of the
+ *       reprojection / 3-D terms with unit loss weight (fY = lw[1] g2u + lw[0] g3u; d fY/d loss_weight) and
+ *       H = (fYY + fYY^T)/2 as the reference forms it (:51).  workspace: rpe_pose_backward_workspace_bytes(n,h,w).
+ *   rpe_pose_backward_grads:   given u (n,6) f64 = -H^-1 v, writes fXY^T u for flow (n,2,h,w), pcl1, pcl2 (n,3,h,w),
+ *       w1, w2 (n,1,h,w), float32, NaN -> 0 (:76); any output pointer may be NULL.
+ * The 6x6 solve, the optimality test |fY| <= eps (:43-47) and d/d loss_weight = (u.g3u, u.g2u) stay on the host side. */
+size_t rpe_pose_backward_workspace_bytes(int n, int h, int w);
+int rpe_pose_backward_moments(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
+                              const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
+                              const double *T, int n, int h, int w, double *out, void *workspace, void *stream);
+int rpe_pose_backward_grads(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
+                            const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
+                            const double *T, const double *u, int n, int h, int w, float *grad_flow, float *grad_pcl1,
+                            float *grad_pcl2, float *grad_w1, float *grad_w2, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Stereo depth, back-projection, flow warps and the 1/8 stacks of the weight heads -- replaces
  * core/pose/pose_net.py:73-79 (depth from disparity, validity, proj), :104-108 (remap_from_flow x3,
  * remap_from_flow_nearest; core/interpol/flow_utils.py:4-26) and :110-113 (bilinear x0.125 of the two

@@ -37,8 +37,45 @@ def load_reference():
     node = types.ModuleType('core.ddn.ddn.pytorch.node')
 
     class AbstractDeclarativeNode:
+        """Stand-in for anucvml/ddn ``ddn/pytorch/node.py::AbstractDeclarativeNode`` (submodule core/ddn: EMPTY in the
+        checkout).  Only the plumbing the reference's own ``gradient()`` calls is restated from ddn's published source:
+        input splitting into differentiable leaves, the optimality test ``allclose(fY, 0, atol=eps)`` and the batched
+        Cholesky solve (LU fallback).  None of it changes numbers; the derivative code that runs is the reference's."""
+
         def __init__(self, eps=1e-12, gamma=None, chunk_size=None):
             self.eps, self.gamma, self.chunk_size = eps, gamma, chunk_size
+
+        def _split_inputs(self, xs):
+            xs_split, xs_sizes, xs_n = [], [], []
+            for x in xs:
+                if isinstance(x, torch.Tensor) and x.requires_grad:
+                    flat = x.reshape(self.b, -1)
+                    xs_split.append((flat,) if self.chunk_size is None else flat.split(self.chunk_size, dim=-1))
+                    xs_sizes.append(x.size())
+                    xs_n.append(flat.size(-1))
+                else:
+                    xs_split.append((x,))
+                    xs_sizes.append(None)
+                    xs_n.append(None)
+            return tuple(xs_split), tuple(xs_sizes), tuple(xs_n)
+
+        def _cat_inputs(self, xs_split, xs_sizes):
+            xs = []
+            for x_split, x_size in zip(xs_split, xs_sizes):
+                if x_size is None:
+                    xs.append(x_split[0])
+                else:
+                    xs.append(torch.cat(x_split, dim=-1).reshape(x_size))
+            return tuple(xs)
+
+        def _check_optimality_cond(self, fY):
+            return torch.allclose(fY, torch.zeros_like(fY), rtol=0.0, atol=self.eps)
+
+        def _solve_linear_system(self, A, B):
+            try:
+                return torch.cholesky_solve(B, torch.linalg.cholesky(A))
+            except Exception:
+                return torch.linalg.solve(A, B)
 
     class DeclarativeFunction(torch.autograd.Function):
         pass
@@ -228,10 +265,63 @@ def gen_metrics(R):
          rpe_trans=np.asarray(rpe_t), rpe_rot=np.asarray(rpe_r))
 
 
+def gen_backward(R):
+    """The reference's OWN implicit-differentiation backward (DeclarativeNodeLie.gradient,
+    core/optimization/declerative_node_lie.py:13-82, with _get_objective_derivatives :106-126 and the double-backward
+    Transform of core/geometry/pinhole_transforms.py:33-76) run on seeded inputs: gradients of a tangent-space loss
+    w.r.t. flow, pcl1, pcl2, w1, w2 and loss_weight, plus fY / fYY.  Stored for float64 inputs (tight comparison) and for
+    float32 inputs (what training feeds it)."""
+    from oracle import synth
+    ph, ose3, pt = R['ph'], R['se3'], R['pt']
+    for name, (seed, n, h, w, kw) in {'backward_a': (61, 2, 20, 28, dict()),
+                                      'backward_b': (62, 1, 16, 24, dict(outliers=False))}.items():
+        c = synth.solver_case(seed, n, h, w, **kw)
+        c['loss_weight'] = torch.tensor([[0.7, 1.3]]).repeat(n, 1)
+        args = synth.solver_args(c)
+        head = ph.DPoseSE3Head(pt.create_img_coords_t(h, w), lbgfs_iters=100)
+        layer = ph.DeclarativeLayerLie(head)
+        with torch.no_grad():
+            vec7, log6 = layer(*args)                        # the layer's forward: f32 vec7 of the L-BFGS solution
+        rng = np.random.default_rng(seed + 7)
+        v = torch.from_numpy(rng.normal(size=(n, 1, 6)))
+        out = {k: t for k, t in c.items()}
+        out.update(vec7=vec7, v=v)
+        for tag, dt in (('f64', torch.float64), ('f32', torch.float32)):
+            xs = []
+            for i, a in enumerate(args):
+                a = a.detach().clone()
+                if a.dtype in (torch.float32, torch.float64):
+                    a = a.to(dt)
+                    a.requires_grad_(i in (0, 1, 2, 3, 4, 8))        # flow, pcl1, pcl2, w1, w2, loss_weight (K: no grad, pose_net.py:39)
+                xs.append(a)
+            head2 = ph.DPoseSE3Head(pt.create_img_coords_t(h, w).to(dt), lbgfs_iters=100)
+            y = (ose3.LieGroupParameter(ose3.SE3(vec7.to(dt))),)
+            y[0].requires_grad_(True)
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter('always')
+                grads = head2.gradient(*xs, y=y, v=(v.to(dt),))
+            assert not wlist, [str(x.message) for x in wlist]     # optimality check passed, system solved
+            # fY, fYY as the reference builds them
+            head2.b, head2.m = n, 6
+            xs_split, xs_sizes, head2.n = head2._split_inputs(tuple(xs))
+            fY, fYY, _ = head2._get_objective_derivatives(head2._cat_inputs(xs_split, xs_sizes), y)
+            out.update({f'fY_{tag}': fY.detach(), f'fYY_{tag}': fYY.detach()})
+            for nm, g in zip(('flow', 'pcl1', 'pcl2', 'w1', 'w2', 'mask1', 'mask2', 'K', 'loss_weight'), grads):
+                if g is not None:
+                    out[f'g_{nm}_{tag}'] = g.detach()
+            print(name, tag, 'max|fY| %.2e' % float(fY.abs().max()), 'asym fYY %.2e' % float((fYY - fYY.transpose(1, 2)).abs().max()),
+                  {k: '%.2e' % float(out[k].abs().max()) for k in out if k.startswith('g_') and k.endswith(tag)})
+        save(name + '.npz', **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'backward':
+        gen_backward(R)
+        return
     gen_solver(R)
+    gen_backward(R)
     gen_kat(R)
     gen_warp(R)
     gen_geometry(R)

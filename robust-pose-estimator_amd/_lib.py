@@ -44,6 +44,9 @@ SIGNATURES = {
     'rpe_pose_reduce': (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_pose_solve': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rpe_pose_solve_opts': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rpe_pose_backward_workspace_bytes': (_sz, [_i, _i, _i]),
+    'rpe_pose_backward_moments': (_i, [_vp] * 10 + [_i, _i, _i, _vp, _vp, _vp]),
+    'rpe_pose_backward_grads': (_i, [_vp] * 11 + [_i, _i, _i] + [_vp] * 6),
     'rpe_depth_backproject_warp': (_i, [_vp] * 9 + [_i, _i, _i] + [_vp] * 9),
     'rpe_flow2depth': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_warp_taps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -143,6 +143,30 @@ def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mo
     return T, vec7, log6, info
 
 
+def pose_backward_moments(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, T):
+    """At pose T (n,7) f64: (g2u (n,6), g3u (n,6), H (n,6,6)) -- unit-loss-weight tangent gradients of the two terms
+    and the symmetrised fYY of the reference's backward (declerative_node_lie.py:40-51)."""
+    args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
+    T = _dev(T.reshape(n, 7), torch.float64, 'T')
+    out = torch.empty(n, 48, dtype=torch.float64, device=T.device)
+    ws = torch.empty(lib().rpe_pose_backward_workspace_bytes(n, h, w), dtype=torch.uint8, device=T.device)
+    check(lib().rpe_pose_backward_moments(*[ptr(a) for a in args], ptr(T), n, h, w, ptr(out), ptr(ws), stream_ptr()),
+          'rpe_pose_backward_moments')
+    return out[:, :6], out[:, 6:12], out[:, 12:].reshape(n, 6, 6)
+
+
+def pose_backward_grads(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, T, u, want):
+    """fXY^T u for the inputs named in ``want`` (subset of flow, pcl1, pcl2, w1, w2) -> dict of float32 tensors."""
+    args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
+    T = _dev(T.reshape(n, 7), torch.float64, 'T')
+    u = _dev(u.reshape(n, 6), torch.float64, 'u')
+    ch = dict(flow=2, pcl1=3, pcl2=3, w1=1, w2=1)
+    outs = {k: (torch.empty(n, c, h, w, dtype=torch.float32, device=T.device) if k in want else None) for k, c in ch.items()}
+    check(lib().rpe_pose_backward_grads(*[ptr(a) for a in args], ptr(T), ptr(u), n, h, w, ptr(outs['flow']), ptr(outs['pcl1']),
+                                        ptr(outs['pcl2']), ptr(outs['w1']), ptr(outs['w2']), stream_ptr()), 'rpe_pose_backward_grads')
+    return {k: v for k, v in outs.items() if v is not None}
+
+
 # ------------------------------------------------------------------------------------------------- geometry
 def depth_backproject_warp(stereo_flow2, time_flow, baseline, K, depth1, image1l, image2l, stereo_flow1, mask2,
                            want_pcl2=False):

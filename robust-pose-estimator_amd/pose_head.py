@@ -4,7 +4,9 @@ calls it (core/pose/pose_net.py:23,55,84; core/optimization/declerative_node_lie
 core/pose/pose_head.py:60-79), executed by ``rpe_pose_solve`` on the device with no host synchronisation.
 
 Differences from the reference, all documented in DESIGN.md:
-  * forward / inference only (the implicit-differentiation backward is out of scope)
+  * the backward (training) evaluates the implicit-differentiation formulas of
+    declerative_node_lie.py:13-82 in closed form on the device (csrc/pose_backward.hip) instead of differentiating the
+    objective twice with autograd; same gradients (golden: the reference's own backward), float64 arithmetic
   * a batch of n rows is n independent solves (what the reference does per frame; its n>1 coupling through a
     shared L-BFGS history only exists in training)
   * ``solver='gn'`` selects the Gauss-Newton mode of the same kernel
@@ -46,9 +48,63 @@ class DPoseSE3Head:
         return ops.pose_reduce(*xs, T.reshape(n, 7).double())['f']
 
     def solve(self, *xs):
+        xs = [x.detach() if isinstance(x, torch.Tensor) else x for x in xs]
         T, vec7, log6, info = ops.pose_solve(*xs, iters=self.lbgfs_iters, mode=self.mode)
         self.last_info = info
         return SE3(T[:, None]), (vec7, log6)
+
+    def gradient(self, *xs, y, v, needs=None, eps=1e-3):
+        """DeclarativeNodeLie.gradient (declerative_node_lie.py:13-82) at the layer's float32 output pose ``y`` (n,7) for
+        the incoming tangent gradient ``v`` (n,[1,]6): one gradient (or None) per input.  As the reference: all zeros
+        with a warning when the solver did not reach |fY| <= eps (:43-47) or the 6x6 system is not positive definite
+        (:59-63); NaNs in u and in the result are zeroed (:67,76)."""
+        import warnings
+        flow, pcl1, pcl2, w1, w2, mask1, mask2, K, lw = [x.detach() for x in xs]
+        n = flow.shape[0]
+        needs = [True] * 9 if needs is None else list(needs)
+        T = y.reshape(n, 7).double()
+        g2u, g3u, H = ops.pose_backward_moments(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, lw, T)
+        lwd = lw.double()
+        fY = lwd[:, 1:2] * g2u + lwd[:, 0:1] * g3u
+
+        def zeros():
+            return tuple(torch.zeros_like(x) if nd and x.is_floating_point() else None for x, nd in zip(xs, needs))
+        if not bool((fY.abs() <= eps).all()):
+            warnings.warn('Non-zero objective function gradient at y:\n{}'.format(fY.detach().squeeze().cpu().numpy()))
+            return zeros()
+        L, info = torch.linalg.cholesky_ex(H)
+        if bool((info != 0).any()):
+            warnings.warn('linear system is not positive definite ')
+            return zeros()
+        u = torch.cholesky_solve(-v.reshape(n, 6, 1).double(), L)[..., 0]
+        u = torch.where(torch.isnan(u), torch.zeros_like(u), u)
+        names = ('flow', 'pcl1', 'pcl2', 'w1', 'w2')
+        want = [nm for nm, nd in zip(names, needs[:5]) if nd]
+        g = ops.pose_backward_grads(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, lw, T, u, want) if want else {}
+        out = [g.get(nm) for nm in names] + [None, None, None, None]
+        if needs[8]:
+            glw = torch.stack(((u * g3u).sum(-1), (u * g2u).sum(-1)), dim=-1)
+            out[8] = torch.where(torch.isnan(glw), torch.zeros_like(glw), glw).to(lw.dtype)
+        return tuple(out)
+
+
+class DeclarativeFunctionLie(torch.autograd.Function):
+    """declerative_node_lie.py:211-267: forward = solve, outputs (vec7, log6) float32; backward = implicit
+    differentiation in tangent space, driven by the gradient that arrives on log6 (the vec7 gradient is ignored, :264)."""
+
+    @staticmethod
+    def forward(ctx, problem, *inputs):
+        with torch.no_grad():
+            _, (vec7, log6) = problem.solve(*inputs)
+        ctx.problem = problem
+        ctx.save_for_backward(vec7, *inputs)
+        return vec7[:, None].clone(), log6[:, None]   # (n,1,7), (n,1,6) float32 (:233-234)
+
+    @staticmethod
+    def backward(ctx, grad_vec7, grad_log6):
+        vec7, *inputs = ctx.saved_tensors
+        grads = ctx.problem.gradient(*inputs, y=vec7, v=grad_log6, needs=ctx.needs_input_grad[1:])
+        return (None, *grads)
 
 
 class DeclarativeLayerLie(torch.nn.Module):
@@ -56,7 +112,9 @@ class DeclarativeLayerLie(torch.nn.Module):
         super().__init__()
         self.problem = problem
 
-    @torch.no_grad()
     def forward(self, *inputs):
-        _, (vec7, log6) = self.problem.solve(*inputs)
+        if torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in inputs):
+            return DeclarativeFunctionLie.apply(self.problem, *inputs)
+        with torch.no_grad():
+            _, (vec7, log6) = self.problem.solve(*inputs)
         return vec7[:, None], log6[:, None]          # (n,1,7), (n,1,6) float32 (declerative_node_lie.py:233-234)

@@ -1,0 +1,115 @@
+"""GPU: backward of the declarative pose layer (rpe_pose_backward_moments / rpe_pose_backward_grads through the C ABI
+and the autograd wiring of rpe_amd.pose_head.DeclarativeLayerLie) against the gradients the reference's own
+DeclarativeNodeLie.gradient produced with autograd (tests/golden/backward_*.npz, oracle/gen_golden.py::gen_backward)
+and against the closed-form CPU oracle on a larger seeded case.  float64 arithmetic on both sides (gradients are
+returned as float32, the inputs' dtype): 1e-6 relative to each gradient's scale."""
+import warnings
+
+import pytest
+import torch
+
+from conftest import SOLVER_KEYS, load_golden
+from oracle import pose_grad, pose_head, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', ['backward_a', 'backward_b'])
+def test_moments_and_grads_match_reference_golden(rpe, name):
+    from rpe_amd import ops
+    g = load_golden(name + '.npz')
+    args = [g[k].cuda() for k in SOLVER_KEYS]
+    n = args[0].shape[0]
+    T = g['vec7'].reshape(n, 7).double().cuda()
+    g2u, g3u, H = ops.pose_backward_moments(*args, T)
+    lw = g['loss_weight'].double()
+    fY = lw[:, 1:2] * g2u.cpu() + lw[:, 0:1] * g3u.cpu()
+    assert float((fY - g['fY_f64']).abs().max()) < 1e-8
+    Href = 0.5 * (g['fYY_f64'] + g['fYY_f64'].transpose(1, 2))
+    assert float((H.cpu() - Href).abs().max()) < 1e-7 * float(Href.abs().max())
+    u = torch.linalg.solve(Href, -g['v'].reshape(n, 6, 1).double())[..., 0]
+    got = ops.pose_backward_grads(*args, T, u.cuda(), ['flow', 'pcl1', 'pcl2', 'w1', 'w2'])
+    for k, v in got.items():
+        ref = g[f'g_{k}_f64']
+        assert v.dtype == torch.float32 and v.shape == ref.shape
+        assert float((v.cpu().double() - ref).abs().max()) < 1e-6 * float(ref.abs().max()), k
+    only = ops.pose_backward_grads(*args, T, u.cuda(), ['w2'])
+    assert list(only) == ['w2'] and torch.equal(only['w2'], got['w2'])
+
+
+def test_layer_autograd_matches_reference_golden(rpe):
+    """The whole path a training step takes: layer forward (L-BFGS 100), a tangent-space loss, .backward()."""
+    from rpe_amd import pose_head as ph
+    g = load_golden('backward_a.npz')
+    xs = []
+    for i, k in enumerate(SOLVER_KEYS):
+        t = g[k].cuda()
+        if t.is_floating_point() and i in (0, 1, 2, 3, 4, 8):
+            t.requires_grad_(True)
+        xs.append(t)
+    layer = ph.DeclarativeLayerLie(ph.DPoseSE3Head(None, lbgfs_iters=100))
+    vec7, log6 = layer(*xs)
+    assert vec7.shape == (2, 1, 7) and log6.shape == (2, 1, 6) and log6.requires_grad
+    assert float((vec7.detach().cpu() - g['vec7']).abs().max()) < 1e-6          # same solution as the reference's forward
+    (log6 * g['v'].float().cuda()).sum().backward()                              # dL/dlog6 = v
+    for i, k in ((0, 'flow'), (1, 'pcl1'), (2, 'pcl2'), (3, 'w1'), (4, 'w2'), (8, 'loss_weight')):
+        ref = g[f'g_{k}_f64']
+        got = xs[i].grad
+        assert got is not None and got.shape == ref.shape, k
+        # the pose the backward is evaluated at is the GPU solve's float32 vec7 (1e-7 from the reference's): 1e-4 relative
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-4 * float(ref.abs().max()), k
+    assert xs[7].grad is None
+
+
+def test_backward_larger_case_matches_oracle_and_is_linear_in_v(rpe):
+    from rpe_amd import ops
+    c = synth.solver_case(71, 2, 96, 128)
+    c['loss_weight'] = torch.tensor([[1.0, 1.0], [0.3, 2.0]])
+    args = synth.solver_args(c)
+    To, _ = pose_head.lbfgs_solve(*args, iters=100, coupled=False)
+    vec7 = To.float()
+    v = torch.randn(2, 6, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    out, fY, fYY = pose_grad.layer_backward(*args, vec7, v)
+    dargs = [a.cuda() for a in args]
+    T = vec7.double().cuda()
+    g2u, g3u, H = ops.pose_backward_moments(*dargs, T)
+    Hs = 0.5 * (fYY + fYY.transpose(1, 2))
+    assert float((H.cpu() - Hs).abs().max()) < 1e-9 * float(Hs.abs().max())
+    u = torch.cholesky_solve(-v.reshape(2, 6, 1), torch.linalg.cholesky(Hs))[..., 0]
+    got = ops.pose_backward_grads(*dargs, T, u.cuda(), ['flow', 'pcl1', 'pcl2', 'w1', 'w2'])
+    for k, gv in got.items():
+        assert float((gv.cpu().double() - out[k]).abs().max()) < 1e-6 * float(out[k].abs().max()), k
+    twice = ops.pose_backward_grads(*dargs, T, (2 * u).cuda(), ['pcl1'])['pcl1']
+    assert torch.equal(twice, 2 * got['pcl1'])                                   # exactly linear in u (power of two)
+
+
+def test_backward_returns_zeros_when_solver_has_not_converged(rpe):
+    """declerative_node_lie.py:43-47 (the reference's 'more error-handling'): |fY| > 1e-3 -> warning, zero gradients."""
+    from rpe_amd import pose_head as ph
+    c = synth.solver_case(72, 1, 48, 64, sigma_t=0.05, sigma_r=0.1)
+    c['loss_weight'] = torch.tensor([[200.0, 200.0]])                            # large gradient at the 1-iteration iterate
+    xs = [a.cuda() for a in synth.solver_args(c)]
+    xs[3].requires_grad_(True)
+    layer = ph.DeclarativeLayerLie(ph.DPoseSE3Head(None, lbgfs_iters=1))
+    _, log6 = layer(*xs)
+    with pytest.warns(UserWarning, match='Non-zero objective'):
+        log6.sum().backward()
+    assert float(xs[3].grad.abs().max()) == 0.0
+
+
+def test_reference_backward_smoke(rpe):
+    """tests/unit_test_pose_head.py:55-67 of the reference restated: gradient of a supervised tangent loss w.r.t. the loss weights."""
+    from rpe_amd import pose_head as ph
+    from oracle import se3
+    c = synth.solver_case(12345, 5, 180, 180, sigma_t=0.01, sigma_r=0.01, noise=0.0, unit_weights=True, full_masks=True, outliers=False)
+    lw = torch.nn.Parameter(torch.tensor([[0.01, 1.0]]).repeat(5, 1).cuda())
+    c['loss_weight'] = lw
+    xs = [a if a is lw else a.cuda() for a in synth.solver_args(c)]
+    layer = ph.DeclarativeLayerLie(ph.DPoseSE3Head(None, lbgfs_iters=100))
+    poses = layer(*xs)[1]
+    target = se3.se3_log(se3.se3_exp(c['xi_gt'])).float().cuda()
+    loss = (poses[:, 0] - target).abs().sum() / 5
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                                           # converged: no optimality warning
+        grad_x, = torch.autograd.grad(loss, lw)
+    assert grad_x.shape == (5, 2) and bool(torch.isfinite(grad_x).all())

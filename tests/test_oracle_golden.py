@@ -141,3 +141,34 @@ def test_tartanair_ground_truth_pose_recovered():
     T, info = pose_head.lbfgs_solve(g['flow'], pcl1, g['pcl2w'], ones, ones, g['valid'], torch.ones_like(g['valid']),
                                     g['K'], torch.ones(1, 2), iters=20)
     assert float((se3.se3_matrix(T)[0] - g['rel_matrix']).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize('name', ['backward_a', 'backward_b'])
+def test_layer_backward_matches_reference_autograd(name):
+    """oracle.pose_grad (closed-form fY / fYY / fXY^T u) against gradients produced by the reference's OWN
+    DeclarativeNodeLie.gradient with autograd (oracle/gen_golden.py::gen_backward): float64 run tight, float32 run
+    (the dtype training feeds it) within float32 round-off of sums over the image."""
+    from oracle import pose_grad
+    g = load_golden(name + '.npz')
+    args = [g[k] for k in SOLVER_KEYS]
+    out, fY, fYY = pose_grad.layer_backward(*args, g['vec7'], g['v'])
+    assert float((fY - g['fY_f64']).abs().max()) < 1e-8
+    assert float((fYY - g['fYY_f64']).abs().max()) < 1e-7 * float(g['fYY_f64'].abs().max())
+    assert float((fYY - fYY.transpose(1, 2)).abs().max()) > 1e-7          # the reference's fYY is NOT symmetric (J is differentiated too)
+    for k, v in out.items():
+        ref = g[f'g_{k}_f64']
+        assert v.shape == ref.shape
+        assert float((v - ref).abs().max()) < 1e-7 * float(ref.abs().max()), k
+        ref32 = g[f'g_{k}_f32'].double()
+        assert float((v - ref32).abs().max()) < 2e-3 * float(ref.abs().max()), k
+
+
+def test_layer_backward_zero_when_not_converged():
+    """declerative_node_lie.py:43-47: |fY| > eps at the given pose -> warning and all-zero gradients."""
+    from oracle import pose_grad
+    g = load_golden('backward_b.npz')
+    args = [g[k] for k in SOLVER_KEYS]
+    ident = torch.tensor([[0, 0, 0, 0, 0, 0, 1.0]])
+    with pytest.warns(UserWarning, match='Non-zero objective'):
+        out, fY, _ = pose_grad.layer_backward(*args, ident, g['v'], eps=1e-9)
+    assert all(float(v.abs().max()) == 0.0 for v in out.values())
