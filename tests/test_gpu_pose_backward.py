@@ -37,28 +37,43 @@ def test_moments_and_grads_match_reference_golden(rpe, name):
     assert list(only) == ['w2'] and torch.equal(only['w2'], got['w2'])
 
 
-def test_layer_autograd_matches_reference_golden(rpe):
-    """The whole path a training step takes: layer forward (L-BFGS 100), a tangent-space loss, .backward()."""
+def _layer_grads(g, iters=100):
     from rpe_amd import pose_head as ph
-    g = load_golden('backward_a.npz')
     xs = []
     for i, k in enumerate(SOLVER_KEYS):
         t = g[k].cuda()
         if t.is_floating_point() and i in (0, 1, 2, 3, 4, 8):
             t.requires_grad_(True)
         xs.append(t)
-    layer = ph.DeclarativeLayerLie(ph.DPoseSE3Head(None, lbgfs_iters=100))
+    layer = ph.DeclarativeLayerLie(ph.DPoseSE3Head(None, lbgfs_iters=iters))
     vec7, log6 = layer(*xs)
-    assert vec7.shape == (2, 1, 7) and log6.shape == (2, 1, 6) and log6.requires_grad
-    assert float((vec7.detach().cpu() - g['vec7']).abs().max()) < 1e-6          # same solution as the reference's forward
     (log6 * g['v'].float().cuda()).sum().backward()                              # dL/dlog6 = v
+    return xs, vec7, log6
+
+
+def test_layer_autograd_matches_reference_golden(rpe):
+    """The whole path a training step takes: layer forward (L-BFGS 100), a tangent-space loss, .backward() -- against the
+    reference's own run of the same thing (n = 1: the reference's batched forward shares one L-BFGS history between rows)."""
+    g = load_golden('backward_b.npz')
+    xs, vec7, log6 = _layer_grads(g)
+    assert vec7.shape == (1, 1, 7) and log6.shape == (1, 1, 6) and log6.requires_grad
+    assert float((vec7.detach().cpu() - g['vec7']).abs().max()) < 1e-6          # same solution as the reference's forward
     for i, k in ((0, 'flow'), (1, 'pcl1'), (2, 'pcl2'), (3, 'w1'), (4, 'w2'), (8, 'loss_weight')):
         ref = g[f'g_{k}_f64']
         got = xs[i].grad
         assert got is not None and got.shape == ref.shape, k
-        # the pose the backward is evaluated at is the GPU solve's float32 vec7 (1e-7 from the reference's): 1e-4 relative
+        # the pose the backward is evaluated at is the GPU solve's float32 vec7 (~1e-7 from the reference's): 1e-4 relative
         assert float((got.cpu().double() - ref).abs().max()) < 1e-4 * float(ref.abs().max()), k
     assert xs[7].grad is None
+
+
+def test_layer_autograd_batch_rows_match_oracle_at_their_own_pose(rpe):
+    """n = 2 (independent rows on the GPU): gradients vs the closed-form oracle evaluated at the poses the GPU forward returned."""
+    g = load_golden('backward_a.npz')
+    xs, vec7, _ = _layer_grads(g)
+    out, _, _ = pose_grad.layer_backward(*[g[k] for k in SOLVER_KEYS], vec7.detach().cpu(), g['v'])
+    for i, k in ((0, 'flow'), (1, 'pcl1'), (2, 'pcl2'), (3, 'w1'), (4, 'w2'), (8, 'loss_weight')):
+        assert float((xs[i].grad.cpu().double() - out[k]).abs().max()) < 1e-5 * float(out[k].abs().max()), k
 
 
 def test_backward_larger_case_matches_oracle_and_is_linear_in_v(rpe):
