@@ -53,8 +53,45 @@ class PoseNet(nn.Module):
             return depth, flow, valid, dict(fmap=f[:n], cnet=cn)
         return depth, flow, valid
 
+    def forward(self, image1l, image2l, intrinsics, baseline, image1r, image2r, mask1=None, mask2=None, ret_confmap=False):
+        """The reference's TRAINING forward (core/pose/pose_net.py:28-58): both stereo depths, the temporal flow, the weight
+        maps and the declarative pose layer -> (log-pose (n,6), depth1, depth2[, (w2d, w3d)]).  Gradients reach what the
+        reference trains while the flow network is frozen (train.yaml: freeze_flow_steps; RAFT.eval() always): the two
+        weight heads and ``loss_weight``, through the layer's closed-form backward (csrc/pose_backward.hip).  Flow, depth
+        and the warps are computed by the (non-differentiable) HIP kernels, i.e. this mirrors the frozen-flow phase."""
+        n = image1l.shape[0]
+        intrinsics = intrinsics.expand(n, 3, 3).contiguous()
+        baseline = baseline.expand(n).contiguous()
+        with torch.no_grad():
+            depth1, stereo_flow1, valid1 = self.flow2depth(image1l, image1r, baseline)
+            mask1 = (mask1.bool() & valid1) if mask1 is not None else valid1
+            mask2 = mask2.bool().clone() if mask2 is not None else torch.ones_like(valid1)
+            s = self.stages(image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, heads=False)
+        if self.use_weights:
+            w2d = self.weight_head_2d(torch.cat((s['inp1'], s['hidden'], s['context']), dim=1))
+            w3d = self.weight_head_3d(torch.cat((s['inp1'], s['inp2'], s['hidden'], s['context']), dim=1))
+        else:
+            w2d, w3d = torch.ones_like(s['depth2']), torch.ones_like(s['depth2'])
+        _, log6 = self.pose_head(s['time_flow'], s['pcl1'], s['pcl2w'], w2d, w3d, mask1, s['mask2w'], s['intrinsics'],
+                                 self.loss_weight.repeat(n, 1))
+        pose_tan = log6.squeeze(1)
+        if ret_confmap:
+            return pose_tan, depth1, s['depth2'], (w2d, w3d)
+        return pose_tan, depth1, s['depth2']
+
+    def freeze_flow(self, freeze=True):
+        """pose_net.py:148-153.  Un-freezing the flow network needs its backward, which is not built (SURVEY.md 8f-4 covers the
+        declarative layer): refuse instead of training the heads against silently missing flow gradients."""
+        if not freeze:
+            raise NotImplementedError('training the flow network (freeze_flow(False)) is out of scope: RAFT has no backward here')
+        for p in self.parameters():
+            p.requires_grad = True
+        for p in self.flow.parameters():
+            p.requires_grad = False
+        return self
+
     @torch.no_grad()
-    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None):
+    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None, heads=True):
         """Every stage of infer() before the solve.  ``cache1`` = {'fmap','cnet'} of image1l from the previous call
         (streaming: frame t's image2l is frame t+1's image1l), so only the two new images are encoded."""
         n = image1l.shape[0]
@@ -81,7 +118,9 @@ class PoseNet(nn.Module):
         hidden, context = hidden[:n], context[:n]
         g = ops.depth_backproject_warp(stereo_flow2, time_flow, baseline, intrinsics, depth1, image1l, image2l,
                                        stereo_flow1, mask2)
-        if self.use_weights:
+        if not heads:
+            w2d = w3d = None
+        elif self.use_weights:
             w2d = self.weight_head_2d(torch.cat((g['inp1'], hidden, context), dim=1))
             w3d = self.weight_head_3d(torch.cat((g['inp1'], g['inp2'], hidden, context), dim=1))
         else:

@@ -2,11 +2,13 @@
 
 Host mirror of the reference's ``TinyUNet(in_channels, output_size)`` (core/unet/unet.py:80-82; architecture :7-77)
 with its parameter names (``encoder.enc_blocks.i.conv1/norm/conv2``, ``decoder.upconvs.i``, ``decoder.dec_blocks.i``,
-``head``) so checkpoints load unchanged.  Inference only: the batch norms run frozen and are folded, together with
+``head``) so checkpoints load unchanged.  Inference: the batch norms run frozen and are folded, together with
 the preceding conv bias, into one per-channel affine map applied by ``rpe_affine_act``:
     encoder stage : conv1 (no bias) -> [affine + ReLU]                 -> conv2            (conv-norm-relu-conv, :15-16)
     decoder stage : conv1 (no bias) -> [bias + ReLU] -> [affine]       -> conv2            (conv-relu-norm-conv, :18-20)
-The north star keeps the heads' convolutions on PyTorch-ROCm; they cost ~1 ms per 16-frame step."""
+The north star keeps the heads' convolutions on PyTorch-ROCm; they cost ~1 ms per 16-frame step.
+Training (gradients enabled): the same architecture on plain differentiable PyTorch-ROCm ops, batch norm in the module's
+train/eval state -- the heads are what the reference trains (scripts/train_posenet.py:97-136)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -53,8 +55,33 @@ class TinyUNet(nn.Module):
         self.head = nn.Conv2d(WIDTHS[0], 1, 1)
         self.out_sz = output_size
 
-    @torch.no_grad()
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_train(x)
+        with torch.no_grad():
+            return self.forward_infer(x)
+
+    def forward_train(self, x):
+        """core/unet/unet.py:7-77 on differentiable torch ops (encoder: conv-norm-relu-conv + max-pool; decoder: up-conv,
+        centre-cropped skip, conv-relu-norm-conv; 1x1 head; bilinear resize to the output size)."""
+        def bn(st, t):
+            n = st.norm
+            return F.batch_norm(t, n.running_mean, n.running_var, n.weight, n.bias, n.training, n.momentum, n.eps)
+        skips = []
+        for st in self.encoder.enc_blocks:
+            x = F.conv2d(torch.relu(bn(st, F.conv2d(x, st.conv1.weight, st.conv1.bias))), st.conv2.weight, st.conv2.bias)
+            skips.append(x)
+            x = F.max_pool2d(x, 2)
+        x = skips.pop()
+        for upc, st in zip(self.decoder.upconvs, self.decoder.dec_blocks):
+            x = F.conv_transpose2d(x, upc.weight, upc.bias, stride=2)
+            sk = skips.pop()
+            dh, dw = (sk.shape[-2] - x.shape[-2]) // 2, (sk.shape[-1] - x.shape[-1]) // 2
+            x = torch.cat((x, sk[..., dh:sk.shape[-2] - dh, dw:sk.shape[-1] - dw]), dim=1)
+            x = F.conv2d(bn(st, torch.relu(F.conv2d(x, st.conv1.weight, st.conv1.bias))), st.conv2.weight, st.conv2.bias)
+        return F.interpolate(F.conv2d(x, self.head.weight, self.head.bias), self.out_sz, mode='bilinear')
+
+    def forward_infer(self, x):
         skips = []
         for st in self.encoder.enc_blocks:
             scale, shift = st.folded_norm(with_conv_bias=True)

@@ -128,3 +128,43 @@ def test_reference_backward_smoke(rpe):
         warnings.simplefilter('error')                                           # converged: no optimality warning
         grad_x, = torch.autograd.grad(loss, lw)
     assert grad_x.shape == (5, 2) and bool(torch.isfinite(grad_x).all())
+
+
+def test_posenet_training_forward_and_backward(rpe):
+    """The reference's training step (core/pose/pose_net.py:28-58 + scripts/train_posenet.py:97-136) with the flow network
+    frozen: PoseNet.forward -> tangent pose -> L1 loss -> backward reaches both weight heads and loss_weight."""
+    from rpe_amd import pose_net, synth
+    from rpe_amd.se3 import SE3
+    h, w = 352, 384
+    cfg = synth.model_config(h, w, iters=12, lbgfs_iters=100)
+    model = synth.init_synthetic_weights(pose_net.PoseNet(cfg)).cuda()
+    fr = synth.stereo_frames(3, 2, h, w)
+    a = {k: v.cuda() for k, v in fr.items()}
+    # (1) eval mode: the differentiable head path equals the fused inference path, and forward() equals infer()
+    model.eval()
+    x = torch.randn(2, 264, h // 8, w // 8, device='cuda')
+    with torch.no_grad():
+        ref_map = model.weight_head_2d(x)
+    got_map = model.weight_head_2d(x.requires_grad_(True))
+    assert got_map.requires_grad and float((got_map - ref_map).abs().max()) < 1e-5
+    depth1, sflow1, valid1 = model.flow2depth(a['image1l'], a['image2r'], a['baseline'])      # any right image: only the plumbing matters
+    pose_tan, d1, d2, maps = model(a['image1l'], a['image2l'], a['K'], a['baseline'], a['image2r'], a['image2r'],
+                                   mask1=a['mask1'], mask2=a['mask2'], ret_confmap=True)
+    assert pose_tan.shape == (2, 6) and pose_tan.requires_grad and torch.equal(d1, depth1)
+    m1 = a['mask1'] & valid1
+    inf = model.infer(a['image1l'], a['image2l'], a['K'], a['baseline'], depth1, a['image2r'], m1, a['mask2'].clone(), sflow1)
+    assert float((SE3(inf.data).log() - pose_tan.detach()).abs().max()) < 1e-5
+    # (2) train mode (batch-norm statistics of the batch, as the reference trains): gradients arrive
+    model.train().freeze_flow(True)
+    assert not model.flow.training and not any(p.requires_grad for p in model.flow.parameters())
+    pose_tan, _, _ = model(a['image1l'], a['image2l'], a['K'], a['baseline'], a['image2r'], a['image2r'], mask1=a['mask1'], mask2=a['mask2'])
+    gt = torch.zeros_like(pose_tan)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        (pose_tan - gt).abs().sum().backward()
+    heads = [p for n_, p in model.named_parameters() if n_.startswith('weight_head')]
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in heads)
+    assert sum(float(p.grad.abs().sum()) for p in heads) > 0.0
+    assert model.loss_weight.grad is not None and bool(torch.isfinite(model.loss_weight.grad).all()) and float(model.loss_weight.grad.abs().sum()) > 0
+    with pytest.raises(NotImplementedError):
+        model.freeze_flow(False)
