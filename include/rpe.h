@@ -27,6 +27,7 @@ extern "C" {
 
 #define RPE_F32 0
 #define RPE_F64 1
+#define RPE_F16 2      /* rpe_corr_build_ex only: feature maps rounded to fp16 */
 
 /* solver modes of rpe_pose_solve */
 #define RPE_SOLVER_LBFGS 0 /* reference-faithful: torch.optim.LBFGS(lr=1, line_search_fn=None) iterates */
@@ -157,14 +158,20 @@ int rpe_warp_taps(const float *flow, int n, int h, int w, int32_t *x0, int32_t *
  * correlation / sqrt(C), 4-level 2x2 average-pool pyramid, radius-r bilinear window lookup), called from
  * RAFT.forward (call sites core/pose/pose_net.py:47,65,129).
  *
- * The pyramid is an opaque device buffer owned by the caller; its internal layout (8x4 tiles of f32 per
- * query) is private to build/lookup.
+ * The pyramid is an opaque device buffer owned by the caller; its internal layout (f32; the maps of 8 x-neighbouring
+ * queries interleaved and skewed) is private to build/lookup.
  * --------------------------------------------------------------------------------------------------------- */
 size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels);
 /* fmap1, fmap2: (b,c,h8,w8) f32.  Computes corr[b,q1,q2] = <fmap1[:,q1], fmap2[:,q2]> / sqrt(c) and the
  * average-pooled levels. */
 int rpe_corr_build(const float *fmap1, const float *fmap2, int b, int c, int h8, int w8, int levels,
                    void *pyramid, void *stream);
+/* Same with the precision of the feature maps selectable: feature_dtype = RPE_F32 (as rpe_corr_build) or RPE_F16 =
+ * "fp16 features" (BASELINE config 5; RAFT's mixed_precision encoders hand fp16 feature maps to corr.py, which calls
+ * .float() on them): both maps are rounded to fp16 (round to nearest even), the products run on the 16-bit matrix cores
+ * with f32 accumulation (exact products, f32 sums) and the pyramid stays f32.  c % 16 == 0. */
+int rpe_corr_build_ex(const float *fmap1, const float *fmap2, int b, int c, int h8, int w8, int levels, int feature_dtype,
+                      void *pyramid, void *stream);
 /* coords (b,2,h8,w8) f32 (channel 0 = x, 1 = y) -> out (b, levels*(2r+1)^2, h8, w8) f32, channel order
  * level-major then window index i*(2r+1)+j with x offset (i-r) and y offset (j-r) (upstream's transposed
  * window).  radius must be 4, levels <= 4. */

@@ -242,6 +242,10 @@ class RAFT(nn.Module):
         if config.get('small', False):
             raise NotImplementedError("RAFT-small is not on the reference's inference path (train.yaml:5 small: False)")
         self.config = config
+        # "fp16 features" (BASELINE config 5): the feature maps reach the correlation rounded to fp16 -- what upstream's
+        # mixed_precision autocast hands to corr.py before its .float().  The encoders themselves stay f32 on both sides, so
+        # the comparison with the HIP path (16-bit MFMA, f32 accumulation) differs by f32 summation order only.
+        self.mixed_precision = bool(config.get('mixed_precision', False))
         self.iters = int(config.get('iters', 12))
         self.hidden_dim = self.context_dim = 128
         self.corr_levels, self.corr_radius = 4, 4
@@ -260,6 +264,8 @@ class RAFT(nn.Module):
         image1 = 2 * (image1 / 255.0) - 1.0
         image2 = 2 * (image2 / 255.0) - 1.0
         fmap1, fmap2 = self.fnet([image1.contiguous(), image2.contiguous()])
+        if self.mixed_precision:
+            fmap1, fmap2 = fmap1.half(), fmap2.half()
         fmap1, fmap2 = fmap1.float(), fmap2.float()
         corr_fn = CorrBlock(fmap1, fmap2, num_levels=self.corr_levels, radius=self.corr_radius)
         cnet = self.cnet(image1)

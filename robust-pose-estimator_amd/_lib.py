@@ -52,6 +52,7 @@ SIGNATURES = {
     'rpe_warp_taps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rpe_corr_pyramid_bytes': (_sz, [_i, _i, _i, _i]),
     'rpe_corr_build': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_corr_build_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup_taps': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_corr_export_level': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -149,17 +149,68 @@ __device__ __forceinline__ void scatter_level(const float* __restrict__ src, int
     }
 }
 
-// A: (b, K, mp) fmap1 in group order;  B: (b, K, np) fmap2 in patch order.  grid = (nbands, mp/128, b).
-__global__ __launch_bounds__(256, 2) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
-                                                    int K, float scale, PyrGeom G) {
-    // main loop: As[2][BK][BM] | Bs[2][BK][BN] (32 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
-    __shared__ __attribute__((aligned(16))) float smem[64 * TP + 64 * 33 + 64 * 9 + 64 * 3];
-    float (*As)[BK][BM] = (float (*)[BK][BM])smem;
-    float (*Bs)[BK][BN] = (float (*)[BK][BN])(smem + 2 * BK * BM);
+// Epilogue of one 128 x 128 tile: one half (64 queries = the rows of the waves with wm == hh) at a time through LDS
+// (aliasing the operand tiles, which nobody reads after the K loop's last barrier), pooled to levels 1-3 and scattered.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* smem, float* __restrict__ pyr, const PyrGeom& G, float scale,
+                                               int bz, int m0, int band, int px, int tid) {
     float* T = smem;
     float* T1 = smem + 64 * TP;
     float* T2 = T1 + 64 * 33;
     float* T3 = T2 + 64 * 9;
+    const int lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    for (int hh = 0; hh < 2; ++hh) {
+        if (hh) __syncthreads();                              // half 0's scatter has read T..T3
+        if (wm == hh) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        T[row * TP + col] = acc[i][j][r] * scale;
+                    }
+                }
+        }
+        __syncthreads();
+        // 2x2 means in F.avg_pool2d's order: ((a + b) + c) + d, then * 0.25
+        for (int idx = tid; idx < 64 * 32; idx += 256) {      // level 1: 4 x 8 cells per query
+            const int q = idx >> 5, c1 = idx & 31;
+            const float* s = T + q * TP + (2 * (c1 >> 3)) * 16 + 2 * (c1 & 7);
+            T1[q * 33 + c1] = (((s[0] + s[1]) + s[16]) + s[17]) * 0.25f;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 64 * 8; idx += 256) {       // level 2: 2 x 4
+            const int q = idx >> 3, c2 = idx & 7;
+            const float* s = T1 + q * 33 + (2 * (c2 >> 2)) * 8 + 2 * (c2 & 3);
+            T2[q * 9 + c2] = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+        }
+        __syncthreads();
+        if (tid < 64 * 2) {                                   // level 3: 1 x 2
+            const int q = tid >> 1, c3 = tid & 1;
+            const float* s = T2 + q * 9 + 2 * c3;
+            T3[q * 3 + c3] = (((s[0] + s[1]) + s[4]) + s[5]) * 0.25f;
+        }
+        __syncthreads();
+        const int g0 = (m0 + hh * 64) >> 3;
+        scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
+        if (G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
+        if (G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
+        if (G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
+    }
+}
+
+#define SMEM_FLOATS (64 * TP + 64 * 33 + 64 * 9 + 64 * 3)
+
+// A: (b, K, mp) fmap1 in group order;  B: (b, K, np) fmap2 in patch order.  grid = (nbands, mp/128, b).
+__global__ __launch_bounds__(256, 2) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
+                                                    int K, float scale, PyrGeom G) {
+    // main loop: As[2][BK][BM] | Bs[2][BK][BN] (32 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float (*As)[BK][BM] = (float (*)[BK][BM])smem;
+    float (*Bs)[BK][BN] = (float (*)[BK][BN])(smem + 2 * BK * BM);
     const int bz = blockIdx.z, band = blockIdx.x;
     const int m0 = blockIdx.y * BM;
     const int M = G.mp, N = G.np;
@@ -213,52 +264,79 @@ __global__ __launch_bounds__(256, 2) void k_corr_build(const float* __restrict__
             }
             __syncthreads();
         }
-        // ---- epilogue, one half (64 queries = the rows of the waves with wm == hh) at a time.
-        // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        for (int hh = 0; hh < 2; ++hh) {
-            if (hh) __syncthreads();                              // half 0's scatter has read T..T3
-            if (wm == hh) {
+        build_epilogue(acc, smem, pyr, G, scale, bz, m0, band, px, tid);
+    }
+}
+
+// ---- BASELINE config 5 ("fp16 features + fp32 solve"): the feature maps are rounded to fp16 (what RAFT's mixed-precision
+// encoders hand to corr.py before its .float()), the correlation runs on the 16-bit matrix cores with f32 accumulation
+// (products of fp16 values are exact in f32) and the pyramid stays f32.  Operands are stored k4-interleaved,
+// (b, K/4, N', 4) halves, so that a lane's four consecutive k of v_mfma_f32_32x32x8_f16 are one 8-byte LDS read.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_permute_fmap_h(const float* __restrict__ f, half4* __restrict__ out, int C, int h8, int w8, int mode, int gx, int npx, int npad) {
+    const int np = blockIdx.x * blockDim.x + threadIdx.x;         // grid.y = b * C/4
+    if (np >= npad) return;
+    int y, x;
+    if (mode == 0) { const int g = np >> 3; y = g / gx; x = (g % gx) * 8 + (np & 7); }
+    else { const int t = np >> 7, r = np & 127; y = (t / npx) * 8 + (r >> 4); x = (t % npx) * 16 + (r & 15); }
+    const int bz = blockIdx.y / (C / 4), c4 = blockIdx.y % (C / 4);
+    half4 v = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    if (y < h8 && x < w8) {
+        const float* src = f + ((size_t)bz * C + 4 * c4) * h8 * w8 + (size_t)y * w8 + x;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+        for (int e = 0; e < 4; ++e) v[e] = (_Float16)src[(size_t)e * h8 * w8];      // round to nearest even, like tensor.half()
+    }
+    out[(size_t)blockIdx.y * npad + np] = v;
+}
+
+__global__ __launch_bounds__(256, 2) void k_corr_build_h(const half4* __restrict__ A, const half4* __restrict__ B, float* __restrict__ pyr,
+                                                         int K, float scale, PyrGeom G) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    half4 (*As)[BK / 4][BM] = (half4 (*)[BK / 4][BM])smem;                    // 2 x 4 x 128 x 8 B = 8 KB
+    half4 (*Bs)[BK / 4][BN] = (half4 (*)[BK / 4][BN])(smem + 2 * (BK / 4) * BM * 2);
+    const int bz = blockIdx.z, band = blockIdx.x;
+    const int m0 = blockIdx.y * BM;
+    const int M = G.mp, N = G.np, K4 = K / 4;
+    const half4* Ab = A + (size_t)bz * K4 * M;
+    const half4* Bb = B + (size_t)bz * K4 * N;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, lh = lane >> 5;
+    const int lk = tid >> 6, lc = (tid & 63) * 2;                 // loader: k-group lk, two consecutive columns (16 B)
+    const int nk = K / BK;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    for (int px = 0; px < G.npx; ++px) {
+        const int n0 = (band * G.npx + px) * BN;
+        f32x16 acc[2][2];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int col = wn * 64 + j * 32 + (lane & 31);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            T[row * TP + col] = acc[i][j][r] * scale;
-                        }
-                    }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        f32x4v ra = *(const f32x4v*)(Ab + (size_t)lk * M + m0 + lc), rb = *(const f32x4v*)(Bb + (size_t)lk * N + n0 + lc);
+        __syncthreads();                                          // the previous patch's epilogue is done with smem
+        *(f32x4v*)&As[0][lk][lc] = ra; *(f32x4v*)&Bs[0][lk][lc] = rb;
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                const int k4 = (kt + 1) * (BK / 4) + lk;
+                ra = *(const f32x4v*)(Ab + (size_t)k4 * M + m0 + lc); rb = *(const f32x4v*)(Bb + (size_t)k4 * N + n0 + lc);
             }
-            __syncthreads();
-            // 2x2 means in F.avg_pool2d's order: ((a + b) + c) + d, then * 0.25
-            for (int idx = tid; idx < 64 * 32; idx += 256) {      // level 1: 4 x 8 cells per query
-                const int q = idx >> 5, c1 = idx & 31;
-                const float* s = T + q * TP + (2 * (c1 >> 3)) * 16 + 2 * (c1 & 7);
-                T1[q * 33 + c1] = (((s[0] + s[1]) + s[16]) + s[17]) * 0.25f;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {                      // two k = 8 steps per BK = 16
+                const half4 a0 = As[cur][2 * st + lh][wm * 64 + l31], a1 = As[cur][2 * st + lh][wm * 64 + 32 + l31];
+                const half4 b0 = Bs[cur][2 * st + lh][wn * 64 + l31], b1 = Bs[cur][2 * st + lh][wn * 64 + 32 + l31];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x8f16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x8f16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x8f16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x8f16(a1, b1, acc[1][1], 0, 0, 0);
             }
+            if (kt + 1 < nk) { *(f32x4v*)&As[cur ^ 1][lk][lc] = ra; *(f32x4v*)&Bs[cur ^ 1][lk][lc] = rb; }
             __syncthreads();
-            for (int idx = tid; idx < 64 * 8; idx += 256) {       // level 2: 2 x 4
-                const int q = idx >> 3, c2 = idx & 7;
-                const float* s = T1 + q * 33 + (2 * (c2 >> 2)) * 8 + 2 * (c2 & 3);
-                T2[q * 9 + c2] = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
-            }
-            __syncthreads();
-            if (tid < 64 * 2) {                                   // level 3: 1 x 2
-                const int q = tid >> 1, c3 = tid & 1;
-                const float* s = T2 + q * 9 + 2 * c3;
-                T3[q * 3 + c3] = (((s[0] + s[1]) + s[4]) + s[5]) * 0.25f;
-            }
-            __syncthreads();
-            const int g0 = (m0 + hh * 64) >> 3;
-#ifndef CB_SCATTER_MASK
-#define CB_SCATTER_MASK 15                     // (kernel experiments: which levels the epilogue writes)
-#endif
-            if (CB_SCATTER_MASK & 1) scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
-            if ((CB_SCATTER_MASK & 2) && G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
-            if ((CB_SCATTER_MASK & 4) && G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
-            if ((CB_SCATTER_MASK & 8) && G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
         }
+        build_epilogue(acc, smem, pyr, G, scale, bz, m0, band, px, tid);
     }
 }
 
@@ -555,20 +633,35 @@ __global__ void k_corr_export(const float* __restrict__ pyr, float* __restrict__
     }
 }
 
-extern "C" int rpe_corr_build(const float* fmap1, const float* fmap2, int b, int c, int h8, int w8, int levels,
-                              void* pyramid, void* stream) {
+extern "C" int rpe_corr_build_ex(const float* fmap1, const float* fmap2, int b, int c, int h8, int w8, int levels, int feature_dtype,
+                                 void* pyramid, void* stream) {
     PyrGeom G;
+    if (feature_dtype != RPE_F32 && feature_dtype != RPE_F16) return RPE_E_BADARG;
     if (!fmap1 || !fmap2 || !pyramid || c <= 0 || c > 256 || c % BK != 0 || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
     if (((uintptr_t)pyramid) & 15) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     float* pyr = (float*)pyramid;
     float* Ap = pyr + G.total;                               // scratch behind the pyramid: (b, c, mp) then (b, c, np)
     float* Bp = Ap + (size_t)b * c * G.mp;
+    if (feature_dtype == RPE_F16) {                           // same scratch, half the bytes: (b, c/4, mp, 4) then (b, c/4, np, 4) halves
+        half4* Ah = (half4*)Ap;
+        half4* Bh = Ah + (size_t)b * (c / 4) * G.mp;
+        hipLaunchKernelGGL(k_permute_fmap_h, dim3(ceil_div(G.mp, 256), b * (c / 4)), dim3(256), 0, s, fmap1, Ah, c, h8, w8, 0, G.gx, G.npx, G.mp);
+        hipLaunchKernelGGL(k_permute_fmap_h, dim3(ceil_div(G.np, 256), b * (c / 4)), dim3(256), 0, s, fmap2, Bh, c, h8, w8, 1, G.gx, G.npx, G.np);
+        hipLaunchKernelGGL(k_corr_build_h, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, (const half4*)Ah, (const half4*)Bh, pyr, c,
+                           1.0f / sqrtf((float)c), G);
+        return rpe_check_launch();
+    }
     hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.mp, 256), b * c), dim3(256), 0, s, fmap1, Ap, h8, w8, 0, G.gx, G.npx, G.mp);
     hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.np, 256), b * c), dim3(256), 0, s, fmap2, Bp, h8, w8, 1, G.gx, G.npx, G.np);
     hipLaunchKernelGGL(k_corr_build, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, (const float*)Ap, (const float*)Bp, pyr, c,
                        1.0f / sqrtf((float)c), G);
     return rpe_check_launch();
+}
+
+extern "C" int rpe_corr_build(const float* fmap1, const float* fmap2, int b, int c, int h8, int w8, int levels,
+                              void* pyramid, void* stream) {
+    return rpe_corr_build_ex(fmap1, fmap2, b, c, h8, w8, levels, RPE_F32, pyramid, stream);
 }
 
 extern "C" int rpe_corr_lookup(const void* pyramid, const float* coords, int b, int h8, int w8, int levels, int radius,

@@ -218,12 +218,15 @@ class CorrPyramid:
             raise _lib.RpeError('rpe_corr_pyramid_bytes: unsupported geometry')
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
 
-    def build(self, fmap1, fmap2):
+    def build(self, fmap1, fmap2, fp16_features=False):
+        """``fp16_features``: BASELINE config 5 -- both maps are rounded to fp16 and correlated on the 16-bit matrix cores
+        with f32 accumulation; the pyramid stays f32."""
         f1, f2 = _dev(fmap1, torch.float32, 'fmap1'), _dev(fmap2, torch.float32, 'fmap2')
         b, c, h8, w8 = f1.shape
         if (b, h8, w8) != (self.b, self.h8, self.w8) or f2.shape != f1.shape:
             raise _lib.RpeError('corr build: shape mismatch')
-        check(lib().rpe_corr_build(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, ptr(self.buf), stream_ptr()), 'rpe_corr_build')
+        check(lib().rpe_corr_build_ex(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, 2 if fp16_features else 0, ptr(self.buf),
+                                      stream_ptr()), 'rpe_corr_build_ex')
         return self
 
     def lookup(self, coords, out=None):

@@ -395,6 +395,10 @@ class RAFT(nn.Module):
         if config.get('small', False):
             raise NotImplementedError("RAFT-small is not on the reference's inference path (train.yaml:5 small: False)")
         self.config = config
+        # upstream RAFT's ``mixed_precision`` runs the encoders under autocast, i.e. hands fp16 feature maps to the
+        # correlation (BASELINE config 5 "fp16 features").  Here the encoders stay f32 and the feature maps are rounded to
+        # fp16 where the correlation consumes them (16-bit matrix cores, f32 accumulation, f32 pyramid).
+        self.mixed_precision = bool(config.get('mixed_precision', False))
         self.iters = int(config.get('iters', 12))
         self.hidden_dim = self.context_dim = 128
         self.corr_levels, self.corr_radius = 4, 4
@@ -459,7 +463,7 @@ class RAFT(nn.Module):
             fmap1, fmap2 = f[:N], f[N:]
         else:
             fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
-        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float())
+        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision)
         if cnet is None:
             cnet = self.encode_context(image1)
         c = self.hidden_dim

@@ -68,10 +68,11 @@ def infer_args(s):
                 image2r=s['image2r'], mask1=s['mask1'], mask2=s['mask2'], stereo_flow1=s['stereo_flow1'])
 
 
-def model_config(h, w, iters=12, lbgfs_iters=8, solver='lbfgs', use_weights=True):
-    """The ``model`` section of configuration/train.yaml:1-9 of the reference + image shape / solver settings."""
+def model_config(h, w, iters=12, lbgfs_iters=8, solver='lbfgs', use_weights=True, mixed_precision=False):
+    """The ``model`` section of configuration/train.yaml:1-9 of the reference + image shape / solver settings.
+    ``mixed_precision`` (upstream RAFT's flag): fp16 feature maps into the correlation (BASELINE config 5)."""
     return dict(small=False, dropout=0.0, iters=iters, pose_scale=1.0, lbgfs_iters=lbgfs_iters, use_weights=use_weights,
-                image_shape=(h, w), solver=solver)
+                image_shape=(h, w), solver=solver, mixed_precision=mixed_precision)
 
 
 def init_synthetic_weights(model, seed=1234, flow_bias=-0.35):

@@ -239,3 +239,24 @@ def test_flow_head_last_layer(rpe):
         assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4)
         got2 = ops.conv3x3_to2(x.cuda(), wt.cuda(), bias.cuda(), add=coords.cuda()).cpu()
         assert torch.allclose(got2, coords + ref, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('b,h8,w8', [(2, 32, 40), (1, 17, 23), (1, 128, 160)])
+def test_fp16_feature_pyramid_matches_oracle(rpe, b, h8, w8):
+    """BASELINE config 5 ("fp16 features"): feature maps rounded to fp16, 16-bit MFMA with f32 accumulation, f32 pyramid --
+    against the oracle's f32 correlation of the SAME rounded maps (products of fp16 values are exact in f32, so only the
+    summation order differs), at the 1280x1024 geometry too."""
+    from rpe_amd import ops
+    f1, f2 = fmaps(50 + h8, b, h8, w8)
+    ref = oraft.CorrBlock(f1.half().float(), f2.half().float(), num_levels=4, radius=4)
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda(), fp16_features=True)
+    scale = float(ref.corr_pyramid[0].abs().max())
+    for l in (0, 3):
+        dense = pyr.export_level(l).cpu()
+        assert float((dense - ref.corr_pyramid[l][:, 0]).abs().max()) <= 2e-5 * scale, l
+    coords = coords_for(17, b, h8, w8, 3.0)
+    out = pyr.lookup(coords.cuda()).cpu()
+    assert float((out - ref(coords)).abs().max()) <= 4e-5 * scale
+    # and it really is a different (rounded) result than the f32 build
+    f32 = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda()).export_level(0).cpu()
+    assert float((f32 - pyr.export_level(0).cpu()).abs().max()) > 1e-4 * scale

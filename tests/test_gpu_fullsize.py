@@ -140,3 +140,29 @@ def test_rccl_all_gather_of_relative_poses(rpe):
         assert float((poses[1:] - ops.se3_chain(rel_all, scale=250.0)).abs().max()) == 0.0
     finally:
         dist.destroy_process_group()
+
+
+def test_config5_fp16_features_1280x1024(rpe):
+    """BASELINE config 5: 1280x1024 stereo, fp16 features + f32 (f64) solve.  The HIP path (feature maps rounded to fp16, 16-bit
+    MFMA correlation with f32 accumulation, everything else as the f32 path) against the oracle with the same rounding."""
+    from rpe_amd import pose_net, synth
+    h, w = 1024, 1280
+    cfg = synth.model_config(h, w, iters=12, lbgfs_iters=8, mixed_precision=True)
+    model = synth.init_synthetic_weights(pose_net.PoseNet(cfg)).eval().cuda()
+    assert model.flow.mixed_precision
+    om = opn.PoseNet(cfg)
+    om.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    om.eval()
+    assert om.flow.mixed_precision
+    _check_infer(model, om, synth, h, w, 1, seed=43)
+    # the rounding is visible: the f32 model gives a (slightly) different flow on the same frame
+    cfg32 = synth.model_config(h, w, iters=12, lbgfs_iters=8)
+    m32 = pose_net.PoseNet(cfg32)
+    m32.load_state_dict(model.state_dict())
+    m32.eval().cuda()
+    a = synth.infer_args(synth.stereo_frames(43, 1, h, w))
+    f16 = model.stages(**{k: v.cuda() for k, v in a.items()})['time_flow']
+    f32 = m32.stages(**{k: v.cuda() for k, v in a.items()})['time_flow']
+    d = float((f16 - f32).abs().max())
+    print(f'fp16-feature vs f32 flow: {d:.2e} px')
+    assert d > 1e-6
