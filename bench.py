@@ -50,6 +50,21 @@ def conv_roofline(events, steps):
             'tflop_per_step': flop / max(1, steps) / 1e12}
 
 
+def wino_roofline(events, steps):
+    """k_conv_wino (the update block's four 3x3 layers as Winograd F(2x2,3x3)): EXECUTED matrix FLOPs over HIP-event time
+    against the f32 MFMA peak (so frac <= 1); ``effective`` = the direct convolution's FLOPs over the same time."""
+    if not events:
+        return None
+    ms = sum(a.elapsed_time(b) for a, b, _, _ in events)
+    ex = sum(f for _, _, f, _ in events)
+    eff = sum(f for _, _, _, f in events)
+    tf = ex / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {'kernel': 'k_conv_wino', 'bound': 'mfma', 'achieved': tf, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tf / F32_MFMA_PEAK_TFLOPS, 'effective_tflops_direct_equivalent': eff / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+            'launches_per_step': len(events) // max(1, steps), 'ms_per_step': ms / max(1, steps),
+            'executed_tflop_per_step': ex / max(1, steps) / 1e12}
+
+
 def lookup_algorithmic_bytes(pairs, h8, w8, levels=4, r=4):
     """N_q * L * [(2r+2)^2 + (2r+1)^2] * 4 B + coords N_q * 8 B, per pair per launch."""
     nq = h8 * w8
@@ -278,6 +293,30 @@ def run_batch(args, rank, world, dev, dist):
 
     rpe_amd.ops.conv_fused = timed_conv            # raft.py calls it as ops.conv_fused
 
+    # the Winograd 3x3 layers (k_conv_wino): EXECUTED matrix FLOPs = 16 products per 2x2 output tile and (ci, co) pair,
+    # i.e. 4/9 of the direct form's; the direct-form count is kept separately as "effective"
+    wino_events = []
+    real_wino = rpe_amd.ops.conv_wino
+
+    def timed_wino(x, pw, *a, **k):
+        launch = real_wino(x, pw, *a, **k)
+        if not k.get('prepare'):
+            return launch
+        direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * pw.cin * pw.cout * 9
+
+        def timed_launch():
+            if not timing['on']:
+                return launch()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = launch()
+            e1.record()
+            wino_events.append((e0, e1, direct * 4.0 / 9.0, direct))
+            return r
+        return timed_launch
+
+    rpe_amd.ops.conv_wino = timed_wino
+
     def step():
         gpu_in['mask2'].copy_(mask2_init)          # infer() mutates mask2 in place, as the reference does
         return model.infer(**gpu_in, ret_details=True)
@@ -328,6 +367,7 @@ def run_batch(args, rank, world, dev, dist):
                      'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
         'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
         'roofline_conv': conv_roofline(conv_events, args.steps),
+        'roofline_conv_winograd': wino_roofline(wino_events, args.steps),
         'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
         'valid_fraction': float(gpu_in['mask2'].float().mean()),
         'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,

@@ -1,0 +1,305 @@
+// 3x3 stride-1 "same" convolutions of RAFT's update block as Winograd F(2x2, 3x3) on the f32 matrix cores.
+//
+// Replaces (reference's RAFT submodule, call sites core/pose/pose_net.py:47,65,129), twelve times per pass:
+//   core/RAFT/core/update.py  BasicMotionEncoder.convc2 (256->192), convf2 (128->64), conv (256->126), FlowHead.conv1 (128->256)
+//   each followed by bias + ReLU (+ the torch.cat / copy into the GRU input buffers), fused into the epilogue.
+// These four layers are 51 % of the multiply-adds of a GRU iteration.  As direct implicit GEMMs (conv.hip) they are bound
+// by the f32 matrix pipe; Winograd trades 2.25x fewer matrix FLOPs for cheap vector adds:
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        (Lavin & Gray 2016; correlation form, as torch.conv2d)
+//   per 2x2 output tile: d = the 4x4 input patch, g = the 3x3 filter; the 16 element-wise products over (ci) are 16
+//   independent GEMMs  M_p[co][tile] = sum_ci U_p[co][ci] V_p[ci][tile],  p = 0..15.
+// Exact in real arithmetic; in f32 the transforms add a few ulp (|G| <= 1, |B|, |A| in {0, +-1}); the parity tests keep
+// their f64-reference tolerances.
+//
+// Workgroup = 4 waves = 64 output channels x 32 tiles (a patch of 16 x 8 output pixels); wave = 32 channels x 16 tiles =
+// 2 blocks of v_mfma_f32_16x16x4_f32 per position, all 16 positions: 128 accumulator registers per lane, so a lane holds
+// every position of its (channel, tile) outputs and the output transform needs no cross-lane traffic.  K is walked in
+// steps of 4 input channels.  Per step the U slice 4 x 64 x 16 (weights pre-transformed once, L2-resident) and the raw
+// 4 x 10 x 18 input patch arrive by LDS-DMA, issued two / three steps ahead (measured: with register-staged loads issued
+// one step ahead the matrix pipe waited for L2 most of the time: 60 TFLOP/s executed against 104 with the loads removed);
+// two waves turn the raw patch into V 4 x 32 x 16 (B^T d B) for the next step.  The 16 positions of a (channel, output
+// channel | tile) row are contiguous, so a lane's fragments for four positions are one 16-B LDS read.
+#include "rpe_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WB_CO 64
+#define WB_TX 8
+#define WB_TY 4
+#define WB_NT (WB_TX * WB_TY)
+#define WK 4
+#define PS 20                // floats per (ci, tile) row of V in LDS: 16 positions + 4 pad (rows 80 B apart tile the 64 banks for 16
+                             // consecutive rows: the 16-B fragment reads, lane = row, are conflict-free)
+#define RAW_W (2 * WB_TX + 2)                                 // input patch of the workgroup: 18 x 10 pixels per channel
+#define RAW_H (2 * WB_TY + 2)
+#define RAW_CH (RAW_W * RAW_H)
+#define RAW_N (WK * RAW_CH)                                   // 720 dwords per step
+#define RAW_CHUNKS ((RAW_N + 63) / 64)                        // 12 LDS-DMA instructions of 64 dwords, 3 per wave
+#define RAW_BUF (RAW_CHUNKS * 64)
+#define U_STEP (WK * WB_CO * 16)                              // 4096 floats = 16 DMA instructions of 1 KB, 4 per wave
+#define DMA_PER_STEP (U_STEP / 256 / 4 + RAW_CHUNKS / 4)      // per wave: 4 + 3
+
+struct WinoP {
+    const float* x; long long xbs;
+    const float* wp; int cin, cout, coP, H, W;
+    const float* bias;
+    float* out; long long obs;
+    float* out2; long long o2bs;
+    int mode;
+};
+
+// LDS-DMA (global -> LDS without staging registers): every lane supplies its own global address, the destination is the
+// wave-uniform LDS byte address + lane * size.  Issued as inline asm ON PURPOSE: hipcc waits vmcnt(0) in front of every
+// LDS read while one of ITS loads-to-LDS is in flight (it cannot tell the buffers apart), which would serialise the
+// three-deep prefetch; these it does not count, and the kernel waits for them itself (s_waitcnt vmcnt(N), in order).
+#ifndef WINO_DMA_OFFS
+#define WINO_DMA_OFFS 1      // 1: one M0 set-up per group of DMAs, chunks addressed by the instruction offset (added to the global AND the LDS address)
+#endif
+// four 1 KB chunks: global gsrc + 1024 j  ->  LDS lds_addr + 1024 j + lane * 16
+__device__ __forceinline__ void dma16x4(const float* gsrc, unsigned lds_addr) {
+    unsigned keep;
+#if WINO_DMA_OFFS
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc + 256 * j), "s"(lds_addr + 1024u * j) : "memory");
+#endif
+}
+// three 256-B chunks of gathered dwords: lane's sources g0, g1, g2  ->  LDS lds_addr + 256 j + lane * 4
+__device__ __forceinline__ void dma4x3(const float* g0, const float* g1, const float* g2, unsigned lds_addr) {
+    unsigned keep;
+#if WINO_DMA_OFFS
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off offset:256\n\tglobal_load_lds_dword %3, off offset:512\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1 - 64), "v"(g2 - 128), "s"(lds_addr) : "memory");
+#else
+    const float* g[3] = {g0, g1, g2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g[j]), "s"(lds_addr + 256u * j) : "memory");
+#endif
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+__global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
+    __shared__ __attribute__((aligned(16))) float Us[3][U_STEP];             // [ci][co][position], as packed in global memory
+    __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
+    __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptx = (P.W + 2 * WB_TX - 1) / (2 * WB_TX);
+    const int x0 = (blockIdx.x % ptx) * (2 * WB_TX), y0 = (blockIdx.x / ptx) * (2 * WB_TY);
+    const int co0 = blockIdx.y * WB_CO, bz = blockIdx.z;
+    const int H = P.H, W = P.W, hw = H * W;
+    const float* xb = P.x + (size_t)bz * P.xbs;
+    const int nsteps = P.cin / WK;
+
+    // ---- DMA roles.  Raw patch: chunk c = 3*wave + j, element e = 64 c + lane -> (ci, row, col) of the 4 x 10 x 18 patch, read
+    // from the clamped pixel (the mask is applied when the patch is transformed).  U: chunk c = 4*wave + j, plain copy.
+    int roff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int e = (wv * 3 + j) * 64 + lane;
+        e = e < RAW_N ? e : RAW_N - 1;
+        const int ci = e / RAW_CH, rem = e - ci * RAW_CH, r = rem / RAW_W, c = rem - r * RAW_W;
+        int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        roff[j] = ci * hw + yy * W + xx;
+    }
+    const float* wslice = P.wp + (size_t)blockIdx.y * U_STEP + (size_t)(wv * 4) * 256 + lane * 4;      // [step][co tile][ci][co][16]
+    const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP;
+    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)(wv * 4) * 1024u, rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(wv * 3) * 256u;
+    auto issue_u = [&](int step, int buf) {
+        step = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat keeps 7 DMAs per step in flight)
+        dma16x4(wslice + (size_t)step * wstep, us_base + (unsigned)buf * (U_STEP * 4u));
+    };
+    auto issue_raw = [&](int step, int buf) {
+        step = step < nsteps ? step : nsteps - 1;
+        const float* src = xb + (size_t)step * WK * hw;
+        dma4x3(src + roff[0], src + roff[1], src + roff[2], rs_base + (unsigned)buf * (RAW_BUF * 4u));
+    };
+
+    // ---- transform role: thread -> (half, input channel of the step, tile).  V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0;
+    // 0 -1 1 0; 0 1 0 -1]; half 0 produces position rows 0-1 (from patch rows 0-2), half 1 rows 2-3 (from patch rows 1-3).
+    const int v_half = tid >> 7, v_ci = (tid >> 5) & 3, v_tile = tid & 31, v_tx = v_tile & 7, v_ty = v_tile >> 3;
+    unsigned okmask = 0;                          // which of the 3 x 4 patch pixels this thread reads lie inside the map (else zero padding)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int yy = y0 + 2 * v_ty - 1 + v_half + r, xx = x0 + 2 * v_tx - 1 + c;
+            okmask |= ((yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)) ? (1u << (r * 4 + c)) : 0u;
+        }
+    const int v_src = v_ci * RAW_CH + (2 * v_ty + v_half) * RAW_W + 2 * v_tx;
+    auto transform = [&](int rbuf, int vbuf) {
+        const float* rp = &Rs[rbuf][v_src];
+        float d[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? rp[r * RAW_W + c] : 0.0f;
+        // half 0: t0 = d0 - d2, t1 = d1 + d2 (patch rows 0,1,2);  half 1: t2 = d2 - d1, t3 = d1 - d3 (its rows 0,1,2 = patch rows 1,2,3)
+        float ta[4], tb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ta[c] = v_half ? d[4 + c] - d[c] : d[c] - d[8 + c];
+            tb[c] = v_half ? d[c] - d[8 + c] : d[4 + c] + d[8 + c];
+        }
+        const f32x4 va = {ta[0] - ta[2], ta[1] + ta[2], ta[2] - ta[1], ta[1] - ta[3]};
+        const f32x4 vb2 = {tb[0] - tb[2], tb[1] + tb[2], tb[2] - tb[1], tb[1] - tb[3]};
+        *(f32x4*)&Vs[vbuf][v_ci][v_tile][8 * v_half] = va;
+        *(f32x4*)&Vs[vbuf][v_ci][v_tile][8 * v_half + 4] = vb2;
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[p][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
+
+    // ---- prologue: U(0), U(1), raw(0..2) in flight; V(0) built
+    issue_u(0, 0); issue_u(1, 1); issue_raw(0, 0); issue_raw(1, 1); issue_raw(2, 2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    __syncthreads();
+    transform(0, 0);
+    __syncthreads();
+    // ---- step s: DMA U(s+2) and raw(s+3) | 32 MFMAs on U(s), V(s) | V(s+1) from raw(s+1) | everything older than this step's
+    // DMAs has landed (vmcnt counts in order) | barrier.  U(s) and raw(s+1) were issued two steps before they are read.
+    int ub = 0, rb = 0;                                       // s % 3
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        const int ub2 = ub == 0 ? 2 : ub - 1;                 // (s + 2) % 3
+#ifndef WINO_EXP
+#define WINO_EXP 0
+#endif
+        if (!(WINO_EXP & 1)) { issue_u(s + 2, ub2); issue_raw(s + 3, rb); }
+        // fragments: four positions per 16-B read; the reads of group g+1 are in flight while group g's 8 MFMAs issue
+        // U rows are 64 B with no padding (they arrive by 1 KB DMA chunks), so position group g of row r sits in 16-B slot
+        // g ^ ((r >> 2) & 3) (k_wino_pack stores it that way): the 16 rows of a fragment read then cover all 64 banks
+        const float* ua = &Us[ub][(lk * WB_CO + cw * 32 + li) * 16];
+        const int sw = (li >> 2) & 3;
+        const float* vb = &Vs[cur][lk][tw * 16 + li][0];
+        f32x4 fa0 = *(const f32x4*)(ua + 4 * sw), fa1 = *(const f32x4*)(ua + 16 * 16 + 4 * sw), fb = *(const f32x4*)(vb);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 na0 = fa0, na1 = fa1, nb = fb;
+            if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
+                acc[4 * g + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fa0 = na0; fa1 = na1; fb = nb;
+        }
+        const int rb1 = rb == 2 ? 0 : rb + 1;                 // (s + 1) % 3
+        if (s + 1 < nsteps && !(WINO_EXP & 2)) transform(rb1, cur ^ 1);
+        static_assert(DMA_PER_STEP == 7, "the wait below leaves exactly this step's DMAs outstanding");
+        if (WINO_EXP & 1) __builtin_amdgcn_s_waitcnt(0x0F70); else
+        __builtin_amdgcn_s_waitcnt(0x0F77);                   // vmcnt(7), lgkmcnt/expcnt untouched
+        __syncthreads();
+        ub = ub == 2 ? 0 : ub + 1; rb = rb1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // the repeats issued past the end have landed before LDS is released
+
+    // ---- epilogue.  D layout of the 16x16 MFMA: column (tile) = lane % 16, row (channel) = 4 * (lane / 16) + r.
+    // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; then bias, ReLU, and the store(s) into the channel slices.
+    const int tl = tw * 16 + li, ty = tl >> 3, tx = tl & 7;
+    const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
+    const bool pix_ok = (oy < H) & (ox < W);                        // (H, W even: a tile is inside or outside as a whole)
+    float* ob = P.out + (size_t)bz * P.obs;
+    float* ob2 = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+            float sa[4], sb[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                sa[nu] = (acc[0 * 4 + nu][cb][r] + acc[1 * 4 + nu][cb][r]) + acc[2 * 4 + nu][cb][r];
+                sb[nu] = (acc[1 * 4 + nu][cb][r] - acc[2 * 4 + nu][cb][r]) - acc[3 * 4 + nu][cb][r];
+            }
+            const float bi = (P.bias && co < P.cout) ? P.bias[co] : 0.0f;
+            float y00 = (sa[0] + sa[1]) + sa[2] + bi, y01 = (sa[1] - sa[2]) - sa[3] + bi;
+            float y10 = (sb[0] + sb[1]) + sb[2] + bi, y11 = (sb[1] - sb[2]) - sb[3] + bi;
+            if (P.mode == RPE_CONV_RELU) {                                   // NaN stays NaN, like torch.relu
+                y00 = y00 < 0.0f ? 0.0f : y00; y01 = y01 < 0.0f ? 0.0f : y01;
+                y10 = y10 < 0.0f ? 0.0f : y10; y11 = y11 < 0.0f ? 0.0f : y11;
+            }
+            if (pix_ok && co < P.cout) {
+                const size_t e = (size_t)co * hw + (size_t)oy * W + ox;
+                *(float2*)(ob + e) = make_float2(y00, y01);
+                *(float2*)(ob + e + W) = make_float2(y10, y11);
+                if (ob2) { *(float2*)(ob2 + e) = make_float2(y00, y01); *(float2*)(ob2 + e + W) = make_float2(y10, y11); }
+            }
+        }
+}
+
+// weight (cout, cin, 3, 3) -> U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], laid out
+// [step = ci/4][co tile = co/64][ci%4][co%64][16 positions, 4*xi + nu, in 16-B groups swizzled by the row]: a workgroup's slice
+// of a step is 16 KB contiguous (its LDS image)
+__global__ void k_wino_pack(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int coP, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int col = (int)((e >> 4) & 63), cil = (int)((e >> 10) & 3);
+    const int pos = (int)(((((e >> 2) & 3) ^ ((col >> 2) & 3)) << 2) | (e & 3));     // slot s of row `col` holds position group s ^ ((col >> 2) & 3)
+    const long long rest = e >> 12;
+    const int ncot = coP / WB_CO;
+    const int co = (int)(rest % ncot) * WB_CO + col, ci = (int)(rest / ncot) * WK + cil;
+    float v = 0.0f;
+    if (co < cout && ci < cin) {
+        const float* g = w + ((size_t)co * cin + ci) * 9;
+        const int xi = pos >> 2, nu = pos & 3;
+        // row xi of G applied to the columns of g, then row nu of G applied to the result
+        float col[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g0 = g[0 * 3 + c], g1 = g[1 * 3 + c], g2 = g[2 * 3 + c];
+            col[c] = xi == 0 ? g0 : xi == 1 ? 0.5f * ((g0 + g1) + g2) : xi == 2 ? 0.5f * ((g0 - g1) + g2) : g2;
+        }
+        v = nu == 0 ? col[0] : nu == 1 ? 0.5f * ((col[0] + col[1]) + col[2]) : nu == 2 ? 0.5f * ((col[0] - col[1]) + col[2]) : col[2];
+    }
+    wp[e] = v;
+}
+
+static inline int wino_cop(int cout) { return (cout + WB_CO - 1) / WB_CO * WB_CO; }
+
+extern "C" size_t rpe_conv_wino_packed_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cin % WK) return 0;
+    return (size_t)(cin / WK) * 16 * WK * wino_cop(cout);
+}
+
+extern "C" int rpe_conv_wino_pack(const float* weight, int cout, int cin, float* packed, void* stream) {
+    if (!weight || !packed || cout <= 0 || cin <= 0) return RPE_E_BADARG;
+    if (cin % WK) return RPE_E_UNSUPPORTED;
+    const long long total = (long long)rpe_conv_wino_packed_floats(cout, cin);
+    hipLaunchKernelGGL(k_wino_pack, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed, cout, cin, wino_cop(cout), total);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->packed || !d->out || d->b <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return RPE_E_BADARG;
+    if (d->kh != 3 || d->kw != 3 || (d->stride != 0 && d->stride != 1) || (d->cin % WK) || (d->h & 1) || (d->w & 1)) return RPE_E_UNSUPPORTED;
+    if (d->mode != RPE_CONV_LINEAR && d->mode != RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
+    if (d->add || d->scale || d->residual || d->stats || d->pre_norm || d->hidden || d->zgate) return RPE_E_UNSUPPORTED;
+    if ((((uintptr_t)d->packed) & 15) || (((uintptr_t)d->out) & 7) || (d->out_batch_stride & 1) ||
+        (d->out2 && ((((uintptr_t)d->out2) & 7) || (d->out2_batch_stride & 1)))) return RPE_E_UNSUPPORTED;
+    WinoP P;
+    P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed; P.cin = d->cin; P.cout = d->cout; P.coP = wino_cop(d->cout);
+    P.H = d->h; P.W = d->w; P.bias = d->bias; P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
+    P.mode = d->mode;
+    dim3 grid(ceil_div(d->w, 2 * WB_TX) * ceil_div(d->h, 2 * WB_TY), P.coP / WB_CO, d->b);
+    hipLaunchKernelGGL(k_conv_wino, grid, dim3(256), 0, (hipStream_t)stream, P);
+    return rpe_check_launch();
+}

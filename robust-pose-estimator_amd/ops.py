@@ -438,6 +438,58 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     return out
 
 
+class PackedWino:
+    """Weights of a 3x3 stride-1 convolution transformed for rpe_conv_wino (U = G g G^T, once per weight version)."""
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        n = lib().rpe_conv_wino_packed_floats(self.cout, self.cin) if (self.kh, self.kw) == (3, 3) else 0
+        if n == 0:
+            raise _lib.RpeError('PackedWino: needs a (cout, cin % 4 == 0, 3, 3) weight')
+        self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(lib().rpe_conv_wino_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv_wino_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(weight, hh, ww):
+        return tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 4 == 0 and hh % 2 == 0 and ww % 2 == 0
+
+
+def conv_wino(x, pw, mode, out, out2=None, prepare=False):
+    """rpe_conv_wino: out = act(conv3x3(x; pw) + bias) by Winograd F(2x2,3x3); tensors are channel slices of NCHW buffers."""
+    import ctypes
+    d = _lib.ConvDesc()
+    b, cin, hh, ww = x.shape
+    if cin != pw.cin:
+        raise _lib.RpeError(f'conv_wino: input has {cin} channels, weights expect {pw.cin}')
+    if mode not in (CONV_LINEAR, CONV_RELU):
+        raise _lib.RpeError('conv_wino: LINEAR / RELU epilogues only')
+    d.x, d.x_batch_stride = _chan_slice(x, 'x')
+    d.packed, d.bias = ptr(pw.packed), ptr(pw.bias)
+    for name, t in (('out', out), ('out2', out2)):
+        if t is None:
+            setattr(d, name, None); setattr(d, name + '_batch_stride', 0)
+            continue
+        if t.shape[0] != b or tuple(t.shape[2:]) != (hh, ww) or t.shape[1] < pw.cout:
+            raise _lib.RpeError(f'conv_wino: {name} has shape {tuple(t.shape)}')
+        p, s = _chan_slice(t, name)
+        setattr(d, name, p); setattr(d, name + '_batch_stride', s)
+    d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.stride = b, cin, pw.cout, hh, ww, 3, 3, mode, 1
+    if prepare:
+        fn, ref, keep = lib().rpe_conv_wino, ctypes.byref(d), (d, x, pw, out, out2)
+
+        def launch():
+            st = fn(ref, stream_ptr())
+            if st != 0:
+                check(st, 'rpe_conv_wino')
+            return keep[3]
+        launch.keep = keep
+        return launch
+    check(lib().rpe_conv_wino(ctypes.byref(d), stream_ptr()), 'rpe_conv_wino')
+    return out
+
+
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
     """Per-tile (count, mean, M2) records rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 3); hh, ww = input map."""
     return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 3, dtype=torch.float32, device=device)

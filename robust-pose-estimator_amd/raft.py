@@ -26,7 +26,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import ops
+
+WINOGRAD = os.environ.get('RPE_WINOGRAD', '1') != '0'      # 3x3 layers of the update block as F(2x2,3x3) (A/B switch for measurements)
 
 
 def _norm(kind, ch):
@@ -243,11 +247,16 @@ class BasicMotionEncoder(nn.Module):
             if calls is None or calls[0] != key:                      # descriptors checked once per buffer set (the 12 iterations reuse it)
                 cor = packed['cor_buf'](corr)
                 flo = packed['flo_buf'](corr)
+                wino = packed['wino'] if corr.shape[-1] % 2 == 0 and corr.shape[-2] % 2 == 0 else {}
+
+                def c3(name, x, out, out2=None):            # a 3x3 layer: Winograd when available, else the direct implicit GEMM
+                    if name in wino:
+                        return ops.conv_wino(x, wino[name], ops.CONV_RELU, out, out2=out2, prepare=True)
+                    return ops.conv_fused(x, packed[name], ops.CONV_RELU, out, out2=out2, prepare=True)
                 calls = (key, cor, flo,
                          ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, cor, prepare=True),
-                         ops.conv_fused(cor, packed['convc2'], ops.CONV_RELU, cat_buf[:, :192], prepare=True),
-                         ops.conv_fused(flo, packed['convf2'], ops.CONV_RELU, cat_buf[:, 192:], prepare=True),
-                         ops.conv_fused(cat_buf, packed['conv'], ops.CONV_RELU, hx[:, 128:254], out2=rhx[:, 128:254], prepare=True))
+                         c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
+                         c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
                 packed['_enc_calls'] = calls
             _, cor, flo_buf, c1, c2, f2, cv_ = calls
             c1(); c2()
@@ -323,6 +332,9 @@ class BasicUpdateBlock(nn.Module):
         if getattr(self, '_packed', None) is None or self._packed[0] != key:
             W = self.gate_weights()
             P = {n: ops.PackedConv(m.weight, m.bias) for n, m in zip(('convc1', 'convc2', 'convf2', 'conv', 'fh1'), mods)}
+            # the four 3x3 layers also in Winograd form (rpe_conv_wino: 2.25x fewer matrix FLOPs); used on even maps
+            P['wino'] = {n: ops.PackedWino(m.weight, m.bias) for n, m in zip(('convc2', 'convf2', 'conv', 'fh1'), mods[1:])
+                         if ops.PackedWino.supported(m.weight, 2, 2)} if WINOGRAD else {}
             P['convf1'] = ops.PackedStem(e.convf1.weight)
             for n in ('zr1', 'q1', 'zr2', 'q2'):
                 P[n] = ops.PackedConv(W[n][0])                # bias is part of the context term (context_terms)
@@ -359,7 +371,10 @@ class BasicUpdateBlock(nn.Module):
                     seq.append(ops.conv_fused(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
                                               prepare=True))
                     seq.append(ops.conv_fused(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
-                seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+                if 'fh1' in P['wino'] and hx.shape[-1] % 2 == 0 and hx.shape[-2] % 2 == 0:
+                    seq.append(ops.conv_wino(hx[:, :c], P['wino']['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+                else:
+                    seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
                 P['_gru_calls'] = calls = (key, seq)
             for launch in calls[1][:-1]:
                 launch()

@@ -364,3 +364,43 @@ def test_stem_statistics_survive_large_means(rpe):
     inv_ref = 1.0 / torch.sqrt(var + 1e-5)
     assert float(((mi[..., 0] - mean).abs() / mean.abs()).max()) < 1e-6
     assert float(((mi[..., 1] - inv_ref).abs() / inv_ref).max()) < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout,h,w,b', [(256, 192, 64, 80, 2), (128, 64, 64, 80, 1), (256, 126, 44, 48, 2), (128, 256, 32, 40, 1),
+                                            (8, 20, 6, 10, 3), (64, 64, 128, 160, 1)])
+def test_winograd_3x3_matches_f64(rpe, cin, cout, h, w, b):
+    """rpe_conv_wino (F(2x2,3x3) on the f32 matrix cores; the update block's convc2 / convf2 / conv / FlowHead.conv1 shapes, a
+    ragged one and the 1280x1024 grid) against the f64 convolution: same bar as the direct kernel, times 3 for the transforms.
+    Destinations are channel slices; out2 receives a copy; neighbours stay untouched."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, 3, 3, s=0.05), _rand(rng, cout, s=0.5)
+    assert ops.PackedWino.supported(wt, h, w)
+    pw = ops.PackedWino(wt.cuda(), bias.cuda())
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    obuf = torch.full((b, cout + 8, h, w), -7.0, device='cuda')
+    o2buf = torch.full((b, cout + 2, h, w), -7.0, device='cuda')
+    xbuf = torch.zeros(b, cin + 3, h, w, device='cuda')                      # the input is a channel slice too
+    xbuf[:, 3:] = x.cuda()
+    ops.conv_wino(xbuf[:, 3:], pw, ops.CONV_RELU, obuf[:, 4:4 + cout], out2=o2buf[:, 2:])
+    got = obuf[:, 4:4 + cout].cpu().double()
+    assert (got - ref.clamp_min(0)).abs().max() < 3 * _tol(x, wt)
+    assert torch.equal(obuf[:, 4:4 + cout], o2buf[:, 2:])
+    assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all() and (o2buf[:, :2] == -7.0).all()
+    lin = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda')).cpu().double()
+    assert (lin - ref).abs().max() < 3 * _tol(x, wt)
+    # the prepared launcher gives the same bits
+    out3 = torch.empty(b, cout, h, w, device='cuda')
+    ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, out3, prepare=True)()
+    assert torch.equal(out3.cpu().double(), lin)
+
+
+def test_winograd_rejects_what_it_cannot_do(rpe):
+    from rpe_amd import ops
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWino(torch.zeros(8, 6, 3, 3, device='cuda'))               # cin % 4
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWino(torch.zeros(8, 8, 1, 5, device='cuda'))
+    pw = ops.PackedWino(torch.zeros(8, 8, 3, 3, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
+        ops.conv_wino(torch.zeros(1, 8, 7, 12, device='cuda'), pw, ops.CONV_RELU, torch.empty(1, 8, 7, 12, device='cuda'))   # odd height

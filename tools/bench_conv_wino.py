@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Winograd F(2x2,3x3) (rpe_conv_wino) vs the direct implicit GEMM (rpe_conv_fused) on the update block's 3x3 shapes."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rpe_amd
+from rpe_amd import ops
+
+
+def t(fn, reps=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+dev = torch.device('cuda:0'); torch.manual_seed(0)
+N, H, W = int(os.environ.get('CONV_N', 32)), 64, 80
+with torch.no_grad():
+    for name, ci, co in (('convc2', 256, 192), ('convf2', 128, 64), ('conv', 256, 126), ('fh1', 128, 256)):
+        x = torch.randn(N, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05; bias = torch.randn(co, device=dev)
+        o1 = torch.empty(N, co, H, W, device=dev); o2 = torch.empty_like(o1)
+        pc, pw = ops.PackedConv(w, bias), ops.PackedWino(w, bias)
+        flop = 2.0 * N * H * W * ci * co * 9
+        td = t(lambda: ops.conv_fused(x, pc, ops.CONV_RELU, o1))
+        tw = t(lambda: ops.conv_wino(x, pw, ops.CONV_RELU, o2))
+        print('%-7s %3d->%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective)   maxdiff %.1e (|out| %.1f)' % (
+            name, ci, co, td, flop / td / 1e6, tw, flop / 2.25 / tw / 1e6, flop / tw / 1e6, (o1 - o2).abs().max().item(), o1.abs().max().item()))
