@@ -109,7 +109,7 @@ class SequenceTracker:
     def track(self, n_frames, rank=0, world=1, group=None, scale=None):
         """``scale`` defaults to the depth-clipping distance of the estimators this tracker builds."""
         from . import ops
-        est_scale = float(1.0 / self.make_estimator().scale)
+        est_scale = float(self.make_estimator().config['depth_clipping'][1])     # the distance PoseEstimator normalises by (pose_estimator.py:40-43)
         if scale is None:
             scale = est_scale
         elif abs(scale - est_scale) > 1e-6 * est_scale:
