@@ -270,12 +270,15 @@ size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
 /* weight (cout, cin, kh, kw) contiguous -> packed (tap-major 16-channel steps, output channels padded to 128) */
 int rpe_conv_pack(const float *weight, int cout, int cin, int kh, int kw, float *packed, void *stream);
 int rpe_conv_fused(const rpe_conv_desc *desc, void *stream);
-/* The same operation for 3x3 stride-1 convolutions with LINEAR / RELU epilogues (bias, out, out2 only; even h and w,
- * cin % 4 == 0) as Winograd F(2x2,3x3) on the f32 matrix cores: 2.25x fewer matrix FLOPs than the direct form
- * (csrc/conv_wino.hip; the update block's convc2, convf2, conv and FlowHead.conv1, core/RAFT/core/update.py).
- * desc->packed must come from rpe_conv_wino_pack (rpe_conv_wino_packed_floats floats; 0 = unsupported shape).
- * Anything else in the descriptor -> RPE_E_UNSUPPORTED (the caller uses rpe_conv_fused). */
+/* The same operation for 3x3 stride-1 convolutions with LINEAR / RELU epilogues (even h and w, cin % 4 == 0) as Winograd
+ * F(2x2,3x3) on the f32 matrix cores: 2.25x fewer matrix FLOPs than the direct form (csrc/conv_wino.hip; the update block's
+ * convc2, convf2, conv and FlowHead.conv1, core/RAFT/core/update.py, and the encoders' residual blocks,
+ * core/RAFT/core/extractor.py).  Supported descriptor fields: bias, scale, out, out2, residual, stats, pre_norm (cin <= 256
+ * with the last four); stats then has rpe_conv_wino_stats_tiles(h, w) records per plane.  desc->packed must come from
+ * rpe_conv_wino_pack (rpe_conv_wino_packed_floats floats; 0 = unsupported shape).  add / gates -> RPE_E_UNSUPPORTED
+ * (the caller uses rpe_conv_fused). */
 size_t rpe_conv_wino_packed_floats(int cout, int cin);
+int rpe_conv_wino_stats_tiles(int h, int w);
 int rpe_conv_wino_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv_wino(const rpe_conv_desc *desc, void *stream);
 /* number of pixel tiles (= moment records per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input);

@@ -67,6 +67,7 @@ SIGNATURES = {
     'rpe_conv_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'rpe_conv_fused': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_wino_packed_floats': (_sz, [_i, _i]),
+    'rpe_conv_wino_stats_tiles': (_i, [_i, _i]),
     'rpe_conv_wino_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),

@@ -46,6 +46,9 @@ struct WinoP {
     float* out; long long obs;
     float* out2; long long o2bs;
     int mode;
+    // encoder epilogues (ENC instantiation): v = acc * scale + bias; partial instance-norm moments of v; ReLU; residual + ReLU;
+    // and the input normalised + ReLU'd while it is transformed (pre: (b, cin, 2) = mean, 1/std of the previous convolution)
+    const float* scale; const float* res; long long rbs; float* stats; const float* pre;
 };
 
 // LDS-DMA (global -> LDS without staging registers): every lane supplies its own global address, the destination is the
@@ -90,10 +93,12 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+template <bool ENC>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __shared__ __attribute__((aligned(16))) float Us[3][U_STEP];             // [ci][co][position], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
     __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
+    __shared__ float Pn[ENC ? 2 * 256 : 2];                                  // ENC: (mean, 1/std) of every input channel (cin <= 256)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ptx = (P.W + 2 * WB_TX - 1) / (2 * WB_TX);
     const int x0 = (blockIdx.x % ptx) * (2 * WB_TX), y0 = (blockIdx.x / ptx) * (2 * WB_TY);
@@ -139,13 +144,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             okmask |= ((yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)) ? (1u << (r * 4 + c)) : 0u;
         }
     const int v_src = v_ci * RAW_CH + (2 * v_ty + v_half) * RAW_W + 2 * v_tx;
-    auto transform = [&](int rbuf, int vbuf) {
+    const bool pre = ENC && P.pre != nullptr;
+    if (pre) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
+        for (int i = tid; i < 2 * P.cin; i += 256) Pn[i] = P.pre[(size_t)bz * P.cin * 2 + i];
+    }
+    auto transform = [&](int step, int rbuf, int vbuf) {
         const float* rp = &Rs[rbuf][v_src];
         float d[12];
+        const float pm = pre ? Pn[2 * (step * WK + v_ci)] : 0.0f, pi = pre ? Pn[2 * (step * WK + v_ci) + 1] : 1.0f;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? rp[r * RAW_W + c] : 0.0f;
+            for (int c = 0; c < 4; ++c) {
+                float v = rp[r * RAW_W + c];
+                if (pre) { v = (v - pm) * pi; v = v < 0.0f ? 0.0f : v; }      // relu((x - mean) / std); padding stays zero (mask below)
+                d[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? v : 0.0f;
+            }
         // half 0: t0 = d0 - d2, t1 = d1 + d2 (patch rows 0,1,2);  half 1: t2 = d2 - d1, t3 = d1 - d3 (its rows 0,1,2 = patch rows 1,2,3)
         float ta[4], tb[4];
 #pragma unroll
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     issue_u(0, 0); issue_u(1, 1); issue_raw(0, 0); issue_raw(1, 1); issue_raw(2, 2);
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
     __syncthreads();
-    transform(0, 0);
+    transform(0, 0, 0);
     __syncthreads();
     // ---- step s: DMA U(s+2) and raw(s+3) | 32 MFMAs on U(s), V(s) | V(s+1) from raw(s+1) | everything older than this step's
     // DMAs has landed (vmcnt counts in order) | barrier.  U(s) and raw(s+1) were issued two steps before they are read.
@@ -178,10 +192,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         const int ub2 = ub == 0 ? 2 : ub - 1;                 // (s + 2) % 3
-#ifndef WINO_EXP
-#define WINO_EXP 0
-#endif
-        if (!(WINO_EXP & 1)) { issue_u(s + 2, ub2); issue_raw(s + 3, rb); }
+        issue_u(s + 2, ub2);
+        issue_raw(s + 3, rb);
         // fragments: four positions per 16-B read; the reads of group g+1 are in flight while group g's 8 MFMAs issue
         // U rows are 64 B with no padding (they arrive by 1 KB DMA chunks), so position group g of row r sits in 16-B slot
         // g ^ ((r >> 2) & 3) (k_wino_pack stores it that way): the 16 rows of a fragment read then cover all 64 banks
@@ -203,9 +215,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             fa0 = na0; fa1 = na1; fb = nb;
         }
         const int rb1 = rb == 2 ? 0 : rb + 1;                 // (s + 1) % 3
-        if (s + 1 < nsteps && !(WINO_EXP & 2)) transform(rb1, cur ^ 1);
+        if (s + 1 < nsteps) transform(s + 1, rb1, cur ^ 1);
         static_assert(DMA_PER_STEP == 7, "the wait below leaves exactly this step's DMAs outstanding");
-        if (WINO_EXP & 1) __builtin_amdgcn_s_waitcnt(0x0F70); else
         __builtin_amdgcn_s_waitcnt(0x0F77);                   // vmcnt(7), lgkmcnt/expcnt untouched
         __syncthreads();
         ub = ub == 2 ? 0 : ub + 1; rb = rb1;
@@ -213,37 +224,73 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // the repeats issued past the end have landed before LDS is released
 
     // ---- epilogue.  D layout of the 16x16 MFMA: column (tile) = lane % 16, row (channel) = 4 * (lane / 16) + r.
-    // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; then bias, ReLU, and the store(s) into the channel slices.
+    // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; then scale / bias, moments, ReLU, residual, and the store(s) into the channel slices.
     const int tl = tw * 16 + li, ty = tl >> 3, tx = tl & 7;
     const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
     const bool pix_ok = (oy < H) & (ox < W);                        // (H, W even: a tile is inside or outside as a whole)
     float* ob = P.out + (size_t)bz * P.obs;
     float* ob2 = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+    const float* rsb = (ENC && P.res) ? P.res + (size_t)bz * P.rbs : nullptr;
+    float* red = &Vs[0][0][0][0];                                   // [tile half][64 channels][4]: the K loop is done with V
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+            const int col = cw * 32 + cb * 16 + 4 * lk + r, co = co0 + col;
             float sa[4], sb[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 sa[nu] = (acc[0 * 4 + nu][cb][r] + acc[1 * 4 + nu][cb][r]) + acc[2 * 4 + nu][cb][r];
                 sb[nu] = (acc[1 * 4 + nu][cb][r] - acc[2 * 4 + nu][cb][r]) - acc[3 * 4 + nu][cb][r];
             }
-            const float bi = (P.bias && co < P.cout) ? P.bias[co] : 0.0f;
-            float y00 = (sa[0] + sa[1]) + sa[2] + bi, y01 = (sa[1] - sa[2]) - sa[3] + bi;
-            float y10 = (sb[0] + sb[1]) + sb[2] + bi, y11 = (sb[1] - sb[2]) - sb[3] + bi;
-            if (P.mode == RPE_CONV_RELU) {                                   // NaN stays NaN, like torch.relu
-                y00 = y00 < 0.0f ? 0.0f : y00; y01 = y01 < 0.0f ? 0.0f : y01;
-                y10 = y10 < 0.0f ? 0.0f : y10; y11 = y11 < 0.0f ? 0.0f : y11;
+            const bool cok = co < P.cout;
+            const float bi = (P.bias && cok) ? P.bias[co] : 0.0f;
+            float y[4] = {(sa[0] + sa[1]) + sa[2], (sa[1] - sa[2]) - sa[3], (sb[0] + sb[1]) + sb[2], (sb[1] - sb[2]) - sb[3]};
+            if (ENC && P.scale) { const float sc = cok ? P.scale[co] : 1.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] *= sc; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] += bi;
+            if (ENC && P.stats) {
+                // moments of v over this wave's 16 tiles x 4 pixels about a pivot (the wave's first value of the channel: valid
+                // whenever any of its tiles is, because tile 0 is the wave's top-left one), summed over the 16-lane row
+                const float piv = __shfl(y[0], lane & 48, 64);
+                float s1 = 0.0f, s2 = 0.0f, nn = pix_ok ? 4.0f : 0.0f;
+                if (pix_ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float dv = y[e] - piv; s1 += dv; s2 += dv * dv; }
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); nn += __shfl_xor(nn, o, 64); }
+                if (li == 0) { float* rr = red + (tw * WB_CO + col) * 4; rr[0] = s1; rr[1] = s2; rr[2] = piv; rr[3] = nn; }
             }
-            if (pix_ok && co < P.cout) {
-                const size_t e = (size_t)co * hw + (size_t)oy * W + ox;
-                *(float2*)(ob + e) = make_float2(y00, y01);
-                *(float2*)(ob + e + W) = make_float2(y10, y11);
-                if (ob2) { *(float2*)(ob2 + e) = make_float2(y00, y01); *(float2*)(ob2 + e + W) = make_float2(y10, y11); }
+            if (P.mode == RPE_CONV_RELU) {                                   // NaN stays NaN, like torch.relu
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = y[e] < 0.0f ? 0.0f : y[e];
+            }
+            if (pix_ok && cok) {
+                const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
+                if (rsb) {                                                   // ResidualBlock tail: relu(x + y)
+                    const float2 ra = *(const float2*)(rsb + e0), rb2 = *(const float2*)(rsb + e0 + W);
+                    y[0] += ra.x; y[1] += ra.y; y[2] += rb2.x; y[3] += rb2.y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = y[e] < 0.0f ? 0.0f : y[e];
+                }
+                *(float2*)(ob + e0) = make_float2(y[0], y[1]);
+                *(float2*)(ob + e0 + W) = make_float2(y[2], y[3]);
+                if (ob2) { *(float2*)(ob2 + e0) = make_float2(y[0], y[1]); *(float2*)(ob2 + e0 + W) = make_float2(y[2], y[3]); }
             }
         }
+    if (ENC && P.stats) {                                           // the two tile halves of a channel -> one (count, mean, M2) record
+        __syncthreads();
+        if (tid < WB_CO && co0 + tid < P.cout) {
+            StatAcc A;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) { const float* rr = red + (h2 * WB_CO + tid) * 4; A.add_pivoted((int)rr[3], rr[0], rr[1], rr[2]); }
+            float* st = P.stats + (((size_t)bz * P.cout + co0 + tid) * gridDim.x + blockIdx.x) * 3;
+            st[0] = (float)A.n; st[1] = (float)A.mean; st[2] = (float)A.m2;
+        }
+    }
 }
 
 // weight (cout, cin, 3, 3) -> U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], laid out
@@ -288,18 +335,26 @@ extern "C" int rpe_conv_wino_pack(const float* weight, int cout, int cin, float*
     return rpe_check_launch();
 }
 
+extern "C" int rpe_conv_wino_stats_tiles(int h, int w) {
+    return (h > 0 && w > 0) ? ceil_div(w, 2 * WB_TX) * ceil_div(h, 2 * WB_TY) : 0;
+}
+
 extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->packed || !d->out || d->b <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return RPE_E_BADARG;
     if (d->kh != 3 || d->kw != 3 || (d->stride != 0 && d->stride != 1) || (d->cin % WK) || (d->h & 1) || (d->w & 1)) return RPE_E_UNSUPPORTED;
     if (d->mode != RPE_CONV_LINEAR && d->mode != RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
-    if (d->add || d->scale || d->residual || d->stats || d->pre_norm || d->hidden || d->zgate) return RPE_E_UNSUPPORTED;
+    if (d->add || d->hidden || d->zgate) return RPE_E_UNSUPPORTED;
+    const bool enc = d->scale || d->residual || d->stats || d->pre_norm;
+    if (enc && (d->cin > 256 || (d->residual && ((((uintptr_t)d->residual) & 7) || (d->residual_batch_stride & 1))))) return RPE_E_UNSUPPORTED;
     if ((((uintptr_t)d->packed) & 15) || (((uintptr_t)d->out) & 7) || (d->out_batch_stride & 1) ||
         (d->out2 && ((((uintptr_t)d->out2) & 7) || (d->out2_batch_stride & 1)))) return RPE_E_UNSUPPORTED;
     WinoP P;
     P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed; P.cin = d->cin; P.cout = d->cout; P.coP = wino_cop(d->cout);
     P.H = d->h; P.W = d->w; P.bias = d->bias; P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.mode = d->mode;
+    P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats; P.pre = d->pre_norm;
     dim3 grid(ceil_div(d->w, 2 * WB_TX) * ceil_div(d->h, 2 * WB_TY), P.coP / WB_CO, d->b);
-    hipLaunchKernelGGL(k_conv_wino, grid, dim3(256), 0, (hipStream_t)stream, P);
+    if (enc) hipLaunchKernelGGL(k_conv_wino<true>, grid, dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(k_conv_wino<false>, grid, dim3(256), 0, (hipStream_t)stream, P);
     return rpe_check_launch();
 }

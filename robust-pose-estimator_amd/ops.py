@@ -456,8 +456,9 @@ class PackedWino:
         return tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 4 == 0 and hh % 2 == 0 and ww % 2 == 0
 
 
-def conv_wino(x, pw, mode, out, out2=None, prepare=False):
-    """rpe_conv_wino: out = act(conv3x3(x; pw) + bias) by Winograd F(2x2,3x3); tensors are channel slices of NCHW buffers."""
+def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=None, stats=None, pre_norm=None, prepare=False):
+    """rpe_conv_wino: out = epilogue(conv3x3(x; pw) * scale + bias) by Winograd F(2x2,3x3); tensors are channel slices of NCHW
+    buffers.  ``stats`` (conv_wino_stats_buffer) / ``pre_norm`` / ``residual`` / ``scale``: the encoders' epilogues, as conv_fused."""
     import ctypes
     d = _lib.ConvDesc()
     b, cin, hh, ww = x.shape
@@ -466,8 +467,12 @@ def conv_wino(x, pw, mode, out, out2=None, prepare=False):
     if mode not in (CONV_LINEAR, CONV_RELU):
         raise _lib.RpeError('conv_wino: LINEAR / RELU epilogues only')
     d.x, d.x_batch_stride = _chan_slice(x, 'x')
-    d.packed, d.bias = ptr(pw.packed), ptr(pw.bias)
-    for name, t in (('out', out), ('out2', out2)):
+    bias = pw.bias if isinstance(bias, str) else bias
+    for name, t in (('bias', bias), ('scale', scale)):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != pw.cout):
+            raise _lib.RpeError(f'conv_wino: {name} must be a contiguous float32 GPU vector of cout elements')
+    d.packed, d.bias, d.scale = ptr(pw.packed), ptr(bias), ptr(scale)
+    for name, t in (('out', out), ('out2', out2), ('residual', residual)):
         if t is None:
             setattr(d, name, None); setattr(d, name + '_batch_stride', 0)
             continue
@@ -475,9 +480,17 @@ def conv_wino(x, pw, mode, out, out2=None, prepare=False):
             raise _lib.RpeError(f'conv_wino: {name} has shape {tuple(t.shape)}')
         p, s = _chan_slice(t, name)
         setattr(d, name, p); setattr(d, name + '_batch_stride', s)
+    if stats is not None:
+        tiles = lib().rpe_conv_wino_stats_tiles(hh, ww)
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pw.cout, tiles, 3)):
+            raise _lib.RpeError(f'conv_wino: stats must be a contiguous float32 ({b},{pw.cout},{tiles},3) GPU tensor')
+    if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
+                                     and tuple(pre_norm.shape) == (b, cin, 2)):
+        raise _lib.RpeError(f'conv_wino: pre_norm must be a contiguous float32 ({b},{cin},2) GPU tensor')
+    d.stats, d.pre_norm = ptr(stats), ptr(pre_norm)
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.stride = b, cin, pw.cout, hh, ww, 3, 3, mode, 1
     if prepare:
-        fn, ref, keep = lib().rpe_conv_wino, ctypes.byref(d), (d, x, pw, out, out2)
+        fn, ref, keep = lib().rpe_conv_wino, ctypes.byref(d), (d, x, pw, out, out2, scale, bias, residual, stats, pre_norm)
 
         def launch():
             st = fn(ref, stream_ptr())
@@ -488,6 +501,11 @@ def conv_wino(x, pw, mode, out, out2=None, prepare=False):
         return launch
     check(lib().rpe_conv_wino(ctypes.byref(d), stream_ptr()), 'rpe_conv_wino')
     return out
+
+
+def conv_wino_stats_buffer(b, cout, hh, ww, device):
+    """Per-tile (count, mean, M2) records rpe_conv_wino fills when ``stats`` is given: (b, cout, tiles, 3)."""
+    return torch.empty(b, cout, lib().rpe_conv_wino_stats_tiles(hh, ww), 3, dtype=torch.float32, device=device)
 
 
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):

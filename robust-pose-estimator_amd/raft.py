@@ -65,16 +65,26 @@ class ResidualBlock(nn.Module):
         if fused_in:
             b, _, hh, ww = x.shape
             st = self.conv1.stride[0]
-            stats1 = ops.conv_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device, stride=st)
-            raw1 = ops.conv_fused(x, _packed(self.conv1), ops.CONV_LINEAR, torch.empty(b, self.conv1.out_channels, hh // st, ww // st, device=x.device),
-                                  bias=self.conv1.bias.detach(), stats=stats1, stride=st)
+            w1 = _wino(self.conv1, x)
+            raw1 = torch.empty(b, self.conv1.out_channels, hh // st, ww // st, device=x.device)
+            if w1 is not None:                                 # stride 1: Winograd, moments per 16x8-pixel patch
+                stats1 = ops.conv_wino_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device)
+                ops.conv_wino(x, w1, ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1)
+            else:
+                stats1 = ops.conv_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device, stride=st)
+                ops.conv_fused(x, _packed(self.conv1), ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1, stride=st)
             mi = ops.instnorm_finalize(stats1, (hh // st) * (ww // st), eps=self.norm1.eps)
             if self.downsample is not None:
                 x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
             ho, wo = raw1.shape[-2:]
-            stats2 = ops.conv_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
-            raw2 = ops.conv_fused(raw1, _packed(self.conv2), ops.CONV_LINEAR, torch.empty(b, self.conv2.out_channels, ho, wo, device=x.device),
-                                  bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
+            w2 = _wino(self.conv2, raw1)
+            raw2 = torch.empty(b, self.conv2.out_channels, ho, wo, device=x.device)
+            if w2 is not None:
+                stats2 = ops.conv_wino_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
+                ops.conv_wino(raw1, w2, ops.CONV_LINEAR, raw2, bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
+            else:
+                stats2 = ops.conv_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
+                ops.conv_fused(raw1, _packed(self.conv2), ops.CONV_LINEAR, raw2, bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
             return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x)
         y = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         if self.downsample is not None:
@@ -99,6 +109,19 @@ def _packed(conv):
     cached = getattr(conv, '_rpe_packed', None)
     if cached is None or cached[0] != key:
         conv._rpe_packed = cached = (key, ops.PackedConv(conv.weight, None))
+    return cached[1]
+
+
+def _wino(conv, x):
+    """PackedWino of a 3x3 stride-1 convolution when rpe_conv_wino can run it on this input (cached on the module), else None."""
+    if not WINOGRAD or conv.stride != (1, 1) or conv.kernel_size != (3, 3) or conv.padding != (1, 1):
+        return None
+    if not ops.PackedWino.supported(conv.weight, x.shape[-2], x.shape[-1]) or conv.in_channels > 256 or not x.is_contiguous():
+        return None
+    key = (conv.weight._version, conv.weight.data_ptr())
+    cached = getattr(conv, '_rpe_wino', None)
+    if cached is None or cached[0] != key:
+        conv._rpe_wino = cached = (key, ops.PackedWino(conv.weight, None))
     return cached[1]
 
 
@@ -128,12 +151,21 @@ def conv_norm_act(conv, norm, x, relu, residual=None):
         if norm.training:
             raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')
         scale, shift = _bn_affine(conv, norm)
+        pw = _wino(conv, x) if fused else None
+        if pw is not None:                                     # cnet's stride-1 3x3 layers: Winograd with the folded batch norm in the epilogue
+            out = torch.empty(b, conv.out_channels, hh, ww, device=x.device)
+            return ops.conv_wino(x, pw, ops.CONV_RELU if relu else ops.CONV_LINEAR, out, scale=scale, bias=shift, residual=residual)
         if fused:
             out = torch.empty(b, conv.out_channels, hh // stride, ww // stride, device=x.device)
             return ops.conv_fused(x, _packed(conv), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, scale=scale, bias=shift, residual=residual,
                                   stride=stride)
         return ops.affine_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), scale, shift, relu=relu, residual=residual)
     if isinstance(norm, nn.InstanceNorm2d):
+        pw = _wino(conv, x) if fused else None
+        if pw is not None:
+            stats = ops.conv_wino_stats_buffer(b, conv.out_channels, hh, ww, x.device)
+            pre = ops.conv_wino(x, pw, ops.CONV_LINEAR, torch.empty(b, conv.out_channels, hh, ww, device=x.device), bias=conv.bias.detach(), stats=stats)
+            return ops.instnorm_apply(pre, stats, eps=norm.eps, relu=relu, residual=residual)
         if fused:
             stats = ops.conv_stats_buffer(b, conv.out_channels, hh, ww, x.device, stride=stride)
             pre = ops.conv_fused(x, _packed(conv), ops.CONV_LINEAR, torch.empty(b, conv.out_channels, hh // stride, ww // stride, device=x.device),

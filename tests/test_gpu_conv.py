@@ -404,3 +404,40 @@ def test_winograd_rejects_what_it_cannot_do(rpe):
     pw = ops.PackedWino(torch.zeros(8, 8, 3, 3, device='cuda'))
     with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
         ops.conv_wino(torch.zeros(1, 8, 7, 12, device='cuda'), pw, ops.CONV_RELU, torch.empty(1, 8, 7, 12, device='cuda'))   # odd height
+
+
+@pytest.mark.parametrize('c,h,w,b', [(64, 64, 80, 3), (96, 44, 48, 2), (128, 32, 40, 2)])
+def test_winograd_encoder_epilogues_match_f64(rpe, c, h, w, b):
+    """The encoders' epilogues on the Winograd kernel: folded batch norm (scale, shift) + ReLU + residual + ReLU; instance-norm
+    moments per 16x8-pixel patch (-> rpe_instnorm_finalize / rpe_instnorm_apply); and the input normalised + ReLU'd while it
+    is transformed (pre_norm).  Same references and bars as test_encoder_block_epilogues_match_f64, times 3 for the transforms."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(c + h + 1)
+    x, wt, bias = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, s=0.5)
+    res = _rand(rng, b, c, h, w).abs()
+    scale, shift = _rand(rng, c).abs() + 0.5, _rand(rng, c, s=0.3)
+    pw = ops.PackedWino(wt.cuda(), None)
+    conv = F.conv2d(x.double(), wt.double(), None, padding=1)
+    ref = (res.double() + (conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]).clamp_min(0)).clamp_min(0)
+    got = ops.conv_wino(x.cuda(), pw, ops.CONV_RELU, torch.empty(b, c, h, w, device='cuda'), scale=scale.cuda(), bias=shift.cuda(), residual=res.cuda())
+    assert (got.cpu().double() - ref).abs().max() < 3 * _tol(x, wt) * 2.5
+    # instance norm of conv + bias from the per-patch moments
+    pre = conv + bias.double()[None, :, None, None]
+    mean, var = pre.mean((2, 3)), pre.var((2, 3), unbiased=False)
+    stats = ops.conv_wino_stats_buffer(b, c, h, w, 'cuda')
+    raw = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=stats)
+    assert (raw.cpu().double() - pre).abs().max() < 3 * _tol(x, wt)
+    st = stats.cpu().double()
+    assert float(st[..., 0].sum(-1).min()) == float(st[..., 0].sum(-1).max()) == h * w
+    mi = ops.instnorm_finalize(stats, h * w, eps=1e-5).cpu().double()
+    assert float((mi[..., 0] - mean).abs().max()) < 1e-5 and float((mi[..., 1] * torch.sqrt(var + 1e-5) - 1).abs().max()) < 2e-5
+    ref2 = (res.double() + ((pre - mean[:, :, None, None]) / torch.sqrt(var + 1e-5)[:, :, None, None]).clamp_min(0)).clamp_min(0)
+    got2 = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True, residual=res.cuda())
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert (got2.cpu().double() - ref2).abs().max() < (3 * _tol(x, wt) + 2e-6) * inv * 2
+    # pre_norm: conv(relu((x - m) * i)) with (m, i) per input plane
+    m_i = torch.stack((_rand(rng, b, c, s=0.3), _rand(rng, b, c).abs() + 0.5), dim=-1).contiguous()
+    xin = ((x.double() - m_i[..., 0].double()[:, :, None, None]) * m_i[..., 1].double()[:, :, None, None]).clamp_min(0)
+    ref3 = F.conv2d(xin, wt.double(), bias.double(), padding=1)
+    got3 = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), pre_norm=m_i.cuda())
+    assert (got3.cpu().double() - ref3).abs().max() < 3 * _tol(xin.float(), wt) + 1e-5
