@@ -294,6 +294,19 @@ int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, 
  * next rpe_conv_fused, which then normalises its input on the fly (no separate pass for norm1 + ReLU of a ResidualBlock). */
 int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw, float eps, float *mean_inv, void *stream);
 
+/* ---- The two weight heads of PoseNet (core/pose/pose_net.py:109-115: torch.cat of the 1/8 stacks with the GRU hidden
+ * state and the context -> TinyUNet(264) / TinyUNet(272), core/unet/unet.py:7-82 -> bilinear resize to (H, W) -> Sigmoid)
+ * as one chain of 15 launches for both heads and all frames (csrc/unet.hip), inference-mode batch norm folded.
+ *   inp1, inp2 (b,8,h8,w8) from rpe_depth_backproject_warp; hidden, context: channel 0 of (b,128,h8,w8) slices with their
+ *   batch strides (floats); params2d / params3d: rpe_unet_params_floats(264 / 272) floats in the layout documented in
+ *   csrc/unet.hip (3x3 weights as [cin][9][cout], batch norm as per-channel scale/shift); out2d, out3d (b,1,H,W) in (0,1).
+ *   The 1/8 grid must be at least 44x44 (valid convolutions), as in the reference; otherwise RPE_E_UNSUPPORTED. */
+size_t rpe_unet_params_floats(int in_channels);
+size_t rpe_unet_workspace_bytes(int b, int h8, int w8);
+int rpe_unet_heads(const float *inp1, const float *inp2, const float *hidden, const float *context, long long hidden_batch_stride,
+                   long long context_batch_stride, const float *params2d, const float *params3d, int b, int h8, int w8, int H, int W,
+                   float *out2d, float *out3d, void *workspace, void *stream);
+
 /* ---- 7x7 convolutions of few input channels as patch-staged implicit GEMMs (csrc/stem.hip):
  *   cin = 3, stride 2: the encoders' first layer (core/RAFT/core/extractor.py BasicEncoder.conv1/norm1/relu1) on the RAW
  *                      0..255 image with RAFT.forward's normalisation image = 2 * (image / 255) - 1 (core/RAFT/core/raft.py)

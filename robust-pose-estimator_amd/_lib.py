@@ -73,6 +73,9 @@ SIGNATURES = {
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
     'rpe_instnorm_finalize': (_i, [_vp, _i, _i, _i, _i, _c.c_float, _vp, _vp]),
+    'rpe_unet_params_floats': (_sz, [_i]),
+    'rpe_unet_workspace_bytes': (_sz, [_i, _i, _i]),
+    'rpe_unet_heads': (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rpe_stem_tiles': (_i, [_i, _i, _i]),
     'rpe_stem_packed_floats': (_sz, [_i, _i]),
     'rpe_stem_pack': (_i, [_vp, _i, _i, _vp, _vp]),

@@ -565,3 +565,27 @@ def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.
     check(lib().rpe_stem_conv(ptr(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), ptr(ps.packed), ps.cout, ptr(bias), ptr(scale),
                               int(bool(relu)), ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
     return (out, st) if stats else out
+
+
+# ------------------------------------------------------------------------------------------------- weight heads
+def unet_heads(inp1, inp2, hidden, context, params2d, params3d, out_size):
+    """Both TinyUNet weight heads + resize + sigmoid (rpe_unet_heads).  hidden / context may be channel slices of (b,128,..)."""
+    i1, i2 = _nchw(inp1, 'inp1'), _nchw(inp2, 'inp2')
+    b, _, h8, w8 = i1.shape
+    hp, hbs = _chan_slice(hidden, 'hidden')
+    cp, cbs = _chan_slice(context, 'context')
+    if tuple(i1.shape) != (b, 8, h8, w8) or tuple(i2.shape) != (b, 8, h8, w8) or tuple(hidden.shape) != (b, 128, h8, w8) or \
+            tuple(context.shape) != (b, 128, h8, w8):
+        raise _lib.RpeError('unet_heads: inp1, inp2 must be (b,8,h/8,w/8), hidden and context (b,128,h/8,w/8)')
+    for name, t, cin in (('params2d', params2d, 264), ('params3d', params3d, 272)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == lib().rpe_unet_params_floats(cin)):
+            raise _lib.RpeError(f'unet_heads: {name} must be the packed float32 parameter blob of TinyUNet({cin})')
+    nws = lib().rpe_unet_workspace_bytes(b, h8, w8)
+    if nws == 0:
+        raise _lib.RpeError('unet_heads: the 1/8 grid is too small for the valid convolutions (needs >= 44x44)')
+    H, W = out_size
+    ws = torch.empty(nws, dtype=torch.uint8, device=i1.device)
+    o2, o3 = (torch.empty(b, 1, H, W, dtype=torch.float32, device=i1.device) for _ in range(2))
+    check(lib().rpe_unet_heads(ptr(i1), ptr(i2), hp, cp, hbs, cbs, ptr(params2d), ptr(params3d), b, h8, w8, H, W, ptr(o2), ptr(o3), ptr(ws),
+                               stream_ptr()), 'rpe_unet_heads')
+    return o2, o3

@@ -15,7 +15,10 @@ from . import ops
 from .pose_head import DeclarativeLayerLie, DPoseSE3Head, create_img_coords_t
 from .raft import RAFT
 from .se3 import SE3
-from .unet import TinyUNet
+from .unet import TinyUNet, pack_params
+
+import os
+FUSED_HEADS = os.environ.get('RPE_FUSED_HEADS', '1') != '0'      # A/B switch: the heads on the HIP kernel chain vs PyTorch-ROCm + HIP epilogues
 
 
 class PoseNet(nn.Module):
@@ -120,6 +123,10 @@ class PoseNet(nn.Module):
                                        stereo_flow1, mask2)
         if not heads:
             w2d = w3d = None
+        elif self.use_weights and FUSED_HEADS and not (self.weight_head_2d.training or self.weight_head_3d.training):
+            # both heads + resize + sigmoid as one hand-written kernel chain (csrc/unet.hip), no concatenations
+            w2d, w3d = ops.unet_heads(g['inp1'], g['inp2'], hidden, context, pack_params(self.weight_head_2d[0]),
+                                      pack_params(self.weight_head_3d[0]), self.config['image_shape'])
         elif self.use_weights:
             w2d = self.weight_head_2d(torch.cat((g['inp1'], hidden, context), dim=1))
             w3d = self.weight_head_3d(torch.cat((g['inp1'], g['inp2'], hidden, context), dim=1))

@@ -44,6 +44,30 @@ class _Tree(nn.Module):
             setattr(self, k, v)
 
 
+def pack_params(net):
+    """The parameter blob rpe_unet_heads reads (layout: csrc/unet.hip): 3x3 weights as [cin][9][cout], transposed-conv weights as
+    [cin][4][cout], inference-mode batch norm as per-channel (scale, shift) -- after conv1 + bias in the encoder stages
+    (conv-norm-relu-conv), after the ReLU in the decoder stages (conv-relu-norm-conv).  Cached until a parameter changes."""
+    key = tuple(p._version for p in net.parameters()) + tuple(p.data_ptr() for p in net.parameters()) + \
+        tuple(b._version for b in net.buffers())
+    cached = getattr(net, '_rpe_blob', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    parts = []
+    w3 = lambda w: w.detach().permute(1, 2, 3, 0).reshape(-1)            # (cout,cin,3,3) -> [cin][9][cout]
+    for st in net.encoder.enc_blocks:
+        scale, shift = st.folded_norm(with_conv_bias=True)
+        parts += [w3(st.conv1.weight), scale, shift, w3(st.conv2.weight), st.conv2.bias.detach()]
+    for upc, st in zip(net.decoder.upconvs, net.decoder.dec_blocks):
+        scale, shift = st.folded_norm(with_conv_bias=False)
+        parts += [upc.weight.detach().permute(0, 2, 3, 1).reshape(-1), upc.bias.detach(),            # (cin,cout,2,2) -> [cin][4][cout]
+                  w3(st.conv1.weight), st.conv1.bias.detach(), scale, shift, w3(st.conv2.weight), st.conv2.bias.detach()]
+    parts += [net.head.weight.detach().reshape(-1), net.head.bias.detach().reshape(-1)]
+    blob = torch.cat([p.reshape(-1).float() for p in parts]).contiguous()
+    net._rpe_blob = (key, blob)
+    return blob
+
+
 class TinyUNet(nn.Module):
     def __init__(self, in_channels, output_size):
         super().__init__()
