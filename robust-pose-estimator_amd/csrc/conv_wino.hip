@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     if (pre) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
         for (int i = tid; i < 2 * P.cin; i += 256) Pn[i] = P.pre[(size_t)bz * P.cin * 2 + i];
     }
-    auto transform = [&](int step, int rbuf, int vbuf) {
+    // The transform of step s+1 is written as three slices (read + mask, column pass, row pass + store) so that the main loop can
+    // place them between its groups of matrix instructions: their vector / LDS work then issues in the shadow of the matrix pipe.
+    float td[12], tta[4], ttb[4];
+    auto tr_read = [&](int step, int rbuf) {
         const float* rp = &Rs[rbuf][v_src];
-        float d[12];
         const float pm = pre ? Pn[2 * (step * WK + v_ci)] : 0.0f, pi = pre ? Pn[2 * (step * WK + v_ci) + 1] : 1.0f;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -158,20 +160,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             for (int c = 0; c < 4; ++c) {
                 float v = rp[r * RAW_W + c];
                 if (pre) { v = (v - pm) * pi; v = v < 0.0f ? 0.0f : v; }      // relu((x - mean) / std); padding stays zero (mask below)
-                d[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? v : 0.0f;
+                td[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? v : 0.0f;
             }
+    };
+    auto tr_cols = [&]() {
         // half 0: t0 = d0 - d2, t1 = d1 + d2 (patch rows 0,1,2);  half 1: t2 = d2 - d1, t3 = d1 - d3 (its rows 0,1,2 = patch rows 1,2,3)
-        float ta[4], tb[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            ta[c] = v_half ? d[4 + c] - d[c] : d[c] - d[8 + c];
-            tb[c] = v_half ? d[c] - d[8 + c] : d[4 + c] + d[8 + c];
+            tta[c] = v_half ? td[4 + c] - td[c] : td[c] - td[8 + c];
+            ttb[c] = v_half ? td[c] - td[8 + c] : td[4 + c] + td[8 + c];
         }
-        const f32x4 va = {ta[0] - ta[2], ta[1] + ta[2], ta[2] - ta[1], ta[1] - ta[3]};
-        const f32x4 vb2 = {tb[0] - tb[2], tb[1] + tb[2], tb[2] - tb[1], tb[1] - tb[3]};
+    };
+    auto tr_store = [&](int vbuf) {
+        const f32x4 va = {tta[0] - tta[2], tta[1] + tta[2], tta[2] - tta[1], tta[1] - tta[3]};
+        const f32x4 vb2 = {ttb[0] - ttb[2], ttb[1] + ttb[2], ttb[2] - ttb[1], ttb[1] - ttb[3]};
         *(f32x4*)&Vs[vbuf][v_ci][v_tile][8 * v_half] = va;
         *(f32x4*)&Vs[vbuf][v_ci][v_tile][8 * v_half + 4] = vb2;
     };
+    auto transform = [&](int step, int rbuf, int vbuf) { tr_read(step, rbuf); tr_cols(); tr_store(vbuf); };
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -200,22 +206,28 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         const float* ua = &Us[ub][(lk * WB_CO + cw * 32 + li) * 16];
         const int sw = (li >> 2) & 3;
         const float* vb = &Vs[cur][lk][tw * 16 + li][0];
+        const int rb1 = rb == 2 ? 0 : rb + 1;                 // (s + 1) % 3
+        const int tstep = s + 1 < nsteps ? s + 1 : nsteps - 1;   // (last step: a redundant transform into the buffer nobody reads again)
         f32x4 fa0 = *(const f32x4*)(ua + 4 * sw), fa1 = *(const f32x4*)(ua + 16 * 16 + 4 * sw), fb = *(const f32x4*)(vb);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 na0 = fa0, na1 = fa1, nb = fb;
             if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
-            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) tr_read(tstep, rb1);
+            if (g == 1) tr_cols();
+            if (g == 3) tr_store(cur ^ 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
                 acc[4 * g + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][1], 0, 0, 0);
             }
+            // issue order inside this group: the LDS reads first, then each matrix instruction followed by a few vector ones
+            __builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
             __builtin_amdgcn_sched_barrier(0);
             fa0 = na0; fa1 = na1; fb = nb;
         }
-        const int rb1 = rb == 2 ? 0 : rb + 1;                 // (s + 1) % 3
-        if (s + 1 < nsteps) transform(s + 1, rb1, cur ^ 1);
         static_assert(DMA_PER_STEP == 7, "the wait below leaves exactly this step's DMAs outstanding");
         __builtin_amdgcn_s_waitcnt(0x0F77);                   // vmcnt(7), lgkmcnt/expcnt untouched
         __syncthreads();

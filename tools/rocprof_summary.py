@@ -13,7 +13,7 @@ def from_db(path, last_step):
     if last_step:
         starts = [r[0] for r in c.execute(
             "select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id "
-            "where s.kernel_name like '%k_permute_fmap2%' order by d.start")]
+            "where s.kernel_name like '%k_permute_fmap%' order by d.start")]
         if starts:
             where, args = 'where d.start>=?', (starts[-1],)
     if last_step == 'full':   # everything between the last two k_pose_finalize launches = one whole bench step
