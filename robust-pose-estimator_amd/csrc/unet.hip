@@ -14,7 +14,7 @@
 // (3x3 weights tap-major per input channel with the output channels contiguous: uniform across a workgroup -> scalar loads.)
 #include "rpe_common.h"
 
-#define UT 16                 // output channels per thread
+#define UT 16                 // output channels per thread (up-convolution; the 3x3 kernel is instantiated for 16 and 4)
 
 struct USrc { const float* p; long long bs; int c, h, w, oy, ox; };        // (b, c, h, w) read at (y + oy, x + ox)
 struct UConvHead {
@@ -24,8 +24,11 @@ struct UConvHead {
 };
 struct UConvP { UConvHead hd[2]; int b, ho, wo, relu_first, relu_last; };
 
-// valid 3x3 convolution, thread = output pixel x UT output channels:  v = acc + bias; [ReLU]; v = v * scale + shift; [ReLU]
+// valid 3x3 convolution, thread = output pixel x CT output channels:  v = acc + bias; [ReLU]; v = v * scale + shift; [ReLU]
+// (CT = 4 when 16 channels per thread would leave most of the chip idle: one frame pair of sequential tracking)
+template <int CT>
 __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
+    constexpr int UT = CT;
     const int head = blockIdx.z / P.b, bz = blockIdx.z % P.b;
     const UConvHead& H = P.hd[head];
     const int co0 = blockIdx.y * UT;
@@ -168,6 +171,14 @@ static bool unet_geo(int h8, int w8, Geo& g) {
     return true;
 }
 
+static void launch_conv3(const UConvP& P, int cout, int b, hipStream_t s) {
+    const int tiles = ceil_div(P.ho * P.wo, 256);
+    if ((long long)tiles * (cout / 16) * 2 * b < 512)
+        hipLaunchKernelGGL(k_u_conv3<4>, dim3(tiles, cout / 4, 2 * b), dim3(256), 0, s, P);
+    else
+        hipLaunchKernelGGL(k_u_conv3<16>, dim3(tiles, cout / 16, 2 * b), dim3(256), 0, s, P);
+}
+
 extern "C" size_t rpe_unet_params_floats(int in_channels) {
     if (in_channels <= 0) return 0;
     size_t n = 0;
@@ -232,8 +243,8 @@ extern "C" int rpe_unet_heads(const float* inp1, const float* inp2, const float*
             bb.src[0] = USrc{mid[hd], (long long)c * g.h[i] * g.w[i], c, g.h[i], g.w[i], 0, 0}; bb.nsrc = 1;
             bb.w = w2; bb.bias = b2; bb.scale = nullptr; bb.shift = nullptr; bb.out = skip[hd][i]; bb.cout = c;
         }
-        hipLaunchKernelGGL(k_u_conv3, dim3(ceil_div(A.ho * A.wo, 256), c / UT, 2 * b), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(k_u_conv3, dim3(ceil_div(B.ho * B.wo, 256), c / UT, 2 * b), dim3(256), 0, s, B);
+        launch_conv3(A, c, b, s);
+        launch_conv3(B, c, b, s);
         if (i < 2) {
             ch = g.hs[i] / 2; cw = g.ws[i] / 2;
             for (int hd = 0; hd < 2; ++hd) {
@@ -268,8 +279,8 @@ extern "C" int rpe_unet_heads(const float* inp1, const float* inp2, const float*
             cur[hd] = dout;
         }
         hipLaunchKernelGGL(k_u_upconv, dim3(ceil_div(ch * cw, 256), c2 / UT, 2 * b), dim3(256), 0, s, U);
-        hipLaunchKernelGGL(k_u_conv3, dim3(ceil_div(A.ho * A.wo, 256), c2 / UT, 2 * b), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(k_u_conv3, dim3(ceil_div(B.ho * B.wo, 256), c2 / UT, 2 * b), dim3(256), 0, s, B);
+        launch_conv3(A, c2, b, s);
+        launch_conv3(B, c2, b, s);
         ch = g.dh[j]; cw = g.dw[j];
     }
     UHeadP Hp{}; Hp.b = b; Hp.npix = ch * cw;
