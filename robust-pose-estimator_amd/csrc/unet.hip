@@ -28,18 +28,17 @@ struct UConvP { UConvHead hd[2]; int b, ho, wo, relu_first, relu_last; };
 // (CT = 4 when 16 channels per thread would leave most of the chip idle: one frame pair of sequential tracking)
 template <int CT>
 __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
-    constexpr int UT = CT;
     const int head = blockIdx.z / P.b, bz = blockIdx.z % P.b;
     const UConvHead& H = P.hd[head];
-    const int co0 = blockIdx.y * UT;
+    const int co0 = blockIdx.y * CT;
     if (co0 >= H.cout) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int npix = P.ho * P.wo;
     const bool ok = p < npix;
     const int y = ok ? p / P.wo : 0, x = ok ? p - (p / P.wo) * P.wo : 0;
-    float acc[UT];
+    float acc[CT];
 #pragma unroll
-    for (int j = 0; j < UT; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < CT; ++j) acc[j] = 0.0f;
     const float* wp = H.w + co0;
     for (int s = 0; s < H.nsrc; ++s) {
         const USrc S = H.src[s];
@@ -55,14 +54,14 @@ __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int j = 0; j < UT; ++j) acc[j] += v[t] * wp[(size_t)t * H.cout + j];
+                for (int j = 0; j < CT; ++j) acc[j] += v[t] * wp[(size_t)t * H.cout + j];
             wp += (size_t)9 * H.cout;
         }
     }
     if (!ok) return;
     float* o = H.out + ((size_t)bz * H.cout + co0) * npix + p;
 #pragma unroll
-    for (int j = 0; j < UT; ++j) {
+    for (int j = 0; j < CT; ++j) {
         float v = acc[j] + (H.bias ? H.bias[co0 + j] : 0.0f);
         if (P.relu_first) v = v < 0.0f ? 0.0f : v;
         if (H.scale) v = v * H.scale[co0 + j] + H.shift[co0 + j];
