@@ -51,7 +51,7 @@ def conv_roofline(events, steps):
 
 
 def wino_roofline(events, steps):
-    """k_conv_wino (the update block's four 3x3 layers as Winograd F(2x2,3x3)): EXECUTED matrix FLOPs over HIP-event time
+    """k_conv_wino (the update block's four 3x3 layers and the encoders' stride-1 layers as Winograd F(2x2,3x3)): EXECUTED matrix FLOPs over HIP-event time
     against the f32 MFMA peak (so frac <= 1); ``effective`` = the direct convolution's FLOPs over the same time."""
     if not events:
         return None
@@ -299,10 +299,17 @@ def run_batch(args, rank, world, dev, dist):
     real_wino = rpe_amd.ops.conv_wino
 
     def timed_wino(x, pw, *a, **k):
-        launch = real_wino(x, pw, *a, **k)
-        if not k.get('prepare'):
-            return launch
         direct = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * pw.cin * pw.cout * 9
+        if not k.get('prepare'):                   # the encoders' layers: launched directly
+            if not timing['on']:
+                return real_wino(x, pw, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = real_wino(x, pw, *a, **k)
+            e1.record()
+            wino_events.append((e0, e1, direct * 4.0 / 9.0, direct))
+            return r
+        launch = real_wino(x, pw, *a, **k)
 
         def timed_launch():
             if not timing['on']:
