@@ -285,8 +285,16 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
     RowState& S = states[row];
     if (S.stop != 0) return;
     __shared__ double vals[NPART];
+    // The two-loop recursion below runs on one lane; read serially from global memory its (y, s, rho) history costs a
+    // dependent L2 round trip per entry (27 us per iteration at 20 entries).  The wave stages it in LDS first.
+    __shared__ double h_dirs[HIST][6], h_stps[HIST][6], h_ro[HIST], h_al[HIST];
     double sv = sum_partials(partials, row, nblk, lane);
     if (lane < NPART) vals[lane] = sv;
+    if (mode != RPE_SOLVER_GN) {
+        const int nold = S.num_old;
+        for (int e = lane; e < nold * 6; e += RPE_WAVE) { (&h_dirs[0][0])[e] = (&S.old_dirs[0][0])[e]; (&h_stps[0][0])[e] = (&S.old_stps[0][0])[e]; }
+        for (int e = lane; e < nold; e += RPE_WAVE) h_ro[e] = S.ro[e];
+    }
     __syncthreads();
     if (lane != 0) return;
 
@@ -358,29 +366,34 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
         for (int i = 0; i < 6; ++i) { yk[i] = g[i] - S.prev_g[i]; sk[i] = S.d[i] * S.t; }
         double ys = dot6(yk, sk);
         if (ys > 1e-10) {
-            if (S.num_old == hist) {
+            if (S.num_old == hist) {                  // history full: drop the oldest pair (in both copies)
                 for (int k = 1; k < hist; ++k) {
-                    for (int i = 0; i < 6; ++i) { S.old_dirs[k - 1][i] = S.old_dirs[k][i]; S.old_stps[k - 1][i] = S.old_stps[k][i]; }
-                    S.ro[k - 1] = S.ro[k];
+                    for (int i = 0; i < 6; ++i) {
+                        S.old_dirs[k - 1][i] = h_dirs[k - 1][i] = h_dirs[k][i];
+                        S.old_stps[k - 1][i] = h_stps[k - 1][i] = h_stps[k][i];
+                    }
+                    S.ro[k - 1] = h_ro[k - 1] = h_ro[k];
                 }
                 S.num_old = hist - 1;
             }
-            for (int i = 0; i < 6; ++i) { S.old_dirs[S.num_old][i] = yk[i]; S.old_stps[S.num_old][i] = sk[i]; }
-            S.ro[S.num_old] = 1.0 / ys;
-            S.num_old += 1;
+            const int no = S.num_old;
+            for (int i = 0; i < 6; ++i) { S.old_dirs[no][i] = h_dirs[no][i] = yk[i]; S.old_stps[no][i] = h_stps[no][i] = sk[i]; }
+            S.ro[no] = h_ro[no] = 1.0 / ys;
+            S.num_old = no + 1;
             S.H_diag = ys / dot6(yk, yk);
         }
-        double al[HIST];
+        const int nold = S.num_old;
         double qv[6];
         for (int i = 0; i < 6; ++i) qv[i] = -g[i];
-        for (int k = S.num_old - 1; k >= 0; --k) {
-            al[k] = dot6(S.old_stps[k], qv) * S.ro[k];
-            for (int i = 0; i < 6; ++i) qv[i] += S.old_dirs[k][i] * (-al[k]);
+        for (int k = nold - 1; k >= 0; --k) {
+            const double a = dot6(h_stps[k], qv) * h_ro[k];
+            h_al[k] = a;
+            for (int i = 0; i < 6; ++i) qv[i] += h_dirs[k][i] * (-a);
         }
         for (int i = 0; i < 6; ++i) d[i] = qv[i] * S.H_diag;
-        for (int k = 0; k < S.num_old; ++k) {
-            double be = dot6(S.old_dirs[k], d) * S.ro[k];
-            for (int i = 0; i < 6; ++i) d[i] += S.old_stps[k][i] * (al[k] - be);
+        for (int k = 0; k < nold; ++k) {
+            double be = dot6(h_dirs[k], d) * h_ro[k];
+            for (int i = 0; i < 6; ++i) d[i] += h_stps[k][i] * (h_al[k] - be);
         }
     }
     for (int i = 0; i < 6; ++i) { S.prev_g[i] = g[i]; S.d[i] = d[i]; }
