@@ -273,8 +273,9 @@ int rpe_conv_fused(const rpe_conv_desc *desc, void *stream);
 /* The same operation for 3x3 stride-1 convolutions with LINEAR / RELU epilogues (even h and w, cin % 4 == 0) as Winograd
  * F(2x2,3x3) on the f32 matrix cores: 2.25x fewer matrix FLOPs than the direct form (csrc/conv_wino.hip; the update block's
  * convc2, convf2, conv and FlowHead.conv1, core/RAFT/core/update.py, and the encoders' residual blocks,
- * core/RAFT/core/extractor.py).  Supported descriptor fields: bias, scale, out, out2, residual, stats, pre_norm (cin <= 256
- * with the last four); stats then has rpe_conv_wino_stats_tiles(h, w) records per plane.  desc->packed must come from
+ * core/RAFT/core/extractor.py).  Supported descriptor fields: bias, scale, out, out2, residual, stats, pre_norm (cin <= 128
+ * with the last four: the encoders' widths); stats then holds T = rpe_conv_wino_stats_tiles(h, w) records per plane laid out (b, T, cout, 3) -- pass
+ * tiles = -T to rpe_instnorm_apply / rpe_instnorm_finalize (negative = tile-major layout).  desc->packed must come from
  * rpe_conv_wino_pack (rpe_conv_wino_packed_floats floats; 0 = unsupported shape).  add / gates -> RPE_E_UNSUPPORTED
  * (the caller uses rpe_conv_fused). */
 size_t rpe_conv_wino_packed_floats(int cout, int cin);
@@ -285,8 +286,8 @@ int rpe_conv_wino(const rpe_conv_desc *desc, void *stream);
  * the launcher and this function share one tile-width rule */
 int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
 /* Instance norm (torch.nn.InstanceNorm2d, affine=False; fnet of core/RAFT/core/extractor.py) of x (b,c,hw) given the
- * per-tile (count, mean, M2) records rpe_conv_fused / rpe_stem_conv left in `partials` (b,c,tiles,3), merged in f64 with
- * the parallel-variance formula:
+ * per-tile (count, mean, M2) records rpe_conv_fused / rpe_stem_conv left in `partials` (b,c,tiles,3) -- or rpe_conv_wino in
+ * (b,|tiles|,c,3) when tiles < 0 --, merged in f64 with the parallel-variance formula:
  *   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y,0); if (residual) y = max(residual + y, 0).  out may alias x. */
 int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                        const float *residual, float *out, void *stream);

@@ -483,10 +483,14 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
 
 // (mean, 1/sqrt(var + eps)) per (b, c) plane from the per-tile (n, mean, M2) records: what k_conv_igemm's loader-side
 // normalisation reads.  Tiles are combined in f64 with the parallel-variance formula, in a fixed order.
-__device__ __forceinline__ void plane_moments(const float* __restrict__ partials, int tiles, int plane, int nthreads, double* sh, double& mean, double& var) {
-    const float* pp = partials + (size_t)plane * tiles * 3;
+// Record layouts: tiles > 0: (b, c, tiles, 3) (k_conv_igemm, k_stem7x7); tiles < 0: (b, |tiles|, c, 3) (k_conv_wino: a workgroup's
+// records of all its channels are contiguous -- 12-B records strided by the tile count cost it 13 % as partial-sector writes).
+__device__ __forceinline__ void plane_moments(const float* __restrict__ partials, int tiles_signed, int C, int plane, int nthreads, double* sh, double& mean, double& var) {
+    const int tiles = tiles_signed < 0 ? -tiles_signed : tiles_signed;
+    const int ts = tiles_signed < 0 ? 3 * C : 3;                                      // floats between consecutive tiles of one plane
+    const float* pp = tiles_signed < 0 ? partials + ((size_t)(plane / C) * tiles * C + (plane % C)) * 3 : partials + (size_t)plane * tiles * 3;
     double n = 0.0, a = 0.0;
-    for (int i = threadIdx.x; i < tiles; i += nthreads) { n += (double)pp[3 * i]; a += (double)pp[3 * i] * (double)pp[3 * i + 1]; }
+    for (int i = threadIdx.x; i < tiles; i += nthreads) { n += (double)pp[(size_t)ts * i]; a += (double)pp[(size_t)ts * i] * (double)pp[(size_t)ts * i + 1]; }
     n = wave_sum(n); a = wave_sum(a);
     const int nw = nthreads >> 6, wv = threadIdx.x >> 6;
     if (nw > 1) {
@@ -498,7 +502,7 @@ __device__ __forceinline__ void plane_moments(const float* __restrict__ partials
     }
     mean = a / n;
     double q = 0.0;
-    for (int i = threadIdx.x; i < tiles; i += nthreads) { const double d = (double)pp[3 * i + 1] - mean; q += (double)pp[3 * i + 2] + (double)pp[3 * i] * d * d; }
+    for (int i = threadIdx.x; i < tiles; i += nthreads) { const double d = (double)pp[(size_t)ts * i + 1] - mean; q += (double)pp[(size_t)ts * i + 2] + (double)pp[(size_t)ts * i] * d * d; }
     q = wave_sum(q);
     if (nw > 1) {
         if ((threadIdx.x & 63) == 0) sh[wv] = q;
@@ -510,10 +514,10 @@ __device__ __forceinline__ void plane_moments(const float* __restrict__ partials
     var = var < 0.0 ? 0.0 : var;
 }
 
-__global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restrict__ partials, int tiles, int hw, float eps, float* __restrict__ mi) {
+__global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restrict__ partials, int tiles, int C, int hw, float eps, float* __restrict__ mi) {
     const int plane = blockIdx.x;
     double mean, var;
-    plane_moments(partials, tiles, plane, 64, nullptr, mean, var);
+    plane_moments(partials, tiles, C, plane, 64, nullptr, mean, var);
     if (threadIdx.x == 0) { mi[(size_t)plane * 2] = (float)mean; mi[(size_t)plane * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps)); }
     (void)hw;
 }
@@ -521,12 +525,12 @@ __global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restric
 // Instance norm from the per-tile (n, mean, M2) records k_conv_igemm / k_stem7x7 left behind: one workgroup per (b, c)
 // plane combines them in f64 (biased variance), then normalises in ONE read + write pass:
 //   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y, 0); if (residual) y = max(residual + y, 0)
-__global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict__ x, const float* __restrict__ partials, int tiles, int hw,
+__global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict__ x, const float* __restrict__ partials, int tiles, int C, int hw,
                                                         float eps, int relu, const float* __restrict__ residual, float* __restrict__ out) {
     const int plane = blockIdx.x;
     __shared__ double sh[8];
     double dmean, dvar;
-    plane_moments(partials, tiles, plane, 256, sh, dmean, dvar);
+    plane_moments(partials, tiles, C, plane, 256, sh, dmean, dvar);
     const float mean = (float)dmean, inv = (float)(1.0 / sqrt(dvar + (double)eps));
     const float4* xp = (const float4*)(x + (size_t)plane * hw);
     const float4* rp = residual ? (const float4*)(residual + (size_t)plane * hw) : nullptr;
@@ -643,14 +647,14 @@ extern "C" int rpe_conv_stats_tiles(int cout, int h, int w, int stride) {
 
 extern "C" int rpe_instnorm_apply(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,
                                   const float* residual, float* out, void* stream) {
-    if (!x || !partials || !out || tiles <= 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    if (!x || !partials || !out || tiles == 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
     if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, hw, eps, relu, residual, out);
+    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, c, hw, eps, relu, residual, out);
     return rpe_check_launch();
 }
 
 extern "C" int rpe_instnorm_finalize(const float* partials, int tiles, int b, int c, int hw, float eps, float* mean_inv, void* stream) {
-    if (!partials || !mean_inv || tiles <= 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
-    hipLaunchKernelGGL(k_instnorm_finalize, dim3(b * c), dim3(64), 0, (hipStream_t)stream, partials, tiles, hw, eps, mean_inv);
+    if (!partials || !mean_inv || tiles == 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_instnorm_finalize, dim3(b * c), dim3(64), 0, (hipStream_t)stream, partials, tiles, c, hw, eps, mean_inv);
     return rpe_check_launch();
 }

@@ -36,8 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RAW_N (WK * RAW_CH)                                   // 720 dwords per step
 #define RAW_CHUNKS ((RAW_N + 63) / 64)                        // 12 LDS-DMA instructions of 64 dwords, 3 per wave
 #define RAW_BUF (RAW_CHUNKS * 64)
-#define U_STEP (WK * WB_CO * 16)                              // 4096 floats = 16 DMA instructions of 1 KB, 4 per wave
-#define DMA_PER_STEP (U_STEP / 256 / 4 + RAW_CHUNKS / 4)      // per wave: 4 + 3
+#define U_STEP (WK * WB_CO * 16)                              // 4096 floats per 64-channel slice of a step = 16 DMA instructions of 1 KB
 
 struct WinoP {
     const float* x; long long xbs;
@@ -49,6 +48,7 @@ struct WinoP {
     // encoder epilogues (ENC instantiation): v = acc * scale + bias; partial instance-norm moments of v; ReLU; residual + ReLU;
     // and the input normalised + ReLU'd while it is transformed (pre: (b, cin, 2) = mean, 1/std of the previous convolution)
     const float* scale; const float* res; long long rbs; float* stats; const float* pre;
+    int co_base;                                  // first output channel of this launch (a trailing 32-channel tile is its own launch)
 };
 
 // LDS-DMA (global -> LDS without staging registers): every lane supplies its own global address, the destination is the
@@ -73,6 +73,13 @@ __device__ __forceinline__ void dma16x4(const float* gsrc, unsigned lds_addr) {
                      : "=&s"(keep) : "v"(gsrc + 256 * j), "s"(lds_addr + 1024u * j) : "memory");
 #endif
 }
+// two 1 KB chunks (the 32-channel tile: one input channel's 32 rows)
+__device__ __forceinline__ void dma16x2(const float* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
 // three 256-B chunks of gathered dwords: lane's sources g0, g1, g2  ->  LDS lds_addr + 256 j + lane * 4
 __device__ __forceinline__ void dma4x3(const float* g0, const float* g1, const float* g2, unsigned lds_addr) {
     unsigned keep;
@@ -89,20 +96,32 @@ __device__ __forceinline__ void dma4x3(const float* g0, const float* g1, const f
                      : "=&s"(keep) : "v"(g[j]), "s"(lds_addr + 256u * j) : "memory");
 #endif
 }
+// Sum over each 16-lane row of the wave with DPP moves (vector-ALU rate, no LDS traffic): quad butterflies, row half-mirror,
+// row mirror.  Every lane ends with its row's total.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <bool ENC>
+// CB = 16-channel blocks per wave: 2 -> 64 output channels per workgroup, 1 -> 32 (the trailing tile of cout = 96: no padded half)
+template <bool ENC, bool PRE, int CB>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
-    __shared__ __attribute__((aligned(16))) float Us[3][U_STEP];             // [ci][co][position], as packed in global memory
+    constexpr int TCO = 32 * CB, UT_STEP = WK * TCO * 16;
+    __shared__ __attribute__((aligned(16))) float Us[3][UT_STEP];            // [ci][co][position], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
     __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
-    __shared__ float Pn[ENC ? 2 * 256 : 2];                                  // ENC: (mean, 1/std) of every input channel (cin <= 256)
+    __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // ENC: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ptx = (P.W + 2 * WB_TX - 1) / (2 * WB_TX);
     const int x0 = (blockIdx.x % ptx) * (2 * WB_TX), y0 = (blockIdx.x / ptx) * (2 * WB_TY);
-    const int co0 = blockIdx.y * WB_CO, bz = blockIdx.z;
+    const int co0 = P.co_base + blockIdx.y * TCO, bz = blockIdx.z;
     const int H = P.H, W = P.W, hw = H * W;
     const float* xb = P.x + (size_t)bz * P.xbs;
     const int nsteps = P.cin / WK;
@@ -119,12 +138,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
         roff[j] = ci * hw + yy * W + xx;
     }
-    const float* wslice = P.wp + (size_t)blockIdx.y * U_STEP + (size_t)(wv * 4) * 256 + lane * 4;      // [step][co tile][ci][co][16]
+    // packed weights: [step][64-channel tile][ci][co % 64][16].  CB = 2: the wave's four 1 KB chunks are consecutive; CB = 1: wave =
+    // input channel, its 32 rows start at row co0 % 64 of that channel's 64
+    const float* wslice = CB == 2 ? P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)(wv * 4) * 256 + lane * 4
+                                  : P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)wv * (WB_CO * 16) + (size_t)(co0 % WB_CO) * 16 + lane * 4;
     const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP;
-    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)(wv * 4) * 1024u, rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(wv * 3) * 256u;
+    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 4096u : 2048u), rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(wv * 3) * 256u;
     auto issue_u = [&](int step, int buf) {
-        step = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat keeps 7 DMAs per step in flight)
-        dma16x4(wslice + (size_t)step * wstep, us_base + (unsigned)buf * (U_STEP * 4u));
+        step = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat keeps the same number of DMAs per step in flight)
+        if (CB == 2) dma16x4(wslice + (size_t)step * wstep, us_base + (unsigned)buf * (UT_STEP * 4u));
+        else dma16x2(wslice + (size_t)step * wstep, us_base + (unsigned)buf * (UT_STEP * 4u));
     };
     auto issue_raw = [&](int step, int buf) {
         step = step < nsteps ? step : nsteps - 1;
@@ -144,22 +167,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             okmask |= ((yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)) ? (1u << (r * 4 + c)) : 0u;
         }
     const int v_src = v_ci * RAW_CH + (2 * v_ty + v_half) * RAW_W + 2 * v_tx;
-    const bool pre = ENC && P.pre != nullptr;
+    constexpr bool pre = PRE;                                 // (a compile-time choice: a run-time select costs the transform ~60 vector instructions a step)
     if (pre) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
-        for (int i = tid; i < 2 * P.cin; i += 256) Pn[i] = P.pre[(size_t)bz * P.cin * 2 + i];
+        for (int i = tid; i < P.cin; i += 256) {
+            const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
+            Pn[2 * i] = -m * iv; Pn[2 * i + 1] = iv;
+        }
     }
     // The transform of step s+1 is written as three slices (read + mask, column pass, row pass + store) so that the main loop can
     // place them between its groups of matrix instructions: their vector / LDS work then issues in the shadow of the matrix pipe.
     float td[12], tta[4], ttb[4];
     auto tr_read = [&](int step, int rbuf) {
         const float* rp = &Rs[rbuf][v_src];
-        const float pm = pre ? Pn[2 * (step * WK + v_ci)] : 0.0f, pi = pre ? Pn[2 * (step * WK + v_ci) + 1] : 1.0f;
+        const float pm = pre ? Pn[2 * (step * WK + v_ci)] : 0.0f, pi = pre ? Pn[2 * (step * WK + v_ci) + 1] : 1.0f;    // (-mean / std, 1 / std)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float v = rp[r * RAW_W + c];
-                if (pre) { v = (v - pm) * pi; v = v < 0.0f ? 0.0f : v; }      // relu((x - mean) / std); padding stays zero (mask below)
+                if (pre) v = fmaxf(fmaf(v, pi, pm), 0.0f);                    // relu((x - mean) / std); padding stays zero (mask below)
                 td[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? v : 0.0f;
             }
     };
@@ -179,11 +205,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     };
     auto transform = [&](int step, int rbuf, int vbuf) { tr_read(step, rbuf); tr_cols(); tr_store(vbuf); };
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][CB];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) acc[p][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < CB; ++c) acc[p][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
 
     // ---- prologue: U(0), U(1), raw(0..2) in flight; V(0) built
@@ -203,33 +229,33 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         // fragments: four positions per 16-B read; the reads of group g+1 are in flight while group g's 8 MFMAs issue
         // U rows are 64 B with no padding (they arrive by 1 KB DMA chunks), so position group g of row r sits in 16-B slot
         // g ^ ((r >> 2) & 3) (k_wino_pack stores it that way): the 16 rows of a fragment read then cover all 64 banks
-        const float* ua = &Us[ub][(lk * WB_CO + cw * 32 + li) * 16];
+        const float* ua = &Us[ub][(lk * TCO + cw * 16 * CB + li) * 16];
         const int sw = (li >> 2) & 3;
         const float* vb = &Vs[cur][lk][tw * 16 + li][0];
         const int rb1 = rb == 2 ? 0 : rb + 1;                 // (s + 1) % 3
         const int tstep = s + 1 < nsteps ? s + 1 : nsteps - 1;   // (last step: a redundant transform into the buffer nobody reads again)
-        f32x4 fa0 = *(const f32x4*)(ua + 4 * sw), fa1 = *(const f32x4*)(ua + 16 * 16 + 4 * sw), fb = *(const f32x4*)(vb);
+        f32x4 fa0 = *(const f32x4*)(ua + 4 * sw), fa1 = *(const f32x4*)(ua + (CB == 2 ? 16 * 16 : 0) + 4 * sw), fb = *(const f32x4*)(vb);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 na0 = fa0, na1 = fa1, nb = fb;
-            if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
+            if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); if (CB == 2) na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
             if (g == 0) tr_read(tstep, rb1);
             if (g == 1) tr_cols();
             if (g == 3) tr_store(cur ^ 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
-                acc[4 * g + e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][1], 0, 0, 0);
+                if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
             }
             // issue order inside this group: the LDS reads first, then each matrix instruction followed by a few vector ones
             __builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
+            for (int e = 0; e < 4 * CB; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CB == 2 ? 4 : 8, 0); }
             __builtin_amdgcn_sched_barrier(0);
             fa0 = na0; fa1 = na1; fb = nb;
         }
-        static_assert(DMA_PER_STEP == 7, "the wait below leaves exactly this step's DMAs outstanding");
-        __builtin_amdgcn_s_waitcnt(0x0F77);                   // vmcnt(7), lgkmcnt/expcnt untouched
+        // leaves exactly this step's DMAs (2 * CB weight + 3 patch instructions per wave) outstanding; lgkmcnt / expcnt untouched
+        if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F77); else __builtin_amdgcn_s_waitcnt(0x0F75);
         __syncthreads();
         ub = ub == 2 ? 0 : ub + 1; rb = rb1;
     }
@@ -243,12 +269,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     float* ob = P.out + (size_t)bz * P.obs;
     float* ob2 = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
     const float* rsb = (ENC && P.res) ? P.res + (size_t)bz * P.rbs : nullptr;
-    float* red = &Vs[0][0][0][0];                                   // [tile half][64 channels][4]: the K loop is done with V
+    const float nvalid = 4.0f * (float)__popcll(__ballot(pix_ok) & 0xFFFFull);   // pixels of this wave's 16 tiles inside the map
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int col = cw * 32 + cb * 16 + 4 * lk + r, co = co0 + col;
+            const int col = cw * 16 * CB + cb * 16 + 4 * lk + r, co = co0 + col;
             float sa[4], sb[4];
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
@@ -266,15 +292,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             if (ENC && P.stats) {
                 // moments of v over this wave's 16 tiles x 4 pixels about a pivot (the wave's first value of the channel: valid
                 // whenever any of its tiles is, because tile 0 is the wave's top-left one), summed over the 16-lane row
-                const float piv = __shfl(y[0], lane & 48, 64);
-                float s1 = 0.0f, s2 = 0.0f, nn = pix_ok ? 4.0f : 0.0f;
+                const int y0b = __builtin_bit_cast(int, y[0]);                 // lane 0 of this lane's 16-lane row, without an LDS round trip
+                const int p01 = lk & 1 ? __builtin_amdgcn_readlane(y0b, 16) : __builtin_amdgcn_readlane(y0b, 0);
+                const int p23 = lk & 1 ? __builtin_amdgcn_readlane(y0b, 48) : __builtin_amdgcn_readlane(y0b, 32);
+                const float piv = __builtin_bit_cast(float, lk & 2 ? p23 : p01);
+                float s1 = 0.0f, s2 = 0.0f;
                 if (pix_ok) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float dv = y[e] - piv; s1 += dv; s2 += dv * dv; }
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); nn += __shfl_xor(nn, o, 64); }
-                if (li == 0) { float* rr = red + (tw * WB_CO + col) * 4; rr[0] = s1; rr[1] = s2; rr[2] = piv; rr[3] = nn; }
+                s1 = row16_sum(s1); s2 = row16_sum(s2);
+                // one (count, mean, M2) record per channel, patch and tile half, straight to memory: rpe_instnorm_apply / _finalize
+                // merge records in f64 anyway (the pivot is a sample, so s2 - s1^2/n loses at most a factor ~2 in f32)
+                if (li == 0 && cok) {
+                    float* st = P.stats + (((size_t)bz * (2 * gridDim.x) + 2 * blockIdx.x + tw) * P.cout + co) * 3;      // (b, records, cout, 3)
+                    const float m = nvalid > 0.0f ? s1 / nvalid : 0.0f;
+                    st[0] = nvalid; st[1] = piv + m; st[2] = s2 - s1 * m;
+                }
             }
             if (P.mode == RPE_CONV_RELU) {                                   // NaN stays NaN, like torch.relu
 #pragma unroll
@@ -293,16 +327,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
                 if (ob2) { *(float2*)(ob2 + e0) = make_float2(y[0], y[1]); *(float2*)(ob2 + e0 + W) = make_float2(y[2], y[3]); }
             }
         }
-    if (ENC && P.stats) {                                           // the two tile halves of a channel -> one (count, mean, M2) record
-        __syncthreads();
-        if (tid < WB_CO && co0 + tid < P.cout) {
-            StatAcc A;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) { const float* rr = red + (h2 * WB_CO + tid) * 4; A.add_pivoted((int)rr[3], rr[0], rr[1], rr[2]); }
-            float* st = P.stats + (((size_t)bz * P.cout + co0 + tid) * gridDim.x + blockIdx.x) * 3;
-            st[0] = (float)A.n; st[1] = (float)A.mean; st[2] = (float)A.m2;
-        }
-    }
 }
 
 // weight (cout, cin, 3, 3) -> U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], laid out
@@ -348,7 +372,7 @@ extern "C" int rpe_conv_wino_pack(const float* weight, int cout, int cin, float*
 }
 
 extern "C" int rpe_conv_wino_stats_tiles(int h, int w) {
-    return (h > 0 && w > 0) ? ceil_div(w, 2 * WB_TX) * ceil_div(h, 2 * WB_TY) : 0;
+    return (h > 0 && w > 0) ? 2 * ceil_div(w, 2 * WB_TX) * ceil_div(h, 2 * WB_TY) : 0;      // two records (tile halves) per 16x8 patch
 }
 
 extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
@@ -357,7 +381,7 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     if (d->mode != RPE_CONV_LINEAR && d->mode != RPE_CONV_RELU) return RPE_E_UNSUPPORTED;
     if (d->add || d->hidden || d->zgate) return RPE_E_UNSUPPORTED;
     const bool enc = d->scale || d->residual || d->stats || d->pre_norm;
-    if (enc && (d->cin > 256 || (d->residual && ((((uintptr_t)d->residual) & 7) || (d->residual_batch_stride & 1))))) return RPE_E_UNSUPPORTED;
+    if ((d->pre_norm && d->cin > 128) || (d->residual && ((((uintptr_t)d->residual) & 7) || (d->residual_batch_stride & 1)))) return RPE_E_UNSUPPORTED;
     if ((((uintptr_t)d->packed) & 15) || (((uintptr_t)d->out) & 7) || (d->out_batch_stride & 1) ||
         (d->out2 && ((((uintptr_t)d->out2) & 7) || (d->out2_batch_stride & 1)))) return RPE_E_UNSUPPORTED;
     WinoP P;
@@ -365,8 +389,22 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     P.H = d->h; P.W = d->w; P.bias = d->bias; P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.mode = d->mode;
     P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats; P.pre = d->pre_norm;
-    dim3 grid(ceil_div(d->w, 2 * WB_TX) * ceil_div(d->h, 2 * WB_TY), P.coP / WB_CO, d->b);
-    if (enc) hipLaunchKernelGGL(k_conv_wino<true>, grid, dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(k_conv_wino<false>, grid, dim3(256), 0, (hipStream_t)stream, P);
+    // 64-channel tiles; a remainder of at most 32 channels (cout = 96) runs as one 32-channel tile instead of a half-empty 64
+    const int rem = d->cout % WB_CO, tail32 = rem > 0 && rem <= 32;
+    const int n64 = tail32 ? d->cout / WB_CO : P.coP / WB_CO;
+    const unsigned gx = ceil_div(d->w, 2 * WB_TX) * ceil_div(d->h, 2 * WB_TY);
+    hipStream_t s = (hipStream_t)stream;
+    P.co_base = 0;
+    if (n64 > 0) {
+        if (d->pre_norm) hipLaunchKernelGGL((k_conv_wino<true, true, 2>), dim3(gx, n64, d->b), dim3(256), 0, s, P);
+        else if (enc) hipLaunchKernelGGL((k_conv_wino<true, false, 2>), dim3(gx, n64, d->b), dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((k_conv_wino<false, false, 2>), dim3(gx, n64, d->b), dim3(256), 0, s, P);
+    }
+    if (tail32) {
+        P.co_base = n64 * WB_CO;
+        if (d->pre_norm) hipLaunchKernelGGL((k_conv_wino<true, true, 1>), dim3(gx, 1, d->b), dim3(256), 0, s, P);
+        else if (enc) hipLaunchKernelGGL((k_conv_wino<true, false, 1>), dim3(gx, 1, d->b), dim3(256), 0, s, P);
+        else hipLaunchKernelGGL((k_conv_wino<false, false, 1>), dim3(gx, 1, d->b), dim3(256), 0, s, P);
+    }
     return rpe_check_launch();
 }

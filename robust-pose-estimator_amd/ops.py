@@ -482,8 +482,8 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
         setattr(d, name, p); setattr(d, name + '_batch_stride', s)
     if stats is not None:
         tiles = lib().rpe_conv_wino_stats_tiles(hh, ww)
-        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pw.cout, tiles, 3)):
-            raise _lib.RpeError(f'conv_wino: stats must be a contiguous float32 ({b},{pw.cout},{tiles},3) GPU tensor')
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, tiles, pw.cout, 3)):
+            raise _lib.RpeError(f'conv_wino: stats must be a contiguous float32 ({b},{tiles},{pw.cout},3) GPU tensor (conv_wino_stats_buffer)')
     if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
                                      and tuple(pre_norm.shape) == (b, cin, 2)):
         raise _lib.RpeError(f'conv_wino: pre_norm must be a contiguous float32 ({b},{cin},2) GPU tensor')
@@ -504,8 +504,11 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
 
 
 def conv_wino_stats_buffer(b, cout, hh, ww, device):
-    """Per-tile (count, mean, M2) records rpe_conv_wino fills when ``stats`` is given: (b, cout, tiles, 3)."""
-    return torch.empty(b, cout, lib().rpe_conv_wino_stats_tiles(hh, ww), 3, dtype=torch.float32, device=device)
+    """Per-tile (count, mean, M2) records rpe_conv_wino fills when ``stats`` is given: TILE-MAJOR (b, tiles, cout, 3), marked so
+    that instnorm_apply / instnorm_finalize read it that way."""
+    t = torch.empty(b, lib().rpe_conv_wino_stats_tiles(hh, ww), cout, 3, dtype=torch.float32, device=device)
+    t.rpe_tile_major = True
+    return t
 
 
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
@@ -515,7 +518,11 @@ def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
 
 def instnorm_finalize(stats, hw, eps=1e-5):
     """(b,c,2) = (mean, 1/std) per plane from conv_fused's partial sums: the ``pre_norm`` argument of the next conv_fused."""
-    b, c, tiles, _ = stats.shape
+    if getattr(stats, 'rpe_tile_major', False):
+        b, tiles, c, _ = stats.shape
+        tiles = -tiles
+    else:
+        b, c, tiles, _ = stats.shape
     mi = torch.empty(b, c, 2, dtype=torch.float32, device=stats.device)
     check(lib().rpe_instnorm_finalize(ptr(stats), tiles, b, c, hw, float(eps), ptr(mi), stream_ptr()), 'rpe_instnorm_finalize')
     return mi
@@ -525,13 +532,16 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):
     """Instance norm of x (b,c,h,w) from the partial sums of conv_fused(..., stats=stats): one read + one write pass."""
     _nchw(x, 'x')
     b, c, hh, ww = x.shape
-    if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and tuple(stats.shape[:2]) == (b, c)
+    tile_major = getattr(stats, 'rpe_tile_major', False)          # (b, tiles, c, 3): conv_wino's records
+    want = (b, stats.shape[1], c) if tile_major else (b, c, stats.shape[2])
+    if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and tuple(stats.shape[:3]) == want
             and stats.shape[3] == 3):
-        raise _lib.RpeError('instnorm_apply: stats must be the (b,c,tiles,3) buffer of conv_fused')
+        raise _lib.RpeError('instnorm_apply: stats must be the (b,c,tiles,3) buffer of conv_fused or the (b,tiles,c,3) one of conv_wino')
     if residual is not None and _nchw(residual, 'residual').shape != x.shape:
         raise _lib.RpeError('instnorm_apply: residual must have the shape of x')
     out = x if out is None else _nchw(out, 'out')
-    check(lib().rpe_instnorm_apply(ptr(x), ptr(stats), stats.shape[2], b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
+    tiles = -stats.shape[1] if tile_major else stats.shape[2]
+    check(lib().rpe_instnorm_apply(ptr(x), ptr(stats), tiles, b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
                                    stream_ptr()), 'rpe_instnorm_apply')
     return out
 

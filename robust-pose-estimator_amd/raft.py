@@ -116,7 +116,7 @@ def _wino(conv, x):
     """PackedWino of a 3x3 stride-1 convolution when rpe_conv_wino can run it on this input (cached on the module), else None."""
     if not WINOGRAD or conv.stride != (1, 1) or conv.kernel_size != (3, 3) or conv.padding != (1, 1):
         return None
-    if not ops.PackedWino.supported(conv.weight, x.shape[-2], x.shape[-1]) or conv.in_channels > 256 or not x.is_contiguous():
+    if not ops.PackedWino.supported(conv.weight, x.shape[-2], x.shape[-1]) or conv.in_channels > 128 or not x.is_contiguous():
         return None
     key = (conv.weight._version, conv.weight.data_ptr())
     cached = getattr(conv, '_rpe_wino', None)

@@ -427,8 +427,8 @@ def test_winograd_encoder_epilogues_match_f64(rpe, c, h, w, b):
     stats = ops.conv_wino_stats_buffer(b, c, h, w, 'cuda')
     raw = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=stats)
     assert (raw.cpu().double() - pre).abs().max() < 3 * _tol(x, wt)
-    st = stats.cpu().double()
-    assert float(st[..., 0].sum(-1).min()) == float(st[..., 0].sum(-1).max()) == h * w
+    st = stats.cpu().double()                                              # tile-major: (b, records, c, 3)
+    assert float(st[..., 0].sum(1).min()) == float(st[..., 0].sum(1).max()) == h * w
     mi = ops.instnorm_finalize(stats, h * w, eps=1e-5).cpu().double()
     assert float((mi[..., 0] - mean).abs().max()) < 1e-5 and float((mi[..., 1] * torch.sqrt(var + 1e-5) - 1).abs().max()) < 2e-5
     ref2 = (res.double() + ((pre - mean[:, :, None, None]) / torch.sqrt(var + 1e-5)[:, :, None, None]).clamp_min(0)).clamp_min(0)

@@ -29,3 +29,19 @@ with torch.no_grad():
         tw = t(lambda: ops.conv_wino(x, pw, ops.CONV_RELU, o2))
         print('%-7s %3d->%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective)   maxdiff %.1e (|out| %.1f)' % (
             name, ci, co, td, flop / td / 1e6, tw, flop / 2.25 / tw / 1e6, flop / tw / 1e6, (o1 - o2).abs().max().item(), o1.abs().max().item()))
+    print('--- encoder layers (fnet: bias + instance-norm moments; 48 images)')
+    for name, c, hh, ww in (('layer1', 64, 256, 320), ('layer2', 96, 128, 160), ('layer3', 128, 64, 80)):
+        nb = 48
+        x = torch.randn(nb, c, hh, ww, device=dev); w = torch.randn(c, c, 3, 3, device=dev) * 0.05; bias = torch.randn(c, device=dev)
+        o1 = torch.empty(nb, c, hh, ww, device=dev); o2 = torch.empty_like(o1)
+        pc, pw = ops.PackedConv(w, None), ops.PackedWino(w, None)
+        sd, sw = ops.conv_stats_buffer(nb, c, hh, ww, dev), ops.conv_wino_stats_buffer(nb, c, hh, ww, dev)
+        flop = 2.0 * nb * hh * ww * c * c * 9
+        td = t(lambda: ops.conv_fused(x, pc, ops.CONV_LINEAR, o1, bias=bias, stats=sd))
+        tw = t(lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias, stats=sw))
+        tn = t(lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias))
+        ones = torch.ones(c, device=dev)
+        te = t(lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias, scale=ones))
+        print('        (encoder instantiation without moments: %7.1f us)' % te)
+        print('%-7s %3d ch %3dx%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective; without moments %7.1f us)   maxdiff %.1e' % (
+            name, c, hh, ww, td, flop / td / 1e6, tw, flop / 2.25 / tw / 1e6, flop / tw / 1e6, tn, (o1 - o2).abs().max().item()))
