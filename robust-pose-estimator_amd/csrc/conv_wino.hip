@@ -55,46 +55,39 @@ struct WinoP {
 // wave-uniform LDS byte address + lane * size.  Issued as inline asm ON PURPOSE: hipcc waits vmcnt(0) in front of every
 // LDS read while one of ITS loads-to-LDS is in flight (it cannot tell the buffers apart), which would serialise the
 // three-deep prefetch; these it does not count, and the kernel waits for them itself (s_waitcnt vmcnt(N), in order).
-#ifndef WINO_DMA_OFFS
-#define WINO_DMA_OFFS 1      // 1: one M0 set-up per group of DMAs, chunks addressed by the instruction offset (added to the global AND the LDS address)
-#endif
-// four 1 KB chunks: global gsrc + 1024 j  ->  LDS lds_addr + 1024 j + lane * 16
-__device__ __forceinline__ void dma16x4(const float* gsrc, unsigned lds_addr) {
+// The global address is a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset + the instruction offset, and the instruction
+// offset is added to the LDS address as well: one M0 set-up and no 64-bit vector address arithmetic per group of DMAs.
+__device__ __forceinline__ const float* wave_uniform(const float* p) {          // pins a wave-uniform pointer to scalar registers
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+// four 1 KB chunks: global base + voff + 1024 j  ->  LDS lds_addr + 1024 j + lane * 16
+__device__ __forceinline__ void dma16x4(const float* base, unsigned voff, unsigned lds_addr) {
     unsigned keep;
-#if WINO_DMA_OFFS
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-#else
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc + 256 * j), "s"(lds_addr + 1024u * j) : "memory");
-#endif
+    base = wave_uniform(base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
 // two 1 KB chunks (the 32-channel tile: one input channel's 32 rows)
-__device__ __forceinline__ void dma16x2(const float* gsrc, unsigned lds_addr) {
+__device__ __forceinline__ void dma16x2(const float* base, unsigned voff, unsigned lds_addr) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+    base = wave_uniform(base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
-// three 256-B chunks of gathered dwords: lane's sources g0, g1, g2  ->  LDS lds_addr + 256 j + lane * 4
-__device__ __forceinline__ void dma4x3(const float* g0, const float* g1, const float* g2, unsigned lds_addr) {
+// three 256-B chunks of gathered dwords: global base + v_j + 256 j  ->  LDS lds_addr + 256 j + lane * 4   (the caller folds the
+// -256 j into v_j and keeps it non-negative by biasing the base)
+__device__ __forceinline__ void dma4x3(const float* base, unsigned v0, unsigned v1, unsigned v2, unsigned lds_addr) {
     unsigned keep;
-#if WINO_DMA_OFFS
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                 "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %2, off offset:256\n\tglobal_load_lds_dword %3, off offset:512\n\t"
+    base = wave_uniform(base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, %4\n\tglobal_load_lds_dword %2, %4 offset:256\n\tglobal_load_lds_dword %3, %4 offset:512\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g0), "v"(g1 - 64), "v"(g2 - 128), "s"(lds_addr) : "memory");
-#else
-    const float* g[3] = {g0, g1, g2};
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(g[j]), "s"(lds_addr + 256u * j) : "memory");
-#endif
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(base), "s"(lds_addr) : "memory");
 }
 // Sum over each 16-lane row of the wave with DPP moves (vector-ALU rate, no LDS traffic): quad butterflies, row half-mirror,
 // row mirror.  Every lane ends with its row's total.
@@ -119,6 +112,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
     __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // ENC: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WINO_PAD
+    __shared__ float padlds[WINO_PAD];
+    if (P.cin < 0) { padlds[tid] = 1.0f; P.out[0] = padlds[tid ^ 1]; }
+#endif
     const int ptx = (P.W + 2 * WB_TX - 1) / (2 * WB_TX);
     const int x0 = (blockIdx.x % ptx) * (2 * WB_TX), y0 = (blockIdx.x / ptx) * (2 * WB_TY);
     const int co0 = P.co_base + blockIdx.y * TCO, bz = blockIdx.z;
@@ -128,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
 
     // ---- DMA roles.  Raw patch: chunk c = 3*wave + j, element e = 64 c + lane -> (ci, row, col) of the 4 x 10 x 18 patch, read
     // from the clamped pixel (the mask is applied when the patch is transformed).  U: chunk c = 4*wave + j, plain copy.
-    int roff[3];
+    unsigned roff[3];                                         // byte offsets from (step's first channel - 512 B), chunk offset folded in
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         int e = (wv * 3 + j) * 64 + lane;
@@ -136,23 +133,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         const int ci = e / RAW_CH, rem = e - ci * RAW_CH, r = rem / RAW_W, c = rem - r * RAW_W;
         int yy = y0 - 1 + r, xx = x0 - 1 + c;
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-        roff[j] = ci * hw + yy * W + xx;
+        roff[j] = (unsigned)(ci * hw + yy * W + xx) * 4u + 512u - 256u * j;
     }
     // packed weights: [step][64-channel tile][ci][co % 64][16].  CB = 2: the wave's four 1 KB chunks are consecutive; CB = 1: wave =
     // input channel, its 32 rows start at row co0 % 64 of that channel's 64
-    const float* wslice = CB == 2 ? P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)(wv * 4) * 256 + lane * 4
-                                  : P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)wv * (WB_CO * 16) + (size_t)(co0 % WB_CO) * 16 + lane * 4;
+    const float* wslice = CB == 2 ? P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)(wv * 4) * 256
+                                  : P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)wv * (WB_CO * 16) + (size_t)(co0 % WB_CO) * 16;
+    const unsigned uoff = lane * 16u;
     const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP;
     const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 4096u : 2048u), rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(wv * 3) * 256u;
     auto issue_u = [&](int step, int buf) {
         step = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat keeps the same number of DMAs per step in flight)
-        if (CB == 2) dma16x4(wslice + (size_t)step * wstep, us_base + (unsigned)buf * (UT_STEP * 4u));
-        else dma16x2(wslice + (size_t)step * wstep, us_base + (unsigned)buf * (UT_STEP * 4u));
+        if (CB == 2) dma16x4(wslice + (size_t)step * wstep, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
+        else dma16x2(wslice + (size_t)step * wstep, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
     };
     auto issue_raw = [&](int step, int buf) {
         step = step < nsteps ? step : nsteps - 1;
-        const float* src = xb + (size_t)step * WK * hw;
-        dma4x3(src + roff[0], src + roff[1], src + roff[2], rs_base + (unsigned)buf * (RAW_BUF * 4u));
+        dma4x3(xb + (size_t)step * WK * hw - 128, roff[0], roff[1], roff[2], rs_base + (unsigned)buf * (RAW_BUF * 4u));
     };
 
     // ---- transform role: thread -> (half, input channel of the step, tile).  V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0;
@@ -212,52 +209,80 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         for (int c = 0; c < CB; ++c) acc[p][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
 
-    // ---- prologue: U(0), U(1), raw(0..2) in flight; V(0) built
-    issue_u(0, 0); issue_u(1, 1); issue_raw(0, 0); issue_raw(1, 1); issue_raw(2, 2);
+    // ---- prologue: U(0), raw(0), raw(1) land; V(0) is built; then the two DMA groups the loop expects in flight
+    issue_u(0, 0); issue_raw(0, 0); issue_raw(1, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
     __syncthreads();
     transform(0, 0, 0);
-    __syncthreads();
-    // ---- step s: DMA U(s+2) and raw(s+3) | 32 MFMAs on U(s), V(s) | V(s+1) from raw(s+1) | everything older than this step's
-    // DMAs has landed (vmcnt counts in order) | barrier.  U(s) and raw(s+1) were issued two steps before they are read.
-    int ub = 0, rb = 0;                                       // s % 3
+    __syncthreads();                                          // V(0) visible; raw(0)'s buffer free
+    issue_u(1, 1); issue_raw(2, 2);
+    issue_u(2, 2); issue_raw(3, 0);
+    // ---- step s, four groups of 8 (CB = 2) matrix instructions, one per four positions:
+    //   g0  | fragment reads of g1 | patch reads of raw(s+1), masks                          (all of this in the matrix pipe's shadow)
+    //   g1  | fragment reads of g2 | column pass of the transform
+    //   g2  | fragment reads of g3 | row pass, V(s+1) stored | wait: own DMAs older than the last group landed | BARRIER
+    //   g3  | fragment reads of g0 of step s+1 (U(s+1), V(s+1) are visible now) | DMA U(s+3) -> U(s)'s buffer, raw(s+4) -> raw(s+1)'s
+    // so nothing but the barrier itself separates two steps' matrix instructions: the reads behind it and the DMA issue (60-180
+    // cycles per instruction) run beside g3.  A DMA group is issued two barriers before its data is read.
+    // U rows are 64 B with no padding (they arrive by 1 KB DMA chunks), so position group g of row r sits in 16-B slot
+    // g ^ ((r >> 2) & 3) (k_wino_pack stores it that way): the 16 rows of a fragment read then cover all 64 banks
+    const int sw = (li >> 2) & 3;
+    const int uoffl = (lk * TCO + cw * 16 * CB + li) * 16, voffl = (lk * WB_NT + tw * 16 + li) * PS;
+    f32x4 fa0 = *(const f32x4*)(&Us[0][uoffl] + 4 * sw), fa1 = *(const f32x4*)(&Us[0][uoffl] + (CB == 2 ? 16 * 16 : 0) + 4 * sw), fb = *(const f32x4*)(&Vs[0][0][0][0] + voffl);
+    int ub = 0, rb1 = 1;                                      // s % 3, (s + 1) % 3
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
-        const int ub2 = ub == 0 ? 2 : ub - 1;                 // (s + 2) % 3
-        issue_u(s + 2, ub2);
-        issue_raw(s + 3, rb);
-        // fragments: four positions per 16-B read; the reads of group g+1 are in flight while group g's 8 MFMAs issue
-        // U rows are 64 B with no padding (they arrive by 1 KB DMA chunks), so position group g of row r sits in 16-B slot
-        // g ^ ((r >> 2) & 3) (k_wino_pack stores it that way): the 16 rows of a fragment read then cover all 64 banks
-        const float* ua = &Us[ub][(lk * TCO + cw * 16 * CB + li) * 16];
-        const int sw = (li >> 2) & 3;
-        const float* vb = &Vs[cur][lk][tw * 16 + li][0];
-        const int rb1 = rb == 2 ? 0 : rb + 1;                 // (s + 1) % 3
+        const float* ua = &Us[ub][uoffl];
+        const float* vb = &Vs[cur][0][0][0] + voffl;
+        const float* ua_n = &Us[rb1][uoffl];                  // U ring and raw ring turn together: (s + 1) % 3
+        const float* vb_n = &Vs[cur ^ 1][0][0][0] + voffl;
         const int tstep = s + 1 < nsteps ? s + 1 : nsteps - 1;   // (last step: a redundant transform into the buffer nobody reads again)
-        f32x4 fa0 = *(const f32x4*)(ua + 4 * sw), fa1 = *(const f32x4*)(ua + (CB == 2 ? 16 * 16 : 0) + 4 * sw), fb = *(const f32x4*)(vb);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 na0 = fa0, na1 = fa1, nb = fb;
-            if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); if (CB == 2) na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
+            f32x4 na0, na1, nb;
+            if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); na1 = na0; if (CB == 2) na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
+            else { na0 = *(const f32x4*)(ua_n + 4 * sw); na1 = na0; if (CB == 2) na1 = *(const f32x4*)(ua_n + 16 * 16 + 4 * sw); nb = *(const f32x4*)(vb_n); }
+#ifndef WINO_NOTR
             if (g == 0) tr_read(tstep, rb1);
             if (g == 1) tr_cols();
-            if (g == 3) tr_store(cur ^ 1);
+            if (g == 2) tr_store(cur ^ 1);
+#endif
+            if (g < 3) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
-                if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
+                    if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
+                }
+                // issue order inside this group: the LDS reads first, then each matrix instruction followed by a few vector ones
+                __builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
+#pragma unroll
+                for (int e = 0; e < 4 * CB; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CB == 2 ? 4 : 8, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 2) {
+                    // own DMAs except the newest group (2 * CB weight + 3 patch instructions) have landed, the V stores and every
+                    // fragment read of this step are complete: after the barrier U(s), V(s) and raw(s+1) may be overwritten
+#ifndef WINO_NOWAIT
+                    if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F77 & ~0x0F00); else __builtin_amdgcn_s_waitcnt(0x0F75 & ~0x0F00);     // vmcnt(7|5) lgkmcnt(0)
+#endif
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
+                    if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_NODMA
+                    if (e == 0) issue_u(s + 3, ub);
+                    if (e == 1) issue_raw(s + 4, rb1);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            // issue order inside this group: the LDS reads first, then each matrix instruction followed by a few vector ones
-            __builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
-#pragma unroll
-            for (int e = 0; e < 4 * CB; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CB == 2 ? 4 : 8, 0); }
-            __builtin_amdgcn_sched_barrier(0);
             fa0 = na0; fa1 = na1; fb = nb;
         }
-        // leaves exactly this step's DMAs (2 * CB weight + 3 patch instructions per wave) outstanding; lgkmcnt / expcnt untouched
-        if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F77); else __builtin_amdgcn_s_waitcnt(0x0F75);
-        __syncthreads();
-        ub = ub == 2 ? 0 : ub + 1; rb = rb1;
+        ub = rb1; rb1 = rb1 == 2 ? 0 : rb1 + 1;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // the repeats issued past the end have landed before LDS is released
 

@@ -20,7 +20,9 @@ def t(fn, reps=10):
 dev = torch.device('cuda:0'); torch.manual_seed(0)
 N, H, W = int(os.environ.get('CONV_N', 32)), 64, 80
 with torch.no_grad():
+    only = os.environ.get('CONV_ONLY')
     for name, ci, co in (('convc2', 256, 192), ('convf2', 128, 64), ('conv', 256, 126), ('fh1', 128, 256)):
+        if only and name != only: continue
         x = torch.randn(N, ci, H, W, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05; bias = torch.randn(co, device=dev)
         o1 = torch.empty(N, co, H, W, device=dev); o2 = torch.empty_like(o1)
         pc, pw = ops.PackedConv(w, bias), ops.PackedWino(w, bias)
@@ -29,6 +31,7 @@ with torch.no_grad():
         tw = t(lambda: ops.conv_wino(x, pw, ops.CONV_RELU, o2))
         print('%-7s %3d->%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective)   maxdiff %.1e (|out| %.1f)' % (
             name, ci, co, td, flop / td / 1e6, tw, flop / 2.25 / tw / 1e6, flop / tw / 1e6, (o1 - o2).abs().max().item(), o1.abs().max().item()))
+    if only: sys.exit(0)
     print('--- encoder layers (fnet: bias + instance-norm moments; 48 images)')
     for name, c, hh, ww in (('layer1', 64, 256, 320), ('layer2', 96, 128, 160), ('layer3', 128, 64, 80)):
         nb = 48
