@@ -20,6 +20,7 @@
 // two waves turn the raw patch into V 4 x 32 x 16 (B^T d B) for the next step.  The 16 positions of a (channel, output
 // channel | tile) row are contiguous, so a lane's fragments for four positions are one 16-B LDS read.
 #include "rpe_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -103,6 +104,15 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+#ifdef WINO_TIMING
+// Experiment hook (tools/build_variant.sh ... -DWINO_TIMING): s_memtime stamps at the group boundaries of the main loop, summed over
+// the steps of workgroup (0, 0, 0), wave 0; read back with rpe_debug_wino_timing.
+__device__ unsigned long long g_wino_timing[8];
+extern "C" int rpe_debug_wino_timing(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wino_timing), 64) == hipSuccess ? 0 : -1; }
+#define STAMP(i) T[i] = __builtin_readcyclecounter()
+#else
+#define STAMP(i)
+#endif
 // CB = 16-channel blocks per wave: 2 -> 64 output channels per workgroup, 1 -> 32 (the trailing tile of cout = 96: no padded half)
 template <bool ENC, bool PRE, int CB>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
@@ -124,74 +134,79 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     const int nsteps = P.cin / WK;
 
     // ---- DMA roles.  Raw patch: chunk c = 3*wave + j, element e = 64 c + lane -> (ci, row, col) of the 4 x 10 x 18 patch, read
-    // from the clamped pixel (the mask is applied when the patch is transformed).  U: chunk c = 4*wave + j, plain copy.
+    // from the clamped pixel; in workgroups on the map's border the lane overwrites its out-of-map elements with the padding
+    // value once they have landed (patch_raw), so the transform itself carries no masks.  U: chunk c = 4*wave + j, plain copy.
     unsigned roff[3];                                         // byte offsets from (step's first channel - 512 B), chunk offset folded in
+    unsigned oob = 0;                                         // bit j: this lane's element of chunk j is outside the map
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        int e = (wv * 3 + j) * 64 + lane;
-        e = e < RAW_N ? e : RAW_N - 1;
+        const int e0 = (wv * 3 + j) * 64 + lane;
+        const int e = e0 < RAW_N ? e0 : RAW_N - 1;
         const int ci = e / RAW_CH, rem = e - ci * RAW_CH, r = rem / RAW_W, c = rem - r * RAW_W;
         int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        if (e0 < RAW_N && (yy < 0 || yy >= H || xx < 0 || xx >= W)) oob |= 1u << j;
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
         roff[j] = (unsigned)(ci * hw + yy * W + xx) * 4u + 512u - 256u * j;
     }
+    const bool border = (y0 < 1) | (y0 + 2 * WB_TY >= H) | (x0 < 1) | (x0 + 2 * WB_TX >= W);       // workgroup-uniform
+    // padding: zero; with the loader-side normalisation -inf, which relu((x - mean) / std) turns into the zero torch pads with (1/std > 0)
+    const float padv = PRE ? -__builtin_inff() : 0.0f;
+    auto patch_raw = [&](int buf) {
+        if (border) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if ((oob >> j) & 1) Rs[buf][(wv * 3 + j) * 64 + lane] = padv;
+        }
+    };
     // packed weights: [step][64-channel tile][ci][co % 64][16].  CB = 2: the wave's four 1 KB chunks are consecutive; CB = 1: wave =
     // input channel, its 32 rows start at row co0 % 64 of that channel's 64
     const float* wslice = CB == 2 ? P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)(wv * 4) * 256
                                   : P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)wv * (WB_CO * 16) + (size_t)(co0 % WB_CO) * 16;
     const unsigned uoff = lane * 16u;
-    const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP;
+    const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP, rstep = (size_t)WK * hw;
     const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 4096u : 2048u), rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(wv * 3) * 256u;
-    auto issue_u = [&](int step, int buf) {
-        step = step < nsteps ? step : nsteps - 1;                // (past the end: a harmless repeat keeps the same number of DMAs per step in flight)
-        if (CB == 2) dma16x4(wslice + (size_t)step * wstep, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
-        else dma16x2(wslice + (size_t)step * wstep, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
+    auto dma_u = [&](const float* src, int buf) {
+        if (CB == 2) dma16x4(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
+        else dma16x2(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
     };
-    auto issue_raw = [&](int step, int buf) {
-        step = step < nsteps ? step : nsteps - 1;
-        dma4x3(xb + (size_t)step * WK * hw - 128, roff[0], roff[1], roff[2], rs_base + (unsigned)buf * (RAW_BUF * 4u));
-    };
+    auto dma_raw = [&](const float* src, int buf) { dma4x3(src, roff[0], roff[1], roff[2], rs_base + (unsigned)buf * (RAW_BUF * 4u)); };
+    auto clamped = [&](int step) { return step < nsteps ? step : nsteps - 1; };    // (past the end: a harmless repeat keeps the DMA count per step constant)
+    const float* xsrc = xb - 128;                                                   // (the 512-B bias of roff)
 
     // ---- transform role: thread -> (half, input channel of the step, tile).  V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0;
-    // 0 -1 1 0; 0 1 0 -1]; half 0 produces position rows 0-1 (from patch rows 0-2), half 1 rows 2-3 (from patch rows 1-3).
+    // 0 -1 1 0; 0 1 0 -1].  Half 0 produces position rows 0-1: t0 = d0 - d2, t1 = d1 + d2; half 1 rows 2-3: t2 = d2 - d1,
+    // t3 = d1 - d3.  With the patch rows a thread reads ordered (A, B, C) = (d0, d2, d1) | (d2, d1, d3) both halves compute
+    // A - B and B + sigma C (sigma = +1 | -1, exact), so the column pass has no selects: vector instructions do NOT issue in the
+    // shadow of the f32 matrix instructions (measured: ~4 cycles each on top, experiments/mfma_filler_probe.hip), their count matters.
     const int v_half = tid >> 7, v_ci = (tid >> 5) & 3, v_tile = tid & 31, v_tx = v_tile & 7, v_ty = v_tile >> 3;
-    unsigned okmask = 0;                          // which of the 3 x 4 patch pixels this thread reads lie inside the map (else zero padding)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int yy = y0 + 2 * v_ty - 1 + v_half + r, xx = x0 + 2 * v_tx - 1 + c;
-            okmask |= ((yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)) ? (1u << (r * 4 + c)) : 0u;
-        }
-    const int v_src = v_ci * RAW_CH + (2 * v_ty + v_half) * RAW_W + 2 * v_tx;
-    constexpr bool pre = PRE;                                 // (a compile-time choice: a run-time select costs the transform ~60 vector instructions a step)
-    if (pre) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
+    const int v_base = v_ci * RAW_CH + 2 * v_ty * RAW_W + 2 * v_tx;
+    const int srcA = v_base + (v_half ? 2 : 0) * RAW_W, srcB = v_base + (v_half ? 1 : 2) * RAW_W, srcC = v_base + (v_half ? 3 : 1) * RAW_W;
+    const float sigma = v_half ? -1.0f : 1.0f;
+    if (PRE) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
         for (int i = tid; i < P.cin; i += 256) {
             const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
             Pn[2 * i] = -m * iv; Pn[2 * i + 1] = iv;
         }
     }
-    // The transform of step s+1 is written as three slices (read + mask, column pass, row pass + store) so that the main loop can
-    // place them between its groups of matrix instructions: their vector / LDS work then issues in the shadow of the matrix pipe.
-    float td[12], tta[4], ttb[4];
+    // The transform of step s+1 is written as three slices (patch reads, column pass, row pass + store) placed by the main loop
+    float tdA[4], tdB[4], tdC[4], tta[4], ttb[4];
+    float2 pn = make_float2(0.0f, 1.0f);
     auto tr_read = [&](int step, int rbuf) {
-        const float* rp = &Rs[rbuf][v_src];
-        const float pm = pre ? Pn[2 * (step * WK + v_ci)] : 0.0f, pi = pre ? Pn[2 * (step * WK + v_ci) + 1] : 1.0f;    // (-mean / std, 1 / std)
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = rp[r * RAW_W + c];
-                if (pre) v = fmaxf(fmaf(v, pi, pm), 0.0f);                    // relu((x - mean) / std); padding stays zero (mask below)
-                td[r * 4 + c] = (okmask >> (r * 4 + c)) & 1 ? v : 0.0f;
-            }
+        const float* rp = &Rs[rbuf][0];
+        const float2 a0 = *(const float2*)(rp + srcA), a1 = *(const float2*)(rp + srcA + 2), b0 = *(const float2*)(rp + srcB), b1 = *(const float2*)(rp + srcB + 2);
+        const float2 c0 = *(const float2*)(rp + srcC), c1 = *(const float2*)(rp + srcC + 2);
+        if (PRE) pn = *(const float2*)&Pn[2 * (step * WK + v_ci)];                   // (-mean / std, 1 / std)
+        tdA[0] = a0.x; tdA[1] = a0.y; tdA[2] = a1.x; tdA[3] = a1.y;
+        tdB[0] = b0.x; tdB[1] = b0.y; tdB[2] = b1.x; tdB[3] = b1.y;
+        tdC[0] = c0.x; tdC[1] = c0.y; tdC[2] = c1.x; tdC[3] = c1.y;
     };
     auto tr_cols = [&]() {
-        // half 0: t0 = d0 - d2, t1 = d1 + d2 (patch rows 0,1,2);  half 1: t2 = d2 - d1, t3 = d1 - d3 (its rows 0,1,2 = patch rows 1,2,3)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            tta[c] = v_half ? td[4 + c] - td[c] : td[c] - td[8 + c];
-            ttb[c] = v_half ? td[c] - td[8 + c] : td[4 + c] + td[8 + c];
+            float va = tdA[c], vb = tdB[c], vc = tdC[c];
+            if (PRE) { va = fmaxf(fmaf(va, pn.y, pn.x), 0.0f); vb = fmaxf(fmaf(vb, pn.y, pn.x), 0.0f); vc = fmaxf(fmaf(vc, pn.y, pn.x), 0.0f); }   // relu((x - mean) / std)
+            tta[c] = va - vb;
+            ttb[c] = fmaf(sigma, vc, vb);
         }
     };
     auto tr_store = [&](int vbuf) {
@@ -200,7 +215,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         *(f32x4*)&Vs[vbuf][v_ci][v_tile][8 * v_half] = va;
         *(f32x4*)&Vs[vbuf][v_ci][v_tile][8 * v_half + 4] = vb2;
     };
-    auto transform = [&](int step, int rbuf, int vbuf) { tr_read(step, rbuf); tr_cols(); tr_store(vbuf); };
 
     f32x4 acc[16][CB];
 #pragma unroll
@@ -210,81 +224,132 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
 
     // ---- prologue: U(0), raw(0), raw(1) land; V(0) is built; then the two DMA groups the loop expects in flight
-    issue_u(0, 0); issue_raw(0, 0); issue_raw(1, 1);
+    dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    patch_raw(0); patch_raw(1);
     __syncthreads();
-    transform(0, 0, 0);
+    tr_read(0, 0); tr_cols(); tr_store(0);
     __syncthreads();                                          // V(0) visible; raw(0)'s buffer free
-    issue_u(1, 1); issue_raw(2, 2);
-    issue_u(2, 2); issue_raw(3, 0);
+    dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
+    dma_u(wslice + (size_t)clamped(2) * wstep, 2); dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
+    const float* unext = wave_uniform(wslice + (size_t)clamped(3) * wstep);         // U(s + 3), raw(s + 4) of the step the loop is in
+    const float* rnext = wave_uniform(xsrc + (size_t)clamped(4) * rstep);
     // ---- step s, four groups of 8 (CB = 2) matrix instructions, one per four positions:
-    //   g0  | fragment reads of g1 | patch reads of raw(s+1), masks                          (all of this in the matrix pipe's shadow)
+    //   g0  | fragment reads of g1, patch reads of raw(s+1)
     //   g1  | fragment reads of g2 | column pass of the transform
-    //   g2  | fragment reads of g3 | row pass, V(s+1) stored | wait: own DMAs older than the last group landed | BARRIER
+    //   g2  | fragment reads of g3 | row pass, V(s+1) stored | wait: own DMAs older than the newest group landed | border: patch
+    //       raw(s+2) | BARRIER
     //   g3  | fragment reads of g0 of step s+1 (U(s+1), V(s+1) are visible now) | DMA U(s+3) -> U(s)'s buffer, raw(s+4) -> raw(s+1)'s
-    // so nothing but the barrier itself separates two steps' matrix instructions: the reads behind it and the DMA issue (60-180
-    // cycles per instruction) run beside g3.  A DMA group is issued two barriers before its data is read.
+    // so nothing but the barrier itself separates two steps' matrix instructions, and the vector instructions sit in two
+    // clusters (an isolated one between two matrix instructions costs ~13 cycles, one more in a cluster ~4).  A DMA group is
+    // issued two barriers before its data is read.  The ring positions are compile-time (the loop body is written out for
+    // the six (step % 3, step % 2) combinations): every LDS address is a per-thread constant + an immediate.
     // U rows are 64 B with no padding (they arrive by 1 KB DMA chunks), so position group g of row r sits in 16-B slot
     // g ^ ((r >> 2) & 3) (k_wino_pack stores it that way): the 16 rows of a fragment read then cover all 64 banks
     const int sw = (li >> 2) & 3;
     const int uoffl = (lk * TCO + cw * 16 * CB + li) * 16, voffl = (lk * WB_NT + tw * 16 + li) * PS;
     f32x4 fa0 = *(const f32x4*)(&Us[0][uoffl] + 4 * sw), fa1 = *(const f32x4*)(&Us[0][uoffl] + (CB == 2 ? 16 * 16 : 0) + 4 * sw), fb = *(const f32x4*)(&Vs[0][0][0][0] + voffl);
-    int ub = 0, rb1 = 1;                                      // s % 3, (s + 1) % 3
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        const float* ua = &Us[ub][uoffl];
-        const float* vb = &Vs[cur][0][0][0] + voffl;
-        const float* ua_n = &Us[rb1][uoffl];                  // U ring and raw ring turn together: (s + 1) % 3
-        const float* vb_n = &Vs[cur ^ 1][0][0][0] + voffl;
-        const int tstep = s + 1 < nsteps ? s + 1 : nsteps - 1;   // (last step: a redundant transform into the buffer nobody reads again)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 na0, na1, nb;
-            if (g < 3) { const int o = 4 * ((g + 1) ^ sw); na0 = *(const f32x4*)(ua + o); na1 = na0; if (CB == 2) na1 = *(const f32x4*)(ua + 16 * 16 + o); nb = *(const f32x4*)(vb + 4 * (g + 1)); }
-            else { na0 = *(const f32x4*)(ua_n + 4 * sw); na1 = na0; if (CB == 2) na1 = *(const f32x4*)(ua_n + 16 * 16 + 4 * sw); nb = *(const f32x4*)(vb_n); }
-#ifndef WINO_NOTR
-            if (g == 0) tr_read(tstep, rb1);
-            if (g == 1) tr_cols();
-            if (g == 2) tr_store(cur ^ 1);
+#ifdef WINO_TIMING
+    unsigned long long T[7] = {0, 0, 0, 0, 0, 0, 0}, Tp[7] = {0, 0, 0, 0, 0, 0, 0}, Ta[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
-            if (g < 3) {
+    auto mfma_group = [&](int g) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
-                    if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
-                }
-                // issue order inside this group: the LDS reads first, then each matrix instruction followed by a few vector ones
-                __builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
-#pragma unroll
-                for (int e = 0; e < 4 * CB; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, CB == 2 ? 4 : 8, 0); }
-                __builtin_amdgcn_sched_barrier(0);
-                if (g == 2) {
-                    // own DMAs except the newest group (2 * CB weight + 3 patch instructions) have landed, the V stores and every
-                    // fragment read of this step are complete: after the barrier U(s), V(s) and raw(s+1) may be overwritten
-#ifndef WINO_NOWAIT
-                    if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F77 & ~0x0F00); else __builtin_amdgcn_s_waitcnt(0x0F75 & ~0x0F00);     // vmcnt(7|5) lgkmcnt(0)
-#endif
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
-                    if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#ifndef WINO_NODMA
-                    if (e == 0) issue_u(s + 3, ub);
-                    if (e == 1) issue_raw(s + 4, rb1);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            fa0 = na0; fa1 = na1; fb = nb;
+        for (int e = 0; e < 4; ++e) {
+            acc[4 * g + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[4 * g + e][0], 0, 0, 0);
+            if (CB == 2) acc[4 * g + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[4 * g + e][CB - 1], 0, 0, 0);
         }
-        ub = rb1; rb1 = rb1 == 2 ? 0 : rb1 + 1;
+    };
+    auto step = [&](auto ubc, auto curc, const int s) {
+        constexpr int UB = decltype(ubc)::value, CUR = decltype(curc)::value, UB1 = (UB + 1) % 3, UB2 = (UB + 2) % 3;
+        const float* ua = &Us[UB][uoffl];
+        const float* vb = &Vs[CUR][0][0][0] + voffl;
+        const int tstep = s + 1 < nsteps ? s + 1 : nsteps - 1;   // (last step: a redundant transform into the buffer nobody reads again)
+        f32x4 na0, na1, nb;
+        auto frag_reads = [&](const float* u, const float* v, int slot, int vpos) {
+            na0 = *(const f32x4*)(u + 4 * (slot ^ sw)); na1 = na0;
+            if (CB == 2) na1 = *(const f32x4*)(u + 16 * 16 + 4 * (slot ^ sw));
+            nb = *(const f32x4*)(v + vpos);
+        };
+        STAMP(0);
+        // g0
+        frag_reads(ua, vb, 1, 4);
+        tr_read(tstep, UB1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fa0 = na0; fa1 = na1; fb = nb;
+        STAMP(1);
+        // g1
+        frag_reads(ua, vb, 2, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        tr_cols();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1);
+        __builtin_amdgcn_sched_barrier(0);
+        fa0 = na0; fa1 = na1; fb = nb;
+        STAMP(2);
+        // g2
+        frag_reads(ua, vb, 3, 12);
+        __builtin_amdgcn_sched_barrier(0);
+        tr_store(CUR ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(2);
+        __builtin_amdgcn_sched_barrier(0);
+        fa0 = na0; fa1 = na1; fb = nb;
+        STAMP(3);
+        // own DMAs except the newest group (2 * CB weight + 3 patch instructions) have landed; the V stores and every fragment
+        // read of this step are complete: after the barrier U(s), V(s) and raw(s+1) may be overwritten
+        if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F77); else __builtin_amdgcn_s_waitcnt(0x0F75);     // vmcnt(7 | 5)
+        patch_raw(UB2);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                             // lgkmcnt(0)
+        STAMP(4);
+        __builtin_amdgcn_s_barrier();
+        STAMP(5);
+#ifdef WINO_TIMING
+        if (s > 1) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Ta[i] += Tp[i + 1] - Tp[i];
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        // g3
+        frag_reads(&Us[UB1][uoffl], &Vs[CUR ^ 1][0][0][0] + voffl, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[12 + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[12 + e][0], 0, 0, 0);
+            if (CB == 2) acc[12 + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[12 + e][CB - 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (e == 0) { dma_u(unext, UB); if (s + 4 < nsteps) unext += wstep; }
+            if (e == 1) { dma_raw(rnext, UB1); if (s + 5 < nsteps) rnext += rstep; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fa0 = na0; fa1 = na1; fb = nb;
+#ifdef WINO_TIMING
+        STAMP(6);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) Tp[i] = T[i];
+#endif
+    };
+    {
+        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+        int s = 0;
+        while (true) {
+            step(I0{}, I0{}, s); if (++s == nsteps) break;
+            step(I1{}, I1{}, s); if (++s == nsteps) break;
+            step(I2{}, I0{}, s); if (++s == nsteps) break;
+            step(I0{}, I1{}, s); if (++s == nsteps) break;
+            step(I1{}, I0{}, s); if (++s == nsteps) break;
+            step(I2{}, I1{}, s); if (++s == nsteps) break;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // the repeats issued past the end have landed before LDS is released
+#ifdef WINO_TIMING
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && tid == 0) {
+        for (int i = 0; i < 6; ++i) g_wino_timing[i] = Ta[i];
+        g_wino_timing[6] = nsteps - 2; g_wino_timing[7] = 0;
+    }
+#endif
 
     // ---- epilogue.  D layout of the 16x16 MFMA: column (tile) = lane % 16, row (channel) = 4 * (lane / 16) + r.
     // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; then scale / bias, moments, ReLU, residual, and the store(s) into the channel slices.

@@ -31,6 +31,12 @@ with torch.no_grad():
         tw = t(lambda: ops.conv_wino(x, pw, ops.CONV_RELU, o2))
         print('%-7s %3d->%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective)   maxdiff %.1e (|out| %.1f)' % (
             name, ci, co, td, flop / td / 1e6, tw, flop / 2.25 / tw / 1e6, flop / tw / 1e6, (o1 - o2).abs().max().item(), o1.abs().max().item()))
+        if hasattr(rpe_amd._lib.lib(), 'rpe_debug_wino_timing'):               # -DWINO_TIMING variant builds only
+            import ctypes
+            buf = (ctypes.c_ulonglong * 8)()
+            rpe_amd._lib.lib().rpe_debug_wino_timing(buf)
+            n = max(buf[6], 1)
+            print('        cycles per step, one wave: g0 %.0f  g1 %.0f  g2 %.0f  wait %.0f  barrier %.0f  g3 %.0f' % tuple(buf[i] / n for i in range(6)))
     if only: sys.exit(0)
     print('--- encoder layers (fnet: bias + instance-norm moments; 48 images)')
     for name, c, hh, ww in (('layer1', 64, 256, 320), ('layer2', 96, 128, 160), ('layer3', 128, 64, 80)):
