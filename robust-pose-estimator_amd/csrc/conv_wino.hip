@@ -313,6 +313,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
 #endif
         __builtin_amdgcn_sched_barrier(0);
         // g3
+#ifdef WINO_DMA_EARLY
+        dma_u(unext, UB); if (s + 4 < nsteps) unext += wstep;
+        dma_raw(rnext, UB1); if (s + 5 < nsteps) rnext += rstep;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         frag_reads(&Us[UB1][uoffl], &Vs[CUR ^ 1][0][0][0] + voffl, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -320,8 +325,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             acc[12 + e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[e], fb[e], acc[12 + e][0], 0, 0, 0);
             if (CB == 2) acc[12 + e][CB - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[e], fb[e], acc[12 + e][CB - 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef WINO_DMA_EARLY
+#ifdef WINO_U_HOT
+            if (e == 0) { dma_u(unext, UB); }
+#else
             if (e == 0) { dma_u(unext, UB); if (s + 4 < nsteps) unext += wstep; }
+#endif
+#ifdef WINO_RAW_HOT
+            if (e == 1) { dma_raw(rnext, UB1); }
+#else
             if (e == 1) { dma_raw(rnext, UB1); if (s + 5 < nsteps) rnext += rstep; }
+#endif
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         fa0 = na0; fa1 = na1; fb = nb;
