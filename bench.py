@@ -50,8 +50,8 @@ def conv_roofline(events, steps):
             'tflop_per_step': flop / max(1, steps) / 1e12}
 
 
-def wino_roofline(events, steps):
-    """k_conv_wino (the update block's four 3x3 layers and the encoders' stride-1 layers as Winograd F(2x2,3x3)): EXECUTED matrix FLOPs over HIP-event time
+def wino_roofline(events, steps, kernel='k_conv_wino'):
+    """k_conv_wino1d (the GRU's 1x5 / 5x1 convolutions as Winograd F(4,5) along the axis, gate epilogues included) and k_conv_wino (the update block's four 3x3 layers and the encoders' stride-1 layers as Winograd F(2x2,3x3)): EXECUTED matrix FLOPs over HIP-event time
     against the f32 MFMA peak (so frac <= 1); ``effective`` = the direct convolution's FLOPs over the same time."""
     if not events:
         return None
@@ -59,7 +59,7 @@ def wino_roofline(events, steps):
     ex = sum(f for _, _, f, _ in events)
     eff = sum(f for _, _, _, f in events)
     tf = ex / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {'kernel': 'k_conv_wino', 'bound': 'mfma', 'achieved': tf, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+    return {'kernel': kernel, 'bound': 'mfma', 'achieved': tf, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tf / F32_MFMA_PEAK_TFLOPS, 'effective_tflops_direct_equivalent': eff / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
             'launches_per_step': len(events) // max(1, steps), 'ms_per_step': ms / max(1, steps),
             'executed_tflop_per_step': ex / max(1, steps) / 1e12}
@@ -263,13 +263,14 @@ def run_batch(args, rank, world, dev, dist):
     rpe_amd.pose_head.ops.pose_solve = timed_solve
 
     # the fused convolutions (k_conv_igemm): FLOPs and HIP-event time of every launch inside the timed region
-    conv_events = []
+    conv_events, wino1d_events = [], []
     real_conv = rpe_amd.ops.conv_fused
 
     def timed_conv(x, pc, *a, **k):
         if k.get('prepare'):                       # the GRU loop's prepared launchers: time every launch of them
             launch = real_conv(x, pc, *a, **k)
             flop = 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * pc.cin * pc.cout * pc.kh * pc.kw
+            wino1d = k.get('entry') == 'rpe_conv_wino1d'       # (ops.conv_wino1d goes through conv_fused): 8 products per 4 outputs, not 20
 
             def timed_launch():
                 if not timing['on']:
@@ -278,7 +279,10 @@ def run_batch(args, rank, world, dev, dist):
                 e0.record()
                 r = launch()
                 e1.record()
-                conv_events.append((e0, e1, flop))
+                if wino1d:
+                    wino1d_events.append((e0, e1, flop * 0.4, flop))
+                else:
+                    conv_events.append((e0, e1, flop))
                 return r
             return timed_launch
         if not timing['on']:
@@ -374,6 +378,7 @@ def run_batch(args, rank, world, dev, dist):
                      'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
         'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
         'roofline_conv': conv_roofline(conv_events, args.steps),
+        'roofline_conv_winograd_1d': wino_roofline(wino1d_events, args.steps, 'k_conv_wino1d'),
         'roofline_conv_winograd': wino_roofline(wino_events, args.steps),
         'solver_iters_run': {'min': int(info[:, 0].min()), 'max': int(info[:, 0].max())},
         'valid_fraction': float(gpu_in['mask2'].float().mean()),

@@ -282,6 +282,15 @@ size_t rpe_conv_wino_packed_floats(int cout, int cin);
 int rpe_conv_wino_stats_tiles(int h, int w);
 int rpe_conv_wino_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv_wino(const rpe_conv_desc *desc, void *stream);
+/* The same operation for 1x5 / 5x1 stride-1 convolutions (w % 4 == 0, cin % 4 == 0; tensors 16-byte aligned) with every
+ * epilogue mode of rpe_conv_fused incl. the GRU gates (add, hidden, zgate, out2, gate_channels), as Winograd F(4,5) along the
+ * filter axis on the f32 matrix cores: 8 products per 4 outputs instead of 20 (csrc/conv_wino1d.hip; SepConvGRU's convz|convr
+ * and convq, core/RAFT/core/update.py).  desc->packed must come from rpe_conv_wino1d_pack (weight (cout, cin, 5) = the
+ * contiguous (cout, cin, 1, 5) or (cout, cin, 5, 1) tensor; rpe_conv_wino1d_packed_floats floats, 0 = unsupported shape);
+ * kh, kw select the axis.  scale / residual / stats / pre_norm -> RPE_E_UNSUPPORTED. */
+size_t rpe_conv_wino1d_packed_floats(int cout, int cin);
+int rpe_conv_wino1d_pack(const float *weight, int cout, int cin, float *packed, void *stream);
+int rpe_conv_wino1d(const rpe_conv_desc *desc, void *stream);
 /* number of pixel tiles (= moment records per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input);
  * the launcher and this function share one tile-width rule */
 int rpe_conv_stats_tiles(int cout, int h, int w, int stride);

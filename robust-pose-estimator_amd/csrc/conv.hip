@@ -43,7 +43,6 @@ struct ConvP {
     const float* pre;                         // [b][cin][2] (mean, 1/std) or null: the input is normalised + ReLU'd as it is staged
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Sum over each 32-lane half of the wave with DPP moves (VALU rate, no LDS traffic): quad butterflies, row half-mirror,
 // row mirror, then lane 15 of each even 16-lane row is broadcast into the odd row.  Lanes 31 and 63 hold the totals.

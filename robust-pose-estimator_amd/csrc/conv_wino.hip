@@ -19,10 +19,8 @@
 // one step ahead the matrix pipe waited for L2 most of the time: 60 TFLOP/s executed against 104 with the loads removed);
 // two waves turn the raw patch into V 4 x 32 x 16 (B^T d B) for the next step.  The 16 positions of a (channel, output
 // channel | tile) row are contiguous, so a lane's fragments for four positions are one 16-B LDS read.
-#include "rpe_common.h"
+#include "wino_common.h"
 #include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WB_CO 64
 #define WB_TX 8
@@ -52,34 +50,6 @@ struct WinoP {
     int co_base;                                  // first output channel of this launch (a trailing 32-channel tile is its own launch)
 };
 
-// LDS-DMA (global -> LDS without staging registers): every lane supplies its own global address, the destination is the
-// wave-uniform LDS byte address + lane * size.  Issued as inline asm ON PURPOSE: hipcc waits vmcnt(0) in front of every
-// LDS read while one of ITS loads-to-LDS is in flight (it cannot tell the buffers apart), which would serialise the
-// three-deep prefetch; these it does not count, and the kernel waits for them itself (s_waitcnt vmcnt(N), in order).
-// The global address is a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset + the instruction offset, and the instruction
-// offset is added to the LDS address as well: one M0 set-up and no 64-bit vector address arithmetic per group of DMAs.
-__device__ __forceinline__ const float* wave_uniform(const float* p) {          // pins a wave-uniform pointer to scalar registers
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const float*)(((unsigned long long)hi << 32) | lo);
-}
-// four 1 KB chunks: global base + voff + 1024 j  ->  LDS lds_addr + 1024 j + lane * 16
-__device__ __forceinline__ void dma16x4(const float* base, unsigned voff, unsigned lds_addr) {
-    unsigned keep;
-    base = wave_uniform(base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
-}
-// two 1 KB chunks (the 32-channel tile: one input channel's 32 rows)
-__device__ __forceinline__ void dma16x2(const float* base, unsigned voff, unsigned lds_addr) {
-    unsigned keep;
-    base = wave_uniform(base);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
-}
 // three 256-B chunks of gathered dwords: global base + v_j + 256 j  ->  LDS lds_addr + 256 j + lane * 4   (the caller folds the
 // -256 j into v_j and keeps it non-negative by biasing the base)
 __device__ __forceinline__ void dma4x3(const float* base, unsigned v0, unsigned v1, unsigned v2, unsigned lds_addr) {
@@ -90,20 +60,6 @@ __device__ __forceinline__ void dma4x3(const float* base, unsigned v0, unsigned 
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(base), "s"(lds_addr) : "memory");
 }
-// Sum over each 16-lane row of the wave with DPP moves (vector-ALU rate, no LDS traffic): quad butterflies, row half-mirror,
-// row mirror.  Every lane ends with its row's total.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    return v;
-}
-
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
-
 #ifdef WINO_TIMING
 // Experiment hook (tools/build_variant.sh ... -DWINO_TIMING): s_memtime stamps at the group boundaries of the main loop, summed over
 // the steps of workgroup (0, 0, 0), wave 0; read back with rpe_debug_wino_timing.

@@ -1,0 +1,365 @@
+// The separable 1x5 / 5x1 convolutions of RAFT's SepConvGRU as Winograd F(4, 5) along the filter axis, on the f32 matrix cores.
+//
+// Replaces (reference's RAFT submodule, call sites core/pose/pose_net.py:47,65,129), twelve times per pass:
+//   core/RAFT/core/update.py  SepConvGRU.convz1|convr1, convq1 (1x5) and convz2|convr2, convq2 (5x1) with their gate
+//   arithmetic (sigmoid, r*h, tanh, the convex update of h) fused into the epilogue, like rpe_conv_fused's gate modes.
+// These are the largest single share of a pass (a direct implicit GEMM needs 5 multiply-adds per output and input channel);
+// Toom-Cook / Winograd F(4,5) computes 4 outputs of a 5-tap filter from 8 products instead of 20 (Lavin & Gray 2016, 1-D):
+//     y = A^T [ (G g) .* (B^T d) ],  d = 8 consecutive inputs, g = the 5 taps, points {0, +-1, +-2, +-1/2, inf}
+//   (B^T is the 8-point matrix of F(6,3); every entry is dyadic, so B^T d is exact up to the usual rounding of its sums).
+// In f32 the result differs from a direct f32 accumulation by about as much as two different summation orders do
+// (measured on 256-channel sums: mean |err| 6e-6 against 2.4e-6 for a serial direct sum, tools note in DESIGN.md).
+//
+// Workgroup = 4 waves = 64 output channels x 64 tiles (16 x 16 output pixels; a tile = 4 pixels along the filter axis);
+// wave = 32 channels x 32 tiles = 2 x 2 blocks of v_mfma_f32_16x16x4_f32 per position, 8 positions: 128 accumulator
+// registers.  K is walked in steps of 4 input channels; the pipeline (LDS-DMA rings for the transformed weights U and the raw
+// input patch, V = B^T d built one step ahead, the barrier in front of the last quarter of a step's matrix instructions)
+// is conv_wino.hip's, which explains it.  A (channel | tile) row holds its 8 positions contiguously (32 B): a fragment read is
+// 16 B = four positions; the two halves of row r are swapped when ((r >> 2) ^ (r >> 3)) & 1 so that the 16 lanes of a read
+// group cover all 64 banks.
+#include "wino_common.h"
+#include <type_traits>
+
+#define W1_CO 64
+#define W1_NT 64
+#define W1_K 4
+#define W1_ROW 8
+#define W1_USTEP (W1_K * W1_CO * W1_ROW)          // 2048 floats = 8 KB: weights of a step for 64 output channels = V of a step
+#define W1_RAWF 1536                              // raw patch of a step: 1x5: 4 ci x 16 rows x 24 columns; 5x1: 4 ci x 20 rows x 16 columns
+#define W1_BIAS 1024u                             // keeps the per-lane DMA offsets non-negative
+
+struct W1P {
+    const float* x; long long xbs;
+    const float* wp; int cin, cout, coP, H, W;
+    const float* bias; const float* add; long long abs_;
+    float* out; long long obs; float* out2; long long o2bs;
+    const float* hid; long long hbs; const float* z; long long zbs;
+    int cgate, mode;
+};
+
+__device__ __forceinline__ int row_swap(int r) { return ((r >> 2) ^ (r >> 3)) & 1; }
+
+template <bool VERT>
+__global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
+    __shared__ __attribute__((aligned(16))) float Us[3][W1_USTEP];            // [ci][co][8 positions], as packed in global memory
+    __shared__ __attribute__((aligned(16))) float Vs[2][W1_USTEP];            // [ci][tile][8 positions]
+    __shared__ __attribute__((aligned(16))) float Rs[3][W1_RAWF];             // raw input patch [ci][row][column]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptx = (P.W + 15) / 16;
+    const int x0 = (blockIdx.x % ptx) * 16, y0 = (blockIdx.x / ptx) * 16;
+    const int co0 = blockIdx.y * W1_CO, bz = blockIdx.z;
+    const int H = P.H, W = P.W, hw = H * W;
+    const float* xb = P.x + (size_t)bz * P.xbs;
+    const int nsteps = P.cin / W1_K;
+
+    // ---- DMA roles.  Raw patch in 16-B quads (W % 4 == 0): 1x5: columns x0-4 .. x0+19 of 16 rows, 6 quads a row, 384 a step =
+    // 8 instructions of 48 lanes; 5x1: rows y0-2 .. y0+17 of 16 columns, 320 quads = 8 instructions of 40 lanes (the other lanes
+    // are masked off).  Quads outside the map are read from the clamped position and zeroed after they have landed (border
+    // workgroups only).  U: the step's 8 KB slice, two 1 KB chunks per wave.
+    constexpr int LANES = VERT ? 40 : 48, RQ_CI = VERT ? 80 : 96, RQ_ROW = VERT ? 4 : 6;
+    constexpr unsigned RSTRIDE = LANES * 16u;
+    unsigned roff[2] = {0u, 0u};
+    unsigned oob = 0;
+    if (lane < LANES) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = LANES * (2 * wv + j) + lane;
+            const int ci = q / RQ_CI, rem = q - ci * RQ_CI, r = rem / RQ_ROW, cq = rem - r * RQ_ROW;
+            int yy = VERT ? y0 - 2 + r : y0 + r, xx = VERT ? x0 + 4 * cq : x0 - 4 + 4 * cq;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) oob |= 1u << j;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 4 : xx);
+            roff[j] = (unsigned)(ci * hw + yy * W + xx) * 4u + W1_BIAS - RSTRIDE * j;
+        }
+    }
+    const bool border = VERT ? ((y0 < 2) | (y0 + 18 > H) | (x0 + 16 > W)) : ((y0 + 16 > H) | (x0 < 4) | (x0 + 20 > W));       // workgroup-uniform
+    auto patch_raw = [&](int buf) {
+        if (border) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if ((oob >> j) & 1) *(f32x4*)&Rs[buf][4 * (LANES * (2 * wv + j) + lane)] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    const float* wslice = P.wp + (size_t)(co0 / W1_CO) * W1_USTEP + (size_t)(wv * 2) * 256;
+    const unsigned uoff = lane * 16u;
+    const size_t wstep = (size_t)(P.coP / W1_CO) * W1_USTEP, rstep = (size_t)W1_K * hw;
+    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * 2048u, rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(2 * wv) * RSTRIDE;
+    const unsigned long long lane_mask = (1ull << LANES) - 1ull;
+    auto dma_u = [&](const float* src, int buf) { dma16x2(src, uoff, us_base + (unsigned)buf * (W1_USTEP * 4u)); };
+    auto dma_raw = [&](const float* src, int buf) { dma16x2_masked<RSTRIDE>(src, roff[0], roff[1], rs_base + (unsigned)buf * (W1_RAWF * 4u), lane_mask); };
+    auto clamped = [&](int step) { return step < nsteps ? step : nsteps - 1; };    // (past the end: a harmless repeat keeps the DMA count per step constant)
+    const float* xsrc = xb - W1_BIAS / 4;
+
+    // ---- transform role: thread -> (input channel of the step = wave, tile = lane).  V = B^T d, 8 positions from the 8 inputs
+    // d_k = x[4 t - 2 + k] along the axis:
+    //   v0 = d0 - d6 + 21/4 (d4 - d2)                      v7 = d7 - d1 + 21/4 (d3 - d5)
+    //   v1|v2 = (d2 + d6 - 17/4 d4) +- (d1 + d5 - 17/4 d3)
+    //   v3|v4 = (d6 + 1/4 d2 - 5/4 d4) +- (1/2 d1 - 5/2 d3 + 2 d5)
+    //   v5|v6 = (d6 + 4 d2 - 5 d4) +- (2 d1 - 5/2 d3 + 1/2 d5)
+    const int t_src = VERT ? wv * (RQ_CI * 4) + (4 * (lane >> 4)) * 16 + (lane & 15) : wv * (RQ_CI * 4) + (lane >> 2) * 24 + 4 * (lane & 3) + 2;
+    const int t_dst = (wv * W1_NT + lane) * W1_ROW, t_swap = row_swap(lane & 15);
+    float d[8];
+    f32x4 vlo, vhi;
+    auto tr_read = [&](int rbuf) {
+        const float* rp = &Rs[rbuf][t_src];
+        if (VERT) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = rp[16 * k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) { const float2 v = *(const float2*)(rp + k); d[k] = v.x; d[k + 1] = v.y; }
+        }
+    };
+    auto tr_math = [&]() {
+        const float a12 = fmaf(-4.25f, d[4], d[2] + d[6]), b12 = fmaf(-4.25f, d[3], d[1] + d[5]);
+        const float a34 = fmaf(-1.25f, d[4], fmaf(0.25f, d[2], d[6])), b34 = fmaf(2.0f, d[5], fmaf(-2.5f, d[3], 0.5f * d[1]));
+        const float a56 = fmaf(-5.0f, d[4], fmaf(4.0f, d[2], d[6])), b56 = fmaf(0.5f, d[5], fmaf(-2.5f, d[3], 2.0f * d[1]));
+        vlo = (f32x4){fmaf(5.25f, d[4] - d[2], d[0] - d[6]), a12 + b12, a12 - b12, a34 + b34};
+        vhi = (f32x4){a34 - b34, a56 + b56, a56 - b56, fmaf(5.25f, d[3] - d[5], d[7] - d[1])};
+    };
+    auto tr_store = [&](int vbuf) {
+        *(f32x4*)&Vs[vbuf][t_dst + 4 * t_swap] = vlo;
+        *(f32x4*)&Vs[vbuf][t_dst + 4 * (t_swap ^ 1)] = vhi;
+    };
+
+    f32x4 acc[8][2][2];                                        // [position][channel block][tile block]
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[p][c][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
+
+    // ---- prologue: U(0), raw(0), raw(1) land; V(0) is built; then the two DMA groups the loop expects in flight
+    dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    patch_raw(0); patch_raw(1);
+    __syncthreads();
+    tr_read(0); tr_math(); tr_store(0);
+    __syncthreads();                                          // V(0) visible; raw(0)'s buffer free
+    dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
+    dma_u(wslice + (size_t)clamped(2) * wstep, 2); dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
+    const float* unext = wave_uniform(wslice + (size_t)clamped(3) * wstep);         // U(s + 3), raw(s + 4) of the step the loop is in
+    const float* rnext = wave_uniform(xsrc + (size_t)clamped(4) * rstep);
+    // ---- step s: four groups of 8 matrix instructions = (positions 0-3 | 4-7) x (channel block 0 | 1), each against both tile blocks:
+    //   g0 (lo, c0) | read A(lo, c1); patch reads of raw(s+1)
+    //   g1 (lo, c1) | read A(hi, c0), B(hi, t0), B(hi, t1) | the transform's arithmetic (one cluster: vector instructions are not
+    //               hidden by f32 matrix instructions, an isolated one costs ~13 cycles, one more in a cluster ~4)
+    //   g2 (hi, c0) | read A(hi, c1) | V(s+1) stored | wait: own DMAs older than the newest group landed | border: patch raw(s+2) | BARRIER
+    //   g3 (hi, c1) | read A(lo, c0), B(lo, t0), B(lo, t1) of step s+1 | DMA U(s+3) -> U(s)'s buffer, raw(s+4) -> raw(s+1)'s
+    const int sl = 4 * row_swap(li);                          // float offset of the logical low half within this lane's rows
+    const int aoff = (lk * W1_CO + cw * 32 + li) * W1_ROW, boff = (lk * W1_NT + tw * 32 + li) * W1_ROW;
+    f32x4 fa = *(const f32x4*)&Us[0][aoff + sl], fb0 = *(const f32x4*)&Vs[0][boff + sl], fb1 = *(const f32x4*)&Vs[0][boff + 16 * W1_ROW + sl];
+    auto mfma_group = [&](int half, int cb, const f32x4& a, const f32x4& b0, const f32x4& b1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[4 * half + e][cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[4 * half + e][cb][0], 0, 0, 0);
+            acc[4 * half + e][cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc[4 * half + e][cb][1], 0, 0, 0);
+        }
+    };
+    auto step = [&](auto ubc, auto curc, const int s) {
+        constexpr int UB = decltype(ubc)::value, CUR = decltype(curc)::value, UB1 = (UB + 1) % 3, UB2 = (UB + 2) % 3;
+        const float* ua = &Us[UB][aoff];
+        const float* vb = &Vs[CUR][boff];
+        // g0
+        const f32x4 a_lo1 = *(const f32x4*)(ua + 16 * W1_ROW + sl);
+        tr_read(UB1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, 0, fa, fb0, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // g1
+        const f32x4 a_hi0 = *(const f32x4*)(ua + (sl ^ 4)), b_hi0 = *(const f32x4*)(vb + (sl ^ 4)), b_hi1 = *(const f32x4*)(vb + 16 * W1_ROW + (sl ^ 4));
+        __builtin_amdgcn_sched_barrier(0);
+        tr_math();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, 1, a_lo1, fb0, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // g2
+        const f32x4 a_hi1 = *(const f32x4*)(ua + 16 * W1_ROW + (sl ^ 4));
+        __builtin_amdgcn_sched_barrier(0);
+        tr_store(CUR ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, 0, a_hi0, b_hi0, b_hi1);
+        __builtin_amdgcn_sched_barrier(0);
+        // own DMAs except the newest group (2 weight + 2 patch instructions) have landed; the V stores and every fragment read
+        // of this step are complete: after the barrier U(s), V(s) and raw(s+1) may be overwritten
+        __builtin_amdgcn_s_waitcnt(0x0F74);                                      // vmcnt(4)
+        patch_raw(UB2);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                      // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // g3
+        fa = *(const f32x4*)&Us[UB1][aoff + sl]; fb0 = *(const f32x4*)&Vs[CUR ^ 1][boff + sl]; fb1 = *(const f32x4*)&Vs[CUR ^ 1][boff + 16 * W1_ROW + sl];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[4 + e][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi1[e], b_hi0[e], acc[4 + e][1][0], 0, 0, 0);
+            acc[4 + e][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi1[e], b_hi1[e], acc[4 + e][1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (e == 0) { dma_u(unext, UB); if (s + 4 < nsteps) unext += wstep; }
+            if (e == 1) { dma_raw(rnext, UB1); if (s + 5 < nsteps) rnext += rstep; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+        int s = 0;
+        while (true) {
+            step(I0{}, I0{}, s); if (++s == nsteps) break;
+            step(I1{}, I1{}, s); if (++s == nsteps) break;
+            step(I2{}, I0{}, s); if (++s == nsteps) break;
+            step(I0{}, I1{}, s); if (++s == nsteps) break;
+            step(I1{}, I0{}, s); if (++s == nsteps) break;
+            step(I2{}, I1{}, s); if (++s == nsteps) break;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // the repeats issued past the end have landed before LDS is released
+
+    // ---- epilogue.  D layout of the 16x16 MFMA: column (tile) = lane % 16, row (channel) = 4 * (lane / 16) + r.
+    // y = A^T m:  y0 = m0 + (m1+m2) + (m3+m4) + (m5+m6);   y1 = (m1-m2) + 2 (m3-m4) + 1/2 (m5-m6);
+    //             y2 = (m1+m2) + 4 (m3+m4) + 1/4 (m5+m6);   y3 = (m1-m2) + 8 (m3-m4) + 1/8 (m5-m6) + m7;  then the gate arithmetic.
+    const int mode = P.mode, cg = P.cgate;
+    const float* addb = P.add ? P.add + (size_t)bz * P.abs_ : nullptr;
+    const float* hb = P.hid ? P.hid + (size_t)bz * P.hbs : nullptr;
+    const float* zb = P.z ? P.z + (size_t)bz * P.zbs : nullptr;
+    float* outb = P.out + (size_t)bz * P.obs;
+    float* out2b = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+    const int pstride = VERT ? W : 1;                           // distance of a tile's four pixels
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tile = tw * 32 + tb * 16 + li;
+        const int oy = VERT ? y0 + 4 * (tile >> 4) : y0 + (tile >> 2), ox = VERT ? x0 + (tile & 15) : x0 + 4 * (tile & 3);
+        bool pok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pok[i] = VERT ? (oy + i < H) & (ox < W) : (oy < H) & (ox < W);
+        auto ld4 = [&](const float* p, size_t e, float (&v)[4]) {
+            if (VERT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = pok[i] ? p[e + (size_t)i * W] : 0.0f;
+            } else {
+                const f32x4 q = pok[0] ? *(const f32x4*)(p + e) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+            }
+        };
+        auto st4 = [&](float* p, size_t e, const float (&v)[4]) {
+            if (VERT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (pok[i]) p[e + (size_t)i * W] = v[i];
+            } else if (pok[0]) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
+        };
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+                if (co >= P.cout) continue;
+                float m[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) m[p] = acc[p][cb][tb][r];
+                const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+                float v[4] = {((m[0] + s12) + s34) + s56, fmaf(0.5f, d56, fmaf(2.0f, d34, d12)), fmaf(0.25f, s56, fmaf(4.0f, s34, s12)),
+                              m[7] + fmaf(0.125f, d56, fmaf(8.0f, d34, d12))};
+                const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
+                const float bi = P.bias ? P.bias[co] : 0.0f;
+                float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (addb) ld4(addb, e0, av);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + av[i] + bi;
+                if (mode == RPE_CONV_GATE_ZR) {
+                    // z = sigmoid(.) -> out (channels < gate_channels);  r = sigmoid(.), r * h -> out2 (the other half)
+                    float sg[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sg[i] = sigmoid_f(v[i]);
+                    if (co >= cg) {
+                        const size_t eh = e0 - (size_t)cg * hw;
+                        float hv[4]; ld4(hb, eh, hv);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sg[i] *= hv[i];
+                        st4(out2b, eh, sg);
+                    } else st4(outb, e0, sg);
+                } else if (mode == RPE_CONV_GATE_H) {
+                    // h <- (1 - z) h + z tanh(.)
+                    float zv[4], hv[4]; ld4(zb, e0, zv); ld4(hb, e0, hv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - zv[i]) * hv[i] + zv[i] * tanhf(v[i]);
+                    st4(outb, e0, v);
+                } else {
+                    if (mode == RPE_CONV_RELU) {                                  // NaN stays NaN, like torch.relu
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] < 0.0f ? 0.0f : v[i];
+                    }
+                    st4(outb, e0, v);
+                    if (out2b) st4(out2b, e0, v);
+                }
+            }
+    }
+    (void)pstride;
+}
+
+// weight (cout, cin, 5 taps) [= (cout, cin, 1, 5) or (cout, cin, 5, 1)] -> U = G g, laid out
+// [step = ci/4][co tile = co/64][ci%4][co%64][8 positions; halves swapped when row_swap(co % 16)]: a workgroup's slice of a step is
+// 8 KB contiguous (its LDS image)
+__global__ void k_wino1d_pack(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int coP, long long total) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int slot = (int)(e & 7), col = (int)((e >> 3) & 63), cil = (int)((e >> 9) & 3);
+    const int pos = (((slot >> 2) ^ row_swap(col & 15)) << 2) | (slot & 3);
+    const long long rest = e >> 11;
+    const int ncot = coP / W1_CO;
+    const int co = (int)(rest % ncot) * W1_CO + col, ci = (int)(rest / ncot) * W1_K + cil;
+    double v = 0.0;
+    if (co < cout && ci < cin) {
+        const float* g = w + ((size_t)co * cin + ci) * 5;
+        // G = the evaluation matrix at {0, 1, -1, 2, -2, 1/2, -1/2, inf}, rows scaled to match the dyadic B^T used by the kernel
+        const double G[8][5] = {{1.0, 0.0, 0.0, 0.0, 0.0},
+                                {-2.0 / 9.0, -2.0 / 9.0, -2.0 / 9.0, -2.0 / 9.0, -2.0 / 9.0},
+                                {-2.0 / 9.0, 2.0 / 9.0, -2.0 / 9.0, 2.0 / 9.0, -2.0 / 9.0},
+                                {1.0 / 90.0, 1.0 / 45.0, 2.0 / 45.0, 4.0 / 45.0, 8.0 / 45.0},
+                                {1.0 / 90.0, -1.0 / 45.0, 2.0 / 45.0, -4.0 / 45.0, 8.0 / 45.0},
+                                {32.0 / 45.0, 16.0 / 45.0, 8.0 / 45.0, 4.0 / 45.0, 2.0 / 45.0},
+                                {32.0 / 45.0, -16.0 / 45.0, 8.0 / 45.0, -4.0 / 45.0, 2.0 / 45.0},
+                                {0.0, 0.0, 0.0, 0.0, 1.0}};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v += G[pos][k] * (double)g[k];
+    }
+    wp[e] = (float)v;
+}
+
+static inline int w1_cop(int cout) { return (cout + W1_CO - 1) / W1_CO * W1_CO; }
+
+extern "C" size_t rpe_conv_wino1d_packed_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cin % W1_K) return 0;
+    return (size_t)(cin / W1_K) * W1_K * W1_ROW * w1_cop(cout);
+}
+
+extern "C" int rpe_conv_wino1d_pack(const float* weight, int cout, int cin, float* packed, void* stream) {
+    if (!weight || !packed || cout <= 0 || cin <= 0) return RPE_E_BADARG;
+    if (cin % W1_K) return RPE_E_UNSUPPORTED;
+    const long long total = (long long)rpe_conv_wino1d_packed_floats(cout, cin);
+    hipLaunchKernelGGL(k_wino1d_pack, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed, cout, cin, w1_cop(cout), total);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_conv_wino1d(const rpe_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->packed || !d->out || d->b <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return RPE_E_BADARG;
+    const bool vert = d->kh == 5 && d->kw == 1, horiz = d->kh == 1 && d->kw == 5;
+    if (!(vert || horiz) || (d->stride != 0 && d->stride != 1) || (d->cin % W1_K) || (d->w & 3)) return RPE_E_UNSUPPORTED;
+    if (d->mode < RPE_CONV_LINEAR || d->mode > RPE_CONV_GATE_H) return RPE_E_BADARG;
+    if (d->mode == RPE_CONV_GATE_ZR && (!d->out2 || !d->hidden || d->gate_channels <= 0 || d->cout != 2 * d->gate_channels)) return RPE_E_BADARG;
+    if (d->mode == RPE_CONV_GATE_H && (!d->hidden || !d->zgate)) return RPE_E_BADARG;
+    if (d->scale || d->residual || d->stats || d->pre_norm) return RPE_E_UNSUPPORTED;
+    // 16-byte accesses: the input quads of the LDS-DMA and (1x5) the four pixels of a tile in every tensor of the epilogue
+    auto a16 = [](const void* p, long long bs) { return !p || ((((uintptr_t)p) & 15) == 0 && (bs & 3) == 0); };
+    if (!a16(d->x, d->x_batch_stride) || !a16(d->packed, 0)) return RPE_E_UNSUPPORTED;
+    if (horiz && (!a16(d->out, d->out_batch_stride) || !a16(d->out2, d->out2_batch_stride) || !a16(d->add, d->add_batch_stride) ||
+                  !a16(d->hidden, d->hidden_batch_stride) || !a16(d->zgate, d->zgate_batch_stride))) return RPE_E_UNSUPPORTED;
+    W1P P;
+    P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed; P.cin = d->cin; P.cout = d->cout; P.coP = w1_cop(d->cout);
+    P.H = d->h; P.W = d->w; P.bias = d->bias; P.add = d->add; P.abs_ = d->add_batch_stride;
+    P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
+    P.hid = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels; P.mode = d->mode;
+    const dim3 grid(ceil_div(d->w, 16) * ceil_div(d->h, 16), P.coP / W1_CO, d->b);
+    if (vert) hipLaunchKernelGGL((k_conv_wino1d<true>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((k_conv_wino1d<false>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    return rpe_check_launch();
+}

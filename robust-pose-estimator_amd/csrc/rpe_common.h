@@ -54,4 +54,5 @@ struct StatAcc {
     }
 };
 
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }     // the GRU gates of conv.hip / conv_wino1d.hip
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -381,7 +381,7 @@ class PackedConv:
 
 
 def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
-               residual=None, stats=None, stride=1, pre_norm=None, prepare=False):
+               residual=None, stats=None, stride=1, pre_norm=None, prepare=False, entry='rpe_conv_fused'):
     """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.
     ``bias`` defaults to the one packed with the weights; ``stats`` (from conv_stats_buffer) collects the per-tile moments
     instnorm_apply needs.  ``prepare=True`` returns a zero-argument launcher instead of launching: the GRU loop runs the same
@@ -425,17 +425,42 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     d.stride = stride
     import ctypes
     if prepare:                                    # the checked descriptor, to be launched again and again on the same buffers
-        fn, ref, keep = lib().rpe_conv_fused, ctypes.byref(d), (d, x, pc, out, out2, add, hidden, zgate, scale, bias, residual, stats, pre_norm)
+        fn, ref, keep = getattr(lib(), entry), ctypes.byref(d), (d, x, pc, out, out2, add, hidden, zgate, scale, bias, residual, stats, pre_norm)
 
         def launch():
             st = fn(ref, stream_ptr())
             if st != 0:
-                check(st, 'rpe_conv_fused')
+                check(st, entry)
             return keep[3]
         launch.keep = keep
         return launch
-    check(lib().rpe_conv_fused(ctypes.byref(d), stream_ptr()), 'rpe_conv_fused')
+    check(getattr(lib(), entry)(ctypes.byref(d), stream_ptr()), entry)
     return out
+
+
+class PackedWino1d:
+    """Weights of a 1x5 / 5x1 stride-1 convolution transformed for rpe_conv_wino1d (U = G g along the taps, once per weight version)."""
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        n = lib().rpe_conv_wino1d_packed_floats(self.cout, self.cin) if (self.kh, self.kw) in ((1, 5), (5, 1)) else 0
+        if n == 0:
+            raise _lib.RpeError('PackedWino1d: needs a (cout, cin % 4 == 0, 1, 5) or (.., 5, 1) weight')
+        self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(lib().rpe_conv_wino1d_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv_wino1d_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(weight, ww):
+        return tuple(weight.shape[2:]) in ((1, 5), (5, 1)) and weight.shape[1] % 4 == 0 and ww % 4 == 0
+
+
+def conv_wino1d(x, pw, mode, out, **kw):
+    """rpe_conv_wino1d: conv_fused's operation (all four epilogue modes incl. the GRU gates) for 1x5 / 5x1 stride-1 convolutions
+    by Winograd F(4,5) along the filter axis: 2.5x fewer matrix FLOPs.  Same keyword arguments as conv_fused (no scale /
+    residual / stats / pre_norm)."""
+    return conv_fused(x, pw, mode, out, entry='rpe_conv_wino1d', **kw)
 
 
 class PackedWino:

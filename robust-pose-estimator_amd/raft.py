@@ -369,7 +369,9 @@ class BasicUpdateBlock(nn.Module):
                          if ops.PackedWino.supported(m.weight, 2, 2)} if WINOGRAD else {}
             P['convf1'] = ops.PackedStem(e.convf1.weight)
             for n in ('zr1', 'q1', 'zr2', 'q2'):
-                P[n] = ops.PackedConv(W[n][0])                # bias is part of the context term (context_terms)
+                # the loop-varying 256 channels: Winograd F(4,5) along the filter axis (rpe_conv_wino1d: 2.5x fewer matrix FLOPs), else the
+                # direct implicit GEMM; bias is part of the context term (context_terms)
+                P[n] = ops.PackedWino1d(W[n][0]) if WINOGRAD else ops.PackedConv(W[n][0])
                 P['ctx_' + n] = ops.PackedConv(W[n][1], W[n][2])
             scratch = {}
 
@@ -399,10 +401,11 @@ class BasicUpdateBlock(nn.Module):
             calls = P.get('_gru_calls')
             if calls is None or calls[0] != key:
                 seq = []
+                gconv = ops.conv_wino1d if isinstance(P['zr1'], ops.PackedWino1d) else ops.conv_fused
                 for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
-                    seq.append(ops.conv_fused(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
-                                              prepare=True))
-                    seq.append(ops.conv_fused(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
+                    seq.append(gconv(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
+                                     prepare=True))
+                    seq.append(gconv(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
                 if 'fh1' in P['wino'] and hx.shape[-1] % 2 == 0 and hx.shape[-2] % 2 == 0:
                     seq.append(ops.conv_wino(hx[:, :c], P['wino']['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
                 else:

@@ -56,10 +56,13 @@ def test_conv_bias_act_matches_f64(rpe, cin, cout, kh, kw, h, w, b, relu):
     assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all()            # neighbours untouched
 
 
-@pytest.mark.parametrize('kh,kw,h,w', [(1, 5, 64, 80), (5, 1, 64, 80), (1, 5, 44, 48), (5, 1, 44, 48)])
-def test_gru_half_step_matches_f64(rpe, kh, kw, h, w):
-    """z, r*h and the blended hidden state of one SepConvGRU half, fused into the two convolutions, against f64."""
+@pytest.mark.parametrize('impl', ['direct', 'winograd'])
+@pytest.mark.parametrize('kh,kw,h,w', [(1, 5, 64, 80), (5, 1, 64, 80), (1, 5, 44, 48), (5, 1, 44, 48), (1, 5, 30, 40), (5, 1, 30, 40)])
+def test_gru_half_step_matches_f64(rpe, kh, kw, h, w, impl):
+    """z, r*h and the blended hidden state of one SepConvGRU half, fused into the two convolutions, against f64: the direct
+    implicit GEMM (rpe_conv_fused) and Winograd F(4,5) along the filter axis (rpe_conv_wino1d), same tolerances."""
     from rpe_amd import ops
+    Packed, conv = (ops.PackedConv, ops.conv_fused) if impl == 'direct' else (ops.PackedWino1d, ops.conv_wino1d)
     c, b = 128, 2
     rng = np.random.default_rng(kh * 10 + kw + h)
     hx = _rand(rng, b, 2 * c, h, w, s=0.5)
@@ -74,15 +77,52 @@ def test_gru_half_step_matches_f64(rpe, kh, kw, h, w):
 
     g_hx, g_rhx = hx.cuda(), hx.cuda().clone()
     g_z = torch.empty(b, c, h, w, device='cuda')
-    pzr, pq = ops.PackedConv(wzr.cuda(), bzr.cuda()), ops.PackedConv(wq.cuda(), bq.cuda())
-    ops.conv_fused(g_hx, pzr, ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
+    pzr, pq = Packed(wzr.cuda(), bzr.cuda()), Packed(wq.cuda(), bq.cuda())
+    conv(g_hx, pzr, ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
     tz = _tol(hx, wzr) * 0.25 + 2e-7
     assert (g_z.cpu().double() - z).abs().max() < tz
     assert (g_rhx[:, :c].cpu().double() - r * hid).abs().max() < tz * float(hx.abs().max())
     assert torch.equal(g_rhx[:, c:], g_hx[:, c:])
-    ops.conv_fused(g_rhx, pq, ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)   # in place on h
+    conv(g_rhx, pq, ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)   # in place on h
     assert (g_hx[:, :c].cpu().double() - hnew).abs().max() < _tol(hx, wq) + tz * 2
     assert torch.equal(g_hx[:, c:].cpu(), hx[:, c:])
+
+
+@pytest.mark.parametrize('cin,cout,kh,kw,h,w,b', [
+    (256, 256, 1, 5, 64, 80, 2),      # convz1|convr1 at bench geometry
+    (256, 128, 5, 1, 64, 80, 2),      # convq2
+    (64, 96, 1, 5, 20, 24, 1),        # ragged output channels (96 = 64 + 32), map smaller than two tiles
+    (64, 70, 5, 1, 7, 36, 2),         # 7 rows: the last 4-pixel tile is cut, 36 columns: the last 16-column block is cut
+    (8, 16, 1, 5, 33, 4, 1),          # one quad wide
+    (8, 16, 5, 1, 3, 4, 1),           # shorter than the filter
+])
+@pytest.mark.parametrize('relu', [False, True])
+def test_winograd_1d_matches_f64(rpe, cin, cout, kh, kw, h, w, b, relu):
+    """rpe_conv_wino1d (F(4,5) along the filter axis) with the plain epilogues, on channel slices of wider buffers."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + kh * 7 + kw + h)
+    x, wt, bias, add = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, kh, kw, s=0.05), _rand(rng, cout, s=0.1), _rand(rng, b, cout, h, w, s=0.3)
+    ref = _ref_conv(x, wt, bias, add)
+    if relu:
+        ref = ref.clamp_min(0)
+    xbuf = torch.full((b, cin + 8, h, w), float('nan'), device='cuda'); xbuf[:, 4:4 + cin] = x.cuda()
+    obuf = torch.full((b, cout + 8, h, w), -7.0, device='cuda'); o2buf = torch.full((b, cout + 4, h, w), -7.0, device='cuda')
+    pw = ops.PackedWino1d(wt.cuda(), bias.cuda())
+    ops.conv_wino1d(xbuf[:, 4:4 + cin], pw, ops.CONV_RELU if relu else ops.CONV_LINEAR, obuf[:, 4:4 + cout], out2=o2buf[:, 4:], add=add.cuda())
+    got = obuf[:, 4:4 + cout].cpu().double()
+    assert (got - ref).abs().max() < _tol(x, wt) * 2                       # (the transforms' constants reach 5.25)
+    assert torch.equal(obuf[:, 4:4 + cout], o2buf[:, 4:])
+    assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all()            # neighbours untouched
+
+
+def test_winograd_1d_rejects_what_it_cannot_do(rpe):
+    from rpe_amd import ops
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWino1d(torch.zeros(8, 16, 3, 3, device='cuda'))
+    pw = ops.PackedWino1d(torch.zeros(8, 16, 1, 5, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):                      # width not a multiple of 4
+        ops.conv_wino1d(torch.zeros(1, 16, 8, 10, device='cuda'), pw, ops.CONV_LINEAR, torch.empty(1, 8, 8, 10, device='cuda'))
+    assert not ops.PackedWino1d.supported(torch.zeros(8, 16, 1, 5), 10) and ops.PackedWino1d.supported(torch.zeros(8, 16, 5, 1), 12)
 
 
 def test_fused_gates_agree_with_the_separate_kernels(rpe):

@@ -37,6 +37,29 @@ with torch.no_grad():
             rpe_amd._lib.lib().rpe_debug_wino_timing(buf)
             n = max(buf[6], 1)
             print('        cycles per step, one wave: g0 %.0f  g1 %.0f  g2 %.0f  wait %.0f  barrier %.0f  g3 %.0f' % tuple(buf[i] / n for i in range(6)))
+    print('--- GRU convolutions (256 varying input channels; direct implicit GEMM vs Winograd F(4,5) along the axis, gate epilogues)')
+    c = 128
+    for name, kh, kw, co, mode in (('zr 1x5', 1, 5, 256, ops.CONV_GATE_ZR), ('q 1x5', 1, 5, 128, ops.CONV_GATE_H), ('zr 5x1', 5, 1, 256, ops.CONV_GATE_ZR),
+                                   ('q 5x1', 5, 1, 128, ops.CONV_GATE_H)):
+        if only and only != 'gru': continue
+        hx = torch.randn(N, 256, H, W, device=dev) * 0.5; rhx = hx.clone(); z = torch.rand(N, c, H, W, device=dev)
+        w = torch.randn(co, 256, kh, kw, device=dev) * 0.03; add = torch.randn(N, co, H, W, device=dev) * 0.3
+        pc, pw = ops.PackedConv(w), ops.PackedWino1d(w)
+        flop = 2.0 * N * H * W * 256 * co * 5
+        res = []
+        for conv, pk in ((ops.conv_fused, pc), (ops.conv_wino1d, pw)):
+            if mode == ops.CONV_GATE_ZR:
+                zo, ro = torch.empty(N, c, H, W, device=dev), torch.empty(N, c, H, W, device=dev)
+                fn = conv(hx, pk, mode, zo, out2=ro, add=add, hidden=hx[:, :c], gate_channels=c, prepare=True)
+                out = (zo, ro)
+            else:
+                ho = torch.empty(N, c, H, W, device=dev)
+                fn = conv(rhx, pk, mode, ho, add=add, hidden=hx[:, :c], zgate=z, prepare=True)
+                out = (ho,)
+            res.append((t(fn), out))
+        (td, od), (tw, ow) = res
+        print('%-7s 256->%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective)   maxdiff %.1e' % (
+            name, co, td, flop / td / 1e6, tw, flop / 2.5 / tw / 1e6, flop / tw / 1e6, max((a - b).abs().max().item() for a, b in zip(od, ow))))
     if only: sys.exit(0)
     print('--- encoder layers (fnet: bias + instance-norm moments; 48 images)')
     for name, c, hh, ww in (('layer1', 64, 256, 320), ('layer2', 96, 128, 160), ('layer3', 128, 64, 80)):
