@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
                             const float sg = sigmoid_f(v);
                             if (ok[r]) { if (rrows) out2b0[e[r] - (size_t)cg * hw] = sg * xv[r]; else outb0[e[r]] = sg; }
                         } else if (mode == RPE_CONV_GATE_H) {
-                            if (ok[r]) outb0[e[r]] = (1.0f - xv[r]) * yv[r] + xv[r] * tanhf(v);
+                            if (ok[r]) outb0[e[r]] = (1.0f - xv[r]) * yv[r] + xv[r] * tanh_f(v);
                         } else {
                             if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;    // NaN stays NaN, like torch.relu
                             if (ok[r]) { outb0[e[r]] = v; if (out2b0) out2b0[e[r]] = v; }

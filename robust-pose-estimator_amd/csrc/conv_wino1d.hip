@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                     // h <- (1 - z) h + z tanh(.)
                     float zv[4], hv[4]; ld4(zb, e0, zv); ld4(hb, e0, hv);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - zv[i]) * hv[i] + zv[i] * tanhf(v[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - zv[i]) * hv[i] + zv[i] * tanh_f(v[i]);
                     st4(outb, e0, v);
                 } else {
                     if (mode == RPE_CONV_RELU) {                                  // NaN stays NaN, like torch.relu

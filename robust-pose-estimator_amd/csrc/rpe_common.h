@@ -54,5 +54,9 @@ struct StatAcc {
     }
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }     // the GRU gates of conv.hip / conv_wino1d.hip
+// The GRU gates in the convolution epilogues (conv.hip, conv_wino1d.hip) on the hardware exp2 / reciprocal (each within 1 ulp):
+// absolute error < 3e-7, the size of one f32 rounding of the values they act on; libm's expf / tanhf cost ~30 vector
+// instructions per element, which a matrix-bound kernel cannot hide (vector and f32 matrix instructions share the issue).
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }     // -> +-1 as e^{2x} -> inf | 0
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

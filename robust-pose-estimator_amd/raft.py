@@ -346,7 +346,7 @@ class BasicUpdateBlock(nn.Module):
         P = self.packed_convs(inp.shape[-1]) if out is not None else None
         if P is not None:
             for k in W:
-                ops.conv_fused(inp, P['ctx_' + k], ops.CONV_LINEAR, out[k])
+                (ops.conv_wino1d if isinstance(P['ctx_' + k], ops.PackedWino1d) else ops.conv_fused)(inp, P['ctx_' + k], ops.CONV_LINEAR, out[k])
             return out
         pads = {'zr1': (0, 2), 'q1': (0, 2), 'zr2': (2, 0), 'q2': (2, 0)}
         return {k: F.conv2d(inp, W[k][1], W[k][2], padding=pads[k]) for k in W}
@@ -372,7 +372,7 @@ class BasicUpdateBlock(nn.Module):
                 # the loop-varying 256 channels: Winograd F(4,5) along the filter axis (rpe_conv_wino1d: 2.5x fewer matrix FLOPs), else the
                 # direct implicit GEMM; bias is part of the context term (context_terms)
                 P[n] = ops.PackedWino1d(W[n][0]) if WINOGRAD else ops.PackedConv(W[n][0])
-                P['ctx_' + n] = ops.PackedConv(W[n][1], W[n][2])
+                P['ctx_' + n] = (ops.PackedWino1d if WINOGRAD else ops.PackedConv)(W[n][1], W[n][2])
             scratch = {}
 
             def buf(name, like, c):                            # per-shape scratch for intermediate activations
