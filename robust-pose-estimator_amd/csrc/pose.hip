@@ -10,10 +10,11 @@
 //                   f32 planes + two u8 planes, does all arithmetic in f64 (as the reference), keeps 8 (+21
 //                   with the Hessian) f64 accumulators, then 64-lane butterfly -> LDS -> one partial row
 //                   per block.  No atomics: the result is bit-reproducible run to run.
-//   k_pose_update : grid (n), one wave.  Fixed-order sum of the block partials, gradient clipping, one
+//   k_pose_update : grid (n), 256 threads.  Fixed-order sum of the block partials, gradient clipping, one
 //                   L-BFGS (or GN) iteration in R^6, left retraction T <- exp(t d) T.  State lives in the
 //                   caller's workspace, so the whole N-iteration solve is 2N launches and zero host syncs.
 #include "rpe_common.h"
+#include <cstddef>
 #include "se3_device.h"
 
 #define NPART 32          // doubles per partial row: loss2d, loss3d, g[6], H[21], pad
@@ -266,38 +267,69 @@ __device__ void apply_step(RowState& S, RowUniform& U, const double* dir, double
     write_rt(U, S.T);
 }
 
-// Sums the block partials of one row in a fixed order: lane l owns value (l & 31), lanes >= 32 take the odd
-// blocks; the two halves are combined with one shuffle.
-__device__ __forceinline__ double sum_partials(const double* partials, int row, int nblk, int lane) {
-    const int j = lane & 31, half = lane >> 5;
+// Sums the block partials of one row in a fixed order into vals[0..NPART) (LDS): 256 threads = 8 parts x 32 values; part p takes
+// blocks p, p+8, ... with four loads in flight (one lane walking the 160 rows of a 640x512 frame serially cost 24 us of
+// dependent L2 round trips per launch), then the parts are added in the order 0..7.  Ends with a barrier.
+#define UPD_THREADS 256
+__device__ __forceinline__ void sum_partials(const double* partials, int row, int nblk, int tid, double* vals, double (*red)[NPART]) {
+    const int j = tid & 31, part = tid >> 5;
     const double* p = partials + (size_t)row * nblk * NPART + j;
-    double s = 0.0;
-    for (int b = half; b < nblk; b += 2) s += p[(size_t)b * NPART];
-    s += __shfl_xor(s, 32, RPE_WAVE);
-    return s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = part;
+    for (; b + 24 < nblk; b += 32) {
+        s0 += p[(size_t)b * NPART]; s1 += p[(size_t)(b + 8) * NPART]; s2 += p[(size_t)(b + 16) * NPART]; s3 += p[(size_t)(b + 24) * NPART];
+    }
+    for (; b < nblk; b += 8) s0 += p[(size_t)b * NPART];
+    red[part][j] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (tid < NPART) {
+        double t = 0.0;
+        for (int q = 0; q < UPD_THREADS / 32; ++q) t += red[q][tid];
+        vals[tid] = t;
+    }
+    __syncthreads();
 }
 
 struct SolveOpts { double tol_grad, tol_change; int history; };
 
-__global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform* uni, const double* partials, int nblk,
-                                                    const float* lw, int h, int w, int mode, int max_iter, SolveOpts opt) {
-    const int row = blockIdx.x, lane = threadIdx.x;
-    RowState& S = states[row];
-    if (S.stop != 0) return;
-    __shared__ double vals[NPART];
-    // The two-loop recursion below runs on one lane; read serially from global memory its (y, s, rho) history costs a
-    // dependent L2 round trip per entry (27 us per iteration at 20 entries).  The wave stages it in LDS first.
-    __shared__ double h_dirs[HIST][6], h_stps[HIST][6], h_ro[HIST], h_al[HIST];
-    double sv = sum_partials(partials, row, nblk, lane);
-    if (lane < NPART) vals[lane] = sv;
-    if (mode != RPE_SOLVER_GN) {
-        const int nold = S.num_old;
-        for (int e = lane; e < nold * 6; e += RPE_WAVE) { (&h_dirs[0][0])[e] = (&S.old_dirs[0][0])[e]; (&h_stps[0][0])[e] = (&S.old_stps[0][0])[e]; }
-        for (int e = lane; e < nold; e += RPE_WAVE) h_ro[e] = S.ro[e];
-    }
-    __syncthreads();
-    if (lane != 0) return;
+// One lane runs the iteration logic; every access it makes to the row's state used to be a dependent L2 round trip (28 us per
+// launch at batch 1).  The wave stages the state's head (poses, gradients, counters: 31 doubles), the (y, s, rho) history
+// and the row's rotation in LDS, lane 0 works there, and the wave writes back what changed.
+__device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, int* wb, const double* vals, const float* lw, int row,
+                                int h, int w, int mode, int max_iter, SolveOpts opt);
 
+__global__ __launch_bounds__(UPD_THREADS) void k_pose_update(RowState* states, RowUniform* uni, const double* partials, int nblk,
+                                                             const float* lw, int h, int w, int mode, int max_iter, SolveOpts opt) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    RowState& G = states[row];
+    if (G.stop != 0) return;
+    constexpr int HEAD = 31;                                  // doubles in front of old_dirs (T, g, prev_g, d, t, loss, prev_loss, H_diag, 4 ints)
+    static_assert(offsetof(RowState, old_dirs) == HEAD * sizeof(double), "RowState head");
+    __shared__ double vals[NPART], red[UPD_THREADS / 32][NPART];
+    __shared__ RowState S;
+    __shared__ RowUniform U;
+    __shared__ double h_al[HIST];
+    __shared__ int wb[2];                                     // history entries [wb[0], wb[1]) changed
+    sum_partials(partials, row, nblk, lane, vals, red);
+    if (lane < HEAD) ((double*)&S)[lane] = ((const double*)&G)[lane];
+    if (lane < (int)(sizeof(RowUniform) / sizeof(double))) ((double*)&U)[lane] = ((const double*)&uni[row])[lane];
+    if (mode != RPE_SOLVER_GN) {
+        const int nold = G.num_old;
+        for (int e = lane; e < nold * 6; e += UPD_THREADS) { (&S.old_dirs[0][0])[e] = (&G.old_dirs[0][0])[e]; (&S.old_stps[0][0])[e] = (&G.old_stps[0][0])[e]; }
+        for (int e = lane; e < nold; e += UPD_THREADS) S.ro[e] = G.ro[e];
+    }
+    if (lane == 0) { wb[0] = 0; wb[1] = 0; }
+    __syncthreads();
+    if (lane == 0) pose_update_row(S, U, h_al, wb, vals, lw, row, h, w, mode, max_iter, opt);
+    __syncthreads();
+    if (lane < HEAD) ((double*)&G)[lane] = ((const double*)&S)[lane];
+    if (lane < 12) ((double*)&uni[row])[lane] = ((const double*)&U)[lane];          // R, t (write_rt)
+    for (int e = wb[0] * 6 + lane; e < wb[1] * 6; e += UPD_THREADS) { (&G.old_dirs[0][0])[e] = (&S.old_dirs[0][0])[e]; (&G.old_stps[0][0])[e] = (&S.old_stps[0][0])[e]; }
+    for (int e = wb[0] + lane; e < wb[1]; e += UPD_THREADS) G.ro[e] = S.ro[e];
+}
+
+__device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, int* wb, const double* vals, const float* lw, int row,
+                                int h, int w, int mode, int max_iter, SolveOpts opt) {
     const double hwd = (double)h * (double)w;
     const double loss2d = vals[0] / hwd / hwd, loss3d = vals[1] / hwd;
     const double loss = (double)lw[row * 2 + 1] * loss2d + (double)lw[row * 2 + 0] * loss3d;
@@ -327,7 +359,7 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
         for (int i = 5; i >= 0; --i) { double s = yv[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * dl[k]; dl[i] = s / L[i][i]; }
         for (int i = 0; i < 6; ++i) S.d[i] = dl[i];
         S.t = 1.0;
-        apply_step(S, uni[row], dl, 1.0);
+        apply_step(S, U, dl, 1.0);
         if (absmax6(dl) <= tol_change) S.stop = RPE_STOP_STEP;
         else if (S.n_iter == max_iter) S.stop = RPE_STOP_MAX_ITER;
         return;
@@ -366,34 +398,35 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
         for (int i = 0; i < 6; ++i) { yk[i] = g[i] - S.prev_g[i]; sk[i] = S.d[i] * S.t; }
         double ys = dot6(yk, sk);
         if (ys > 1e-10) {
-            if (S.num_old == hist) {                  // history full: drop the oldest pair (in both copies)
+            bool shifted = false;
+            if (S.num_old == hist) {                  // history full: drop the oldest pair
                 for (int k = 1; k < hist; ++k) {
-                    for (int i = 0; i < 6; ++i) {
-                        S.old_dirs[k - 1][i] = h_dirs[k - 1][i] = h_dirs[k][i];
-                        S.old_stps[k - 1][i] = h_stps[k - 1][i] = h_stps[k][i];
-                    }
-                    S.ro[k - 1] = h_ro[k - 1] = h_ro[k];
+                    for (int i = 0; i < 6; ++i) { S.old_dirs[k - 1][i] = S.old_dirs[k][i]; S.old_stps[k - 1][i] = S.old_stps[k][i]; }
+                    S.ro[k - 1] = S.ro[k];
                 }
                 S.num_old = hist - 1;
+                shifted = true;                       // (every entry moved)
             }
             const int no = S.num_old;
-            for (int i = 0; i < 6; ++i) { S.old_dirs[no][i] = h_dirs[no][i] = yk[i]; S.old_stps[no][i] = h_stps[no][i] = sk[i]; }
-            S.ro[no] = h_ro[no] = 1.0 / ys;
+            for (int i = 0; i < 6; ++i) { S.old_dirs[no][i] = yk[i]; S.old_stps[no][i] = sk[i]; }
+            S.ro[no] = 1.0 / ys;
             S.num_old = no + 1;
+            wb[0] = shifted ? 0 : no;
+            wb[1] = no + 1;
             S.H_diag = ys / dot6(yk, yk);
         }
         const int nold = S.num_old;
         double qv[6];
         for (int i = 0; i < 6; ++i) qv[i] = -g[i];
         for (int k = nold - 1; k >= 0; --k) {
-            const double a = dot6(h_stps[k], qv) * h_ro[k];
+            const double a = dot6(S.old_stps[k], qv) * S.ro[k];
             h_al[k] = a;
-            for (int i = 0; i < 6; ++i) qv[i] += h_dirs[k][i] * (-a);
+            for (int i = 0; i < 6; ++i) qv[i] += S.old_dirs[k][i] * (-a);
         }
         for (int i = 0; i < 6; ++i) d[i] = qv[i] * S.H_diag;
         for (int k = 0; k < nold; ++k) {
-            double be = dot6(h_dirs[k], d) * h_ro[k];
-            for (int i = 0; i < 6; ++i) d[i] += h_stps[k][i] * (h_al[k] - be);
+            double be = dot6(S.old_dirs[k], d) * S.ro[k];
+            for (int i = 0; i < 6; ++i) d[i] += S.old_stps[k][i] * (h_al[k] - be);
         }
     }
     for (int i = 0; i < 6; ++i) { S.prev_g[i] = g[i]; S.d[i] = d[i]; }
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(64) void k_pose_update(RowState* states, RowUniform
     S.t = tstep;
     double gtd = dot6(g, d);
     if (gtd > -tol_change) { S.stop = RPE_STOP_GTD; return; }
-    apply_step(S, uni[row], d, tstep);
+    apply_step(S, U, d, tstep);
     if (S.n_iter == max_iter) S.stop = RPE_STOP_MAX_ITER;
 }
 
@@ -444,12 +477,10 @@ __global__ void k_pose_finalize(RowState* states, int n, double* T_out, float* v
 }
 
 // Packs the reduced sums of one row into the rpe_pose_reduce output layout.
-__global__ __launch_bounds__(64) void k_pose_pack(const double* partials, int nblk, const float* lw, int h, int w, double* out) {
+__global__ __launch_bounds__(UPD_THREADS) void k_pose_pack(const double* partials, int nblk, const float* lw, int h, int w, double* out) {
     const int row = blockIdx.x, lane = threadIdx.x;
-    double sv = sum_partials(partials, row, nblk, lane);
-    __shared__ double vals[NPART];
-    if (lane < NPART) vals[lane] = sv;
-    __syncthreads();
+    __shared__ double vals[NPART], red[UPD_THREADS / 32][NPART];
+    sum_partials(partials, row, nblk, lane, vals, red);
     if (lane >= 32) return;
     const double hwd = (double)h * (double)w;
     double* o = out + (size_t)row * 32;
@@ -502,7 +533,7 @@ extern "C" int rpe_pose_reduce(const float* flow, const float* pcl1, const float
     int nblk = pose_nblk(n, h, w);
     hipLaunchKernelGGL(k_pose_prep, dim3(ceil_div(n, 64)), dim3(64), 0, s, uni, T, K, loss_weight, n, h, w);
     launch_reduce(A, uni, nullptr, partials, nblk, need_hessian != 0, s);
-    hipLaunchKernelGGL(k_pose_pack, dim3(n), dim3(64), 0, s, (const double*)partials, nblk, loss_weight, h, w, out);
+    hipLaunchKernelGGL(k_pose_pack, dim3(n), dim3(UPD_THREADS), 0, s, (const double*)partials, nblk, loss_weight, h, w, out);
     return rpe_check_launch();
 }
 
@@ -542,7 +573,7 @@ extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const f
     int evals = mode == RPE_SOLVER_LBFGS && iters == 0 ? 1 : iters;
     for (int it = 0; it < evals; ++it) {
         launch_reduce(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s);
-        hipLaunchKernelGGL(k_pose_update, dim3(n), dim3(64), 0, s, st, uni, (const double*)partials, nblk, loss_weight, h, w, mode, iters, opt);
+        hipLaunchKernelGGL(k_pose_update, dim3(n), dim3(UPD_THREADS), 0, s, st, uni, (const double*)partials, nblk, loss_weight, h, w, mode, iters, opt);
     }
     hipLaunchKernelGGL(k_pose_finalize, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, n, T_out, vec7, log6, info);
     return rpe_check_launch();
