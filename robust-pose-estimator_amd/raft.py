@@ -22,11 +22,11 @@ Exact re-associations used (results identical up to float rounding of the conv l
 The RAFT architecture itself is restated from princeton-vl/RAFT (the reference's submodule is empty);
 see oracle/raft.py for the CPU restatement these kernels are tested against.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-
-import os
 
 from . import ops
 
@@ -136,7 +136,11 @@ def _fusable(conv, x):
     # the encoder instantiations have no small-tile variant
     wide = conv.out_channels % 128 != 0 and conv.out_channels % 128 <= 96
     tiles = -(-(hh // stride) * (ww // stride) // (128 if (s2 or not wide) else 256)) * -(-conv.out_channels // (128 if (s2 or not wide) else 64))
-    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous() and tiles * x.shape[0] >= 256
+    big = tiles * x.shape[0] >= 256
+    if s1 and WINOGRAD and hh % 2 == 0 and ww % 2 == 0 and conv.in_channels <= 128:
+        # the Winograd kernel's workgroups are 16 x 8 pixels x 64 channels: it still wins over the library at a quarter of the chip
+        big = big or -(-hh // 8) * -(-ww // 16) * -(-conv.out_channels // 64) * x.shape[0] >= int(os.environ.get('RPE_WINO_MIN_WG', '64'))
+    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous() and big
 
 
 def conv_norm_act(conv, norm, x, relu, residual=None):
