@@ -348,6 +348,13 @@ int rpe_resize_crop(const void *in, int in_is_u8_hwc, int c, int h, int w, int r
 /* the same with nearest sampling for the (h,w) u8 mask (InterpolationMode.NEAREST) */
 int rpe_resize_crop_mask(const uint8_t *in, int h, int w, int resized_h, int resized_w, int top, int left, int out_h,
                          int out_w, uint8_t *out, void *stream);
+/* Rectification of one image with precomputed maps: cv2.remap(src, mapx, mapy, INTER_NEAREST) with the default constant-0
+ * border (dataset/preprocess/stereo_rectify.py:44-51, called per frame by StereoRectifier.__call__,
+ * dataset/rectification.py:52-65): dst(ch,y,x) = src(ch, cvRound(mapy[y,x]), cvRound(mapx[y,x])), cvRound = round half to
+ * even, saturated to int16; 0 outside the image.  src / dst planar (c,h,w) / (c,out_h,out_w), uint8 or float32
+ * (src_is_u8); the maps are the CV_32FC1 pair initUndistortRectifyMap produces (preprocess.StereoRectifier builds them). */
+int rpe_remap_nearest(const void *src, int src_is_u8, int c, int h, int w, const float *mapx, const float *mapy, int out_h,
+                      int out_w, void *dst, void *stream);
 
 #ifdef __cplusplus
 }

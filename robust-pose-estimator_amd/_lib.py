@@ -86,6 +86,7 @@ SIGNATURES = {
     'rpe_mask_specularities': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop_mask': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_remap_nearest': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

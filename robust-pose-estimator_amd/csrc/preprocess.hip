@@ -133,3 +133,34 @@ extern "C" int rpe_resize_crop_mask(const uint8_t* in, int h, int w, int resized
                        resized_w, top, left, out_h, out_w, out);
     return rpe_check_launch();
 }
+
+// ---- rectification (dataset/preprocess/stereo_rectify.py:44-51: cv2.remap(img, map1, map2, INTER_NEAREST), default border =
+// constant 0).  cv2 rounds the float maps with cvRound (round half to even) and saturates to int16; a source pixel outside the
+// image gives 0.  Planar (c,h,w) input of T = u8 / f32, maps (out_h,out_w) f32; HBM-bound gather, one thread per output pixel,
+// all channels (the index is shared).
+template <typename T>
+__global__ __launch_bounds__(256) void k_remap_nearest(const T* __restrict__ src, int c, int h, int w, const float* __restrict__ mapx,
+                                                       const float* __restrict__ mapy, int oh, int ow, T* __restrict__ dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    const size_t o = (size_t)y * ow + x;
+    const float fx = __builtin_nontemporal_load(mapx + o), fy = __builtin_nontemporal_load(mapy + o);
+    // cvRound + saturate_cast<short>: NaN / out-of-range land outside every image
+    const float cx = fminf(fmaxf(fx, -32768.0f), 32767.0f), cy = fminf(fmaxf(fy, -32768.0f), 32767.0f);
+    const int sx = (fx == fx) ? __float2int_rn(cx) : -32768, sy = (fy == fy) ? __float2int_rn(cy) : -32768;
+    const bool in = sx >= 0 && sx < w && sy >= 0 && sy < h;
+    const size_t si = in ? (size_t)sy * w + sx : 0;
+    for (int ch = 0; ch < c; ++ch) {
+        const T v = in ? src[(size_t)ch * h * w + si] : (T)0;
+        __builtin_nontemporal_store(v, dst + (size_t)ch * oh * ow + o);
+    }
+}
+
+extern "C" int rpe_remap_nearest(const void* src, int src_is_u8, int c, int h, int w, const float* mapx, const float* mapy, int out_h, int out_w,
+                                 void* dst, void* stream) {
+    if (!src || !dst || !mapx || !mapy || c <= 0 || h <= 0 || w <= 0 || out_h <= 0 || out_w <= 0) return RPE_E_BADARG;
+    dim3 grid(ceil_div(out_w, 256), out_h), block(256);
+    if (src_is_u8) hipLaunchKernelGGL(k_remap_nearest<uint8_t>, grid, block, 0, (hipStream_t)stream, (const uint8_t*)src, c, h, w, mapx, mapy, out_h, out_w, (uint8_t*)dst);
+    else hipLaunchKernelGGL(k_remap_nearest<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, c, h, w, mapx, mapy, out_h, out_w, (float*)dst);
+    return rpe_check_launch();
+}

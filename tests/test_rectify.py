@@ -1,0 +1,177 @@
+"""Rectification (dataset/rectification.py, dataset/preprocess/stereo_rectify.py).  cv2 is absent, so
+the host arithmetic is pinned to first principles (CPU tests) and the GPU gather to the scalar oracle (gpu tests)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import rectify as orc                                   # noqa: E402
+
+
+def _calib(seed=0, size=(160, 128)):
+    rng = np.random.default_rng(seed)
+    w, h = size
+    f = 0.85 * w
+    K1 = np.array([[f, 0, w / 2 - 3.0], [0, f * 0.998, h / 2 + 2.0], [0, 0, 1]])
+    K2 = np.array([[f * 1.004, 0, w / 2 + 4.0], [0, f * 1.001, h / 2 - 1.5], [0, 0, 1]])
+    d1 = np.array([-0.22, 0.09, 0.0012, -0.0007, -0.015]) * rng.uniform(0.7, 1.3)
+    d2 = np.array([-0.20, 0.08, -0.0010, 0.0006, -0.012]) * rng.uniform(0.7, 1.3)
+    om = rng.normal(0, 0.01, 3)
+    T = np.array([-4.2, 0.04, -0.06]) + rng.normal(0, 0.01, 3)
+    return dict(lkmat=K1, rkmat=K2, ld=d1, rd=d2, R=orc.rodrigues_vec_to_mat(om), T=T, img_size=size)
+
+
+@pytest.fixture(scope='module')
+def pp():
+    import rpe_amd
+    from rpe_amd import preprocess
+    return preprocess
+
+
+def test_rodrigues_round_trip_and_oracle(pp):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        v = rng.normal(0, 0.5, 3)
+        R = pp.rodrigues(v)
+        assert np.abs(R - orc.rodrigues_vec_to_mat(v)).max() < 1e-14
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-14 and np.abs(pp.rodrigues(R) - v).max() < 1e-12
+    assert np.array_equal(pp.rodrigues(np.zeros(3)), np.eye(3))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_rectified_views_are_row_aligned(pp, seed):
+    """A 3-D point must land on the same row of both rectified images, with disparity bf / z (the property rectification
+    exists for), and the new camera matrices must share focal length and principal point (CALIB_ZERO_DISPARITY)."""
+    c = _calib(seed)
+    R1, R2, P1, P2 = pp.stereo_rectify(c['lkmat'], c['ld'], c['rkmat'], c['rd'], c['img_size'], c['R'], c['T'], alpha=0)
+    for Rk in (R1, R2):
+        assert np.abs(Rk @ Rk.T - np.eye(3)).max() < 1e-13 and abs(np.linalg.det(Rk) - 1) < 1e-13
+    assert np.array_equal(P1[:, :3], P2[:, :3]) and P1[0, 0] == P1[1, 1] and P2[1, 3] == 0 and P1[0, 3] == 0
+    rng = np.random.default_rng(seed)
+    X = np.stack((rng.uniform(-30, 30, 200), rng.uniform(-25, 25, 200), rng.uniform(50, 300, 200)))
+    Xl, Xr = R1 @ X, R2 @ (c['R'] @ X + c['T'][:, None])             # the point in the two rectified camera frames
+    ul, ur = P1[:, :3] @ Xl, P2[:, :3] @ Xr
+    ul, ur = ul[:2] / ul[2], ur[:2] / ur[2]
+    assert np.abs(ul[1] - ur[1]).max() < 1e-9                          # same row
+    assert np.abs(Xl[2] - Xr[2]).max() < 1e-9                          # same depth in both rectified frames
+    bf = -P2[0, 3]                                                     # Tx * f
+    assert np.allclose((ul[0] - ur[0]) * Xl[2], bf, rtol=1e-11) and bf > 0
+    assert np.allclose(Xr - Xl, np.array([[P2[0, 3] / P2[0, 0]], [0], [0]]), atol=1e-9)          # pure x translation between the views
+
+
+@pytest.mark.parametrize('seed', [0, 3])
+def test_maps_invert_the_camera_model(pp, seed):
+    """map(u, v) must be where the ORIGINAL (distorted) camera sees the point whose rectified projection is (u, v): the
+    vectorised maps against the scalar oracle and against a forward projection of random 3-D points."""
+    c = _calib(seed, size=(48, 40))
+    R1, R2, P1, P2 = pp.stereo_rectify(c['lkmat'], c['ld'], c['rkmat'], c['rd'], c['img_size'], c['R'], c['T'], alpha=0)
+    mx, my = pp.init_undistort_rectify_map(c['lkmat'], c['ld'], R1, P1, c['img_size'])
+    ox, oy = orc.undistort_rectify_map(c['lkmat'], c['ld'], R1, P1, c['img_size'])
+    assert mx.dtype == np.float32 and mx.shape == (40, 48)
+    assert np.abs(mx - ox).max() <= 4e-6 and np.abs(my - oy).max() <= 4e-6          # (one f32 ulp at 48 px)
+    rng = np.random.default_rng(seed)
+    for _ in range(50):
+        u, v = int(rng.integers(0, 48)), int(rng.integers(0, 40))
+        z = rng.uniform(50, 300)
+        Xrect = np.linalg.inv(P1[:, :3]) @ np.array([u, v, 1.0]) * z              # a point that projects to (u, v) in the rectified left view
+        X = R1.T @ Xrect                                                          # ... in the original left camera frame
+        pu, pv = orc.project(X, c['lkmat'], c['ld'])
+        assert abs(pu - mx[v, u]) < 1e-4 and abs(pv - my[v, u]) < 1e-4
+
+
+def test_alpha_zero_keeps_only_valid_pixels(pp):
+    """alpha = 0: every rectified pixel maps inside the source image (up to the sampling of the 9x9 grid cv2 uses)."""
+    c = _calib(0)
+    maps, p1, p2 = pp.get_rect_maps(c['lkmat'], c['rkmat'], c['R'], c['T'], c['ld'], c['rd'], img_size=c['img_size'])
+    w, h = c['img_size']
+    for k in ('lmap1', 'rmap1'):
+        assert maps[k].min() > -1.0 and maps[k].max() < w
+    for k in ('lmap2', 'rmap2'):
+        assert maps[k].min() > -1.0 and maps[k].max() < h
+    # at least one border of one view touches the source border (the scale is the tightest one)
+    edges = [maps['lmap1'].min(), w - 1 - maps['lmap1'].max(), maps['lmap2'].min(), h - 1 - maps['lmap2'].max(),
+             maps['rmap1'].min(), w - 1 - maps['rmap1'].max(), maps['rmap2'].min(), h - 1 - maps['rmap2'].max()]
+    assert min(edges) < 1.5
+
+
+def test_rectifier_interface_and_calibration_files(pp, tmp_path):
+    """Constructor from .json / .ini / OpenCV .yaml, intrinsics scaling + vertical crop (rectification.py:27-37) and
+    get_rectified_calib (rectification.py:66-77)."""
+    c = _calib(2, size=(320, 256))
+    om = pp.rodrigues(c['R'])
+    fl = lambda a: [float(v) for v in a]
+    js = {'data': {'intrinsics': [{'f': fl([c['lkmat'][0, 0], c['lkmat'][1, 1]]), 'c': fl([c['lkmat'][0, 2], c['lkmat'][1, 2]]), 'k': fl(c['ld'])},
+                                  {'f': fl([c['rkmat'][0, 0], c['rkmat'][1, 1]]), 'c': fl([c['rkmat'][0, 2], c['rkmat'][1, 2]]), 'k': fl(c['rd'])}],
+                   'extrinsics': {'T': fl(c['T']), 'om': fl(om)}, 'width': 320, 'height': 256}}
+    (tmp_path / 'c.json').write_text(json.dumps(js))
+    ini = ['[StereoLeft]', 'res_x=320', 'res_y=256'] + ['%s=%r' % (k, float(v)) for k, v in zip(('fc_x', 'fc_y', 'cc_x', 'cc_y'), (c['lkmat'][0, 0], c['lkmat'][1, 1], c['lkmat'][0, 2], c['lkmat'][1, 2]))]
+    ini += ['kc_%d=%r' % (i, float(v)) for i, v in enumerate(list(c['ld']) + [0.0] * 3)]
+    ini += ['[StereoRight]'] + ['%s=%r' % (k, float(v)) for k, v in zip(('fc_x', 'fc_y', 'cc_x', 'cc_y'), (c['rkmat'][0, 0], c['rkmat'][1, 1], c['rkmat'][0, 2], c['rkmat'][1, 2]))]
+    ini += ['kc_%d=%r' % (i, float(v)) for i, v in enumerate(list(c['rd']) + [0.0] * 3)]
+    ini += ['T_%d=%r' % (i, float(v)) for i, v in enumerate(c['T'])] + ['R_%d=%r' % (i, float(v)) for i, v in enumerate(c['R'].reshape(-1))]
+    (tmp_path / 'c.ini').write_text('\n'.join(ini))
+
+    def mat(name, m):
+        m = np.atleast_2d(m)
+        return '%s: !!opencv-matrix\n   rows: %d\n   cols: %d\n   dt: d\n   data: [ %s ]\n' % (name, m.shape[0], m.shape[1], ', '.join(repr(float(v)) for v in m.reshape(-1)))
+    (tmp_path / 'c.yaml').write_text('%YAML:1.0\n---\nCamera.width: 320\nCamera.height: 256\n' + mat('M1', c['lkmat']) + mat('M2', c['rkmat']) +
+                                     mat('D1', c['ld']) + mat('D2', c['rd']) + mat('T', c['T'].reshape(3, 1)) + mat('R', c['R']))
+    rects = [pp.StereoRectifier(str(tmp_path / n)) for n in ('c.json', 'c.ini', 'c.yaml')] + [pp.StereoRectifier(dict(c))]
+    for r in rects[1:]:
+        assert np.abs(r.l_intr - rects[0].l_intr).max() < 1e-8 and np.abs(r.r_intr - rects[0].r_intr).max() < 1e-8
+        assert np.abs(r.maps['rmap1'] - rects[0].maps['rmap1']).max() < 1e-3
+    cal = rects[0].get_rectified_calib()
+    assert cal['intrinsics']['left'].shape == (3, 3) and np.array_equal(cal['intrinsics']['left'], cal['intrinsics']['right'])
+    assert abs(cal['bf'] - abs(rects[0].r_intr[0, 3])) < 1e-9 and cal['bf_orig'] == cal['bf'] and tuple(cal['img_size']) == (320, 256)
+    assert abs(cal['extrinsics'][0, 3] - rects[0].r_intr[0, 3] / rects[0].r_intr[0, 0]) < 1e-12
+    # half-size with a vertical crop: 320x256 -> 160x120 (scale 0.5, crop (128 - 120) / 2 = 4 rows)
+    half = pp.StereoRectifier(dict(c), img_size_new=(160, 120))
+    assert half.scale == 0.5 and abs(half.cal['lkmat'][1, 2] - (c['lkmat'][1, 2] * 0.5 - 4)) < 1e-12 and half.maps['lmap1'].shape == (120, 160)
+    assert abs(half.get_rectified_calib()['bf_orig'] - half.get_rectified_calib()['bf'] / 0.5) < 1e-12
+    with pytest.raises(NotImplementedError):
+        pp.StereoRectifier(dict(c), mode='pseudo')
+
+
+def test_oracle_remap_known_answers():
+    img = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)
+    mapx = np.array([[0.5, 1.5, 2.5, 3.5], [-0.5, 3.49, 3.51, np.nan]], np.float32)
+    mapy = np.array([[0.0, 0.0, 0.0, 0.0], [2.5, 1.5, 1.0, 1.0]], np.float32)
+    out = orc.remap_nearest(img, mapx, mapy)
+    # half to even: 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 3.5 -> 4 (outside: 0); -0.5 -> 0 with y 2.5 -> 2; 3.49 -> 3, y 1.5 -> 2; 3.51 -> 4 outside; NaN outside
+    assert out[0].tolist() == [[0.0, 2.0, 2.0, 0.0], [8.0, 11.0, 0.0, 0.0]]
+    assert out[1].tolist() == [[12.0, 14.0, 14.0, 0.0], [20.0, 23.0, 0.0, 0.0]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.float32])
+def test_gpu_remap_bit_exact(pp, dtype):
+    rng = np.random.default_rng(5)
+    c, h, w, oh, ow = 3, 37, 52, 41, 60
+    img = rng.integers(0, 256, (c, h, w)).astype(np.uint8 if dtype == torch.uint8 else np.float32)
+    mapx = (rng.uniform(-3, w + 3, (oh, ow))).astype(np.float32); mapy = (rng.uniform(-3, h + 3, (oh, ow))).astype(np.float32)
+    mapx[0, :8] = np.array([0.5, 1.5, 2.5, -0.5, w - 0.5, w - 1.5, np.nan, 1e9], np.float32)            # ties, borders, NaN, overflow
+    mapy[1, :4] = np.array([0.5, h - 0.5, -1e9, np.inf], np.float32)
+    ref = orc.remap_nearest(img, mapx, mapy)
+    got = pp.remap_nearest(torch.from_numpy(img).cuda(), torch.from_numpy(mapx).cuda(), torch.from_numpy(mapy).cuda())
+    assert got.dtype == dtype and np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_rectifier_matches_oracle_and_aligns_rows(pp):
+    """StereoRectifier.__call__ on the GPU = the oracle's remap of the same maps; and an image of a synthetic scene rendered
+    through both distorted cameras comes out row-aligned."""
+    c = _calib(1, size=(96, 80))
+    rect = pp.StereoRectifier(dict(c))
+    rng = np.random.default_rng(2)
+    L = rng.integers(0, 256, (3, 80, 96)).astype(np.uint8); Rr = rng.integers(0, 256, (3, 80, 96)).astype(np.uint8)
+    gl, gr = rect(torch.from_numpy(L).cuda(), torch.from_numpy(Rr).cuda())
+    assert np.array_equal(gl.cpu().numpy(), orc.remap_nearest(L, rect.maps['lmap1'], rect.maps['lmap2']))
+    assert np.array_equal(gr.cpu().numpy(), orc.remap_nearest(Rr, rect.maps['rmap1'], rect.maps['rmap2']))
+    # the right map is built with the LEFT distortion coefficients, as the reference does (stereo_rectify.py:29)
+    _, R2, _, P2 = pp.stereo_rectify(c['lkmat'], c['ld'], c['rkmat'], c['rd'], c['img_size'], c['R'], c['T'], alpha=0)
+    ox, oy = orc.undistort_rectify_map(c['rkmat'], c['ld'], R2, P2, c['img_size'])
+    assert np.abs(rect.maps['rmap1'] - ox).max() <= 8e-6 and np.abs(rect.maps['rmap2'] - oy).max() <= 8e-6
