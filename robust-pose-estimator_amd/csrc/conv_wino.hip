@@ -179,15 +179,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         for (int c = 0; c < CB; ++c) acc[p][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
 
-    // ---- prologue: U(0), raw(0), raw(1) land; V(0) is built; then the two DMA groups the loop expects in flight
+    // ---- prologue: everything the first steps need is requested at once (the groups the loop expects in flight, in its order);
+    // the wave waits for U(0), raw(0), raw(1) only, V(0) is built, and raw(3) follows once raw(0)'s buffer is free.  Raw
+    // s_barrier + explicit waits: __syncthreads() would drain the DMA queue.
     dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-    patch_raw(0); patch_raw(1);
-    __syncthreads();
-    tr_read(0, 0); tr_cols(); tr_store(0);
-    __syncthreads();                                          // V(0) visible; raw(0)'s buffer free
     dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
-    dma_u(wslice + (size_t)clamped(2) * wstep, 2); dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
+    dma_u(wslice + (size_t)clamped(2) * wstep, 2);
+    if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F7B); else __builtin_amdgcn_s_waitcnt(0x0F77);     // vmcnt(4 + 3 + 4 | 2 + 3 + 2)
+    patch_raw(0); patch_raw(1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    tr_read(0, 0); tr_cols(); tr_store(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                             // V(0) visible; raw(0)'s buffer free
+    dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
     const float* unext = wave_uniform(wslice + (size_t)clamped(3) * wstep);         // U(s + 3), raw(s + 4) of the step the loop is in
     const float* rnext = wave_uniform(xsrc + (size_t)clamped(4) * rstep);
     // ---- step s, four groups of 8 (CB = 2) matrix instructions, one per four positions:

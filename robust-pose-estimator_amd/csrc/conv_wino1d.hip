@@ -130,15 +130,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
             for (int t = 0; t < 2; ++t) acc[p][c][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
 
-    // ---- prologue: U(0), raw(0), raw(1) land; V(0) is built; then the two DMA groups the loop expects in flight
+    // ---- prologue: everything the first steps need is requested at once (the groups the loop expects in flight, in its order);
+    // the wave waits for U(0), raw(0), raw(1) only, V(0) is built, and raw(3) follows once raw(0)'s buffer is free
     dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
-    patch_raw(0); patch_raw(1);
-    __syncthreads();
-    tr_read(0); tr_math(); tr_store(0);
-    __syncthreads();                                          // V(0) visible; raw(0)'s buffer free
     dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
-    dma_u(wslice + (size_t)clamped(2) * wstep, 2); dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
+    dma_u(wslice + (size_t)clamped(2) * wstep, 2);
+    __builtin_amdgcn_s_waitcnt(0x0F76);                       // vmcnt(2 + 2 + 2)
+    patch_raw(0); patch_raw(1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    tr_read(0); tr_math(); tr_store(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                             // V(0) visible; raw(0)'s buffer free
+    dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
     const float* unext = wave_uniform(wslice + (size_t)clamped(3) * wstep);         // U(s + 3), raw(s + 4) of the step the loop is in
     const float* rnext = wave_uniform(xsrc + (size_t)clamped(4) * rstep);
     // ---- step s: four groups of 8 matrix instructions = (positions 0-3 | 4-7) x (channel block 0 | 1), each against both tile blocks:
