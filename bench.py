@@ -292,7 +292,11 @@ def run_batch(args, rank, world, dev, dist):
         r = real_conv(x, pc, *a, **k)
         e1.record()
         st = k.get('stride', 1)
-        conv_events.append((e0, e1, 2.0 * x.shape[0] * (x.shape[2] // st) * (x.shape[3] // st) * pc.cin * pc.cout * pc.kh * pc.kw))
+        flop = 2.0 * x.shape[0] * (x.shape[2] // st) * (x.shape[3] // st) * pc.cin * pc.cout * pc.kh * pc.kw
+        if k.get('entry') == 'rpe_conv_wino1d':    # the GRU's context terms
+            wino1d_events.append((e0, e1, flop * 0.4, flop))
+        else:
+            conv_events.append((e0, e1, flop))
         return r
 
     rpe_amd.ops.conv_fused = timed_conv            # raft.py calls it as ops.conv_fused
