@@ -228,28 +228,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     const float* zb = P.z ? P.z + (size_t)bz * P.zbs : nullptr;
     float* outb = P.out + (size_t)bz * P.obs;
     float* out2b = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
-    const int pstride = VERT ? W : 1;                           // distance of a tile's four pixels
+    // 5x1: a lane's four outputs are four ROWS of one column.  Moving them (and the add / hidden / z operands) as strided dwords
+    // costs four times the memory instructions of the 1x5 case (PMC: matrix pipe 58 % busy against 68 %), so each 16-lane
+    // group first transposes its 16 columns x 4 rows through LDS -- the wave's own slice of the idle weight ring -- and a lane
+    // ends up with four consecutive columns of one row: every access below is 16 bytes in both orientations.
+    float* tsc = &Us[0][wv * 512] + lk * 64;
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
         const int tile = tw * 32 + tb * 16 + li;
-        const int oy = VERT ? y0 + 4 * (tile >> 4) : y0 + (tile >> 2), ox = VERT ? x0 + (tile & 15) : x0 + 4 * (tile & 3);
-        bool pok[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pok[i] = VERT ? (oy + i < H) & (ox < W) : (oy < H) & (ox < W);
+        const int oy = VERT ? y0 + 4 * (tile >> 4) + (li >> 2) : y0 + (tile >> 2), ox = VERT ? x0 + 4 * (li & 3) : x0 + 4 * (tile & 3);
+        const bool pok = (oy < H) & (ox < W);                         // (W % 4 == 0: a quad is inside or outside as a whole)
         auto ld4 = [&](const float* p, size_t e, float (&v)[4]) {
-            if (VERT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = pok[i] ? p[e + (size_t)i * W] : 0.0f;
-            } else {
-                const f32x4 q = pok[0] ? *(const f32x4*)(p + e) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-            }
+            const f32x4 q = pok ? *(const f32x4*)(p + e) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
         };
         auto st4 = [&](float* p, size_t e, const float (&v)[4]) {
-            if (VERT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) if (pok[i]) p[e + (size_t)i * W] = v[i];
-            } else if (pok[0]) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
+            if (pok) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
         };
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -263,6 +257,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                 const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
                 float v[4] = {((m[0] + s12) + s34) + s56, fmaf(0.5f, d56, fmaf(2.0f, d34, d12)), fmaf(0.25f, s56, fmaf(4.0f, s34, s12)),
                               m[7] + fmaf(0.125f, d56, fmaf(8.0f, d34, d12))};
+                if (VERT) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tsc[i * 16 + li] = v[i];                 // [row][column]
+                    const f32x4 q = *(const f32x4*)&tsc[(li >> 2) * 16 + 4 * (li & 3)];  // (LDS operations of a wave execute in order)
+                    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+                }
                 const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
                 const float bi = P.bias ? P.bias[co] : 0.0f;
                 float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -297,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                 }
             }
     }
-    (void)pstride;
 }
 
 // weight (cout, cin, 5 taps) [= (cout, cin, 1, 5) or (cout, cin, 5, 1)] -> U = G g, laid out
@@ -352,10 +351,10 @@ extern "C" int rpe_conv_wino1d(const rpe_conv_desc* d, void* stream) {
     if (d->mode == RPE_CONV_GATE_ZR && (!d->out2 || !d->hidden || d->gate_channels <= 0 || d->cout != 2 * d->gate_channels)) return RPE_E_BADARG;
     if (d->mode == RPE_CONV_GATE_H && (!d->hidden || !d->zgate)) return RPE_E_BADARG;
     if (d->scale || d->residual || d->stats || d->pre_norm) return RPE_E_UNSUPPORTED;
-    // 16-byte accesses: the input quads of the LDS-DMA and (1x5) the four pixels of a tile in every tensor of the epilogue
+    // 16-byte accesses: the input quads of the LDS-DMA and the four pixels a lane handles in every tensor of the epilogue
     auto a16 = [](const void* p, long long bs) { return !p || ((((uintptr_t)p) & 15) == 0 && (bs & 3) == 0); };
     if (!a16(d->x, d->x_batch_stride) || !a16(d->packed, 0)) return RPE_E_UNSUPPORTED;
-    if (horiz && (!a16(d->out, d->out_batch_stride) || !a16(d->out2, d->out2_batch_stride) || !a16(d->add, d->add_batch_stride) ||
+    if ((!a16(d->out, d->out_batch_stride) || !a16(d->out2, d->out2_batch_stride) || !a16(d->add, d->add_batch_stride) ||
                   !a16(d->hidden, d->hidden_batch_stride) || !a16(d->zgate, d->zgate_batch_stride))) return RPE_E_UNSUPPORTED;
     W1P P;
     P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed; P.cin = d->cin; P.cout = d->cout; P.coP = w1_cop(d->cout);
