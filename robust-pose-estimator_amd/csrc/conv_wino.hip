@@ -60,11 +60,13 @@ __device__ __forceinline__ void dma4x3(const float* base, unsigned v0, unsigned 
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "s"(base), "s"(lds_addr) : "memory");
 }
-#ifdef WINO_TIMING
+#if defined(WINO_TIMING) || defined(WINO_PHASES)
 // Experiment hook (tools/build_variant.sh ... -DWINO_TIMING): s_memtime stamps at the group boundaries of the main loop, summed over
 // the steps of workgroup (0, 0, 0), wave 0; read back with rpe_debug_wino_timing.
 __device__ unsigned long long g_wino_timing[8];
 extern "C" int rpe_debug_wino_timing(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wino_timing), 64) == hipSuccess ? 0 : -1; }
+#endif
+#ifdef WINO_TIMING
 #define STAMP(i) T[i] = __builtin_readcyclecounter()
 #else
 #define STAMP(i)
@@ -78,12 +80,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
     __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // ENC: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WINO_PHASES
+    const unsigned long long ph0 = __builtin_readcyclecounter();
+#endif
 #ifdef WINO_PAD
     __shared__ float padlds[WINO_PAD];
     if (P.cin < 0) { padlds[tid] = 1.0f; P.out[0] = padlds[tid ^ 1]; }
 #endif
     const int ptx = (P.W + 2 * WB_TX - 1) / (2 * WB_TX);
-    const int x0 = (blockIdx.x % ptx) * (2 * WB_TX), y0 = (blockIdx.x / ptx) * (2 * WB_TY);
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id (= blockIdx.x mod 8 when gridDim.x is a multiple of 8): each XCD
+    // takes a contiguous run of patches, so neighbours -- shared halo rows, the two 64-B halves of an output line -- meet in one L2
+#ifndef WINO_NO_XCD
+    const int pid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#else
+    const int pid = blockIdx.x;
+#endif
+    const int x0 = (pid % ptx) * (2 * WB_TX), y0 = (pid / ptx) * (2 * WB_TY);
     const int co0 = P.co_base + blockIdx.y * TCO, bz = blockIdx.z;
     const int H = P.H, W = P.W, hw = H * W;
     const float* xb = P.x + (size_t)bz * P.xbs;
@@ -307,6 +319,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         for (int i = 0; i < 7; ++i) Tp[i] = T[i];
 #endif
     };
+#ifdef WINO_PHASES
+    const unsigned long long ph1 = __builtin_readcyclecounter();
+#endif
     {
         typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
         int s = 0;
@@ -320,6 +335,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // the repeats issued past the end have landed before LDS is released
+#ifdef WINO_PHASES
+    const unsigned long long ph2 = __builtin_readcyclecounter();
+#endif
 #ifdef WINO_TIMING
     if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && tid == 0) {
         for (int i = 0; i < 6; ++i) g_wino_timing[i] = Ta[i];
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
                 // one (count, mean, M2) record per channel, patch and tile half, straight to memory: rpe_instnorm_apply / _finalize
                 // merge records in f64 anyway (the pivot is a sample, so s2 - s1^2/n loses at most a factor ~2 in f32)
                 if (li == 0 && cok) {
-                    float* st = P.stats + (((size_t)bz * (2 * gridDim.x) + 2 * blockIdx.x + tw) * P.cout + co) * 3;      // (b, records, cout, 3)
+                    float* st = P.stats + (((size_t)bz * (2 * gridDim.x) + 2 * pid + tw) * P.cout + co) * 3;      // (b, records, cout, 3)
                     const float m = nvalid > 0.0f ? s1 / nvalid : 0.0f;
                     st[0] = nvalid; st[1] = piv + m; st[2] = s2 - s1 * m;
                 }
@@ -393,6 +411,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
                 if (ob2) { *(float2*)(ob2 + e0) = make_float2(y[0], y[1]); *(float2*)(ob2 + e0 + W) = make_float2(y[2], y[3]); }
             }
         }
+#ifdef WINO_PHASES
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && tid == 0) {
+        const unsigned long long ph3 = __builtin_readcyclecounter();
+        g_wino_timing[0] = ph1 - ph0; g_wino_timing[1] = ph2 - ph1; g_wino_timing[2] = ph3 - ph2; g_wino_timing[3] = g_wino_timing[4] = g_wino_timing[5] = 0; g_wino_timing[6] = 1;
+    }
+#endif
 }
 
 // weight (cout, cin, 3, 3) -> U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], laid out

@@ -46,7 +46,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     __shared__ __attribute__((aligned(16))) float Rs[3][W1_RAWF];             // raw input patch [ci][row][column]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ptx = (P.W + 15) / 16;
-    const int x0 = (blockIdx.x % ptx) * 16, y0 = (blockIdx.x / ptx) * 16;
+    // each XCD (workgroups are dealt round-robin by linear id) takes a contiguous run of patches: neighbours share halo and output lines in one L2
+#ifndef WINO_NO_XCD
+    const int pid = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#else
+    const int pid = blockIdx.x;
+#endif
+    const int x0 = (pid % ptx) * 16, y0 = (pid / ptx) * 16;
     const int co0 = blockIdx.y * W1_CO, bz = blockIdx.z;
     const int H = P.H, W = P.W, hw = H * W;
     const float* xb = P.x + (size_t)bz * P.xbs;
