@@ -48,6 +48,7 @@ struct WinoP {
     // and the input normalised + ReLU'd while it is transformed (pre: (b, cin, 2) = mean, 1/std of the previous convolution)
     const float* scale; const float* res; long long rbs; float* stats; const float* pre;
     int co_base;                                  // first output channel of this launch (a trailing 32-channel tile is its own launch)
+    int v4;                                       // W % 4 == 0 and out / out2 / residual 16-byte aligned: the epilogue moves 16 bytes per lane
 };
 
 // three 256-B chunks of gathered dwords: global base + v_j + 256 j  ->  LDS lds_addr + 256 j + lane * 4   (the caller folds the
@@ -72,13 +73,17 @@ extern "C" int rpe_debug_wino_timing(unsigned long long* out8) { return hipMemcp
 #define STAMP(i)
 #endif
 // CB = 16-channel blocks per wave: 2 -> 64 output channels per workgroup, 1 -> 32 (the trailing tile of cout = 96: no padded half)
-template <bool ENC, bool PRE, int CB>
+// EPI = the epilogue's compile-time shape: 0 bias / ReLU / out2 (update block); 1 + scale and residual (cnet: folded batch norm);
+// 2 + moments (fnet); 3 all of them at run time.  (With every feature behind a run-time branch the encoder epilogue took 14-22 k
+// cycles per workgroup against 9 k for the plain one.)
+template <int EPI, bool PRE, int CB>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
+    constexpr bool HAS_AFFINE = EPI == 1 || EPI == 3, HAS_STATS = EPI == 2 || EPI == 3;
     constexpr int TCO = 32 * CB, UT_STEP = WK * TCO * 16;
     __shared__ __attribute__((aligned(16))) float Us[3][UT_STEP];            // [ci][co][position], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
     __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
-    __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // ENC: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
+    __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // PRE: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef WINO_PHASES
     const unsigned long long ph0 = __builtin_readcyclecounter();
@@ -190,6 +195,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
 #pragma unroll
         for (int c = 0; c < CB; ++c) acc[p][c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
+    // per-channel epilogue constants, requested before the first DMA (ordinary loads return in order with the DMAs: issued here they
+    // have landed long before the first counted wait, issued in the epilogue they cost it a memory round trip)
+    float bi_[CB][4], sc_[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
+            const int cc = co < P.cout ? co : P.cout - 1;            // (clamped: no branch around the load; rows past cout are never stored)
+            bi_[cb][r] = P.bias ? P.bias[cc] : 0.0f;
+            sc_[cb][r] = (HAS_AFFINE && P.scale) ? P.scale[cc] : 1.0f;
+        }
 
     // ---- prologue: everything the first steps need is requested at once (the groups the loop expects in flight, in its order);
     // the wave waits for U(0), raw(0), raw(1) only, V(0) is built, and raw(3) follows once raw(0)'s buffer is free.  Raw
@@ -352,10 +369,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     const bool pix_ok = (oy < H) & (ox < W);                        // (H, W even: a tile is inside or outside as a whole)
     float* ob = P.out + (size_t)bz * P.obs;
     float* ob2 = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
-    const float* rsb = (ENC && P.res) ? P.res + (size_t)bz * P.rbs : nullptr;
+    const float* rsb = (HAS_AFFINE && P.res) ? P.res + (size_t)bz * P.rbs : nullptr;
     const float nvalid = 4.0f * (float)__popcll(__ballot(pix_ok) & 0xFFFFull);   // pixels of this wave's 16 tiles inside the map
+    const float inv_nvalid = nvalid > 0.0f ? 1.0f / nvalid : 0.0f;               // (4, 8, ..., 64: the reciprocal is exact or 1 ulp)
+    const bool odd = li & 1;                                        // lane pairs = two x-neighbouring tiles
+    // the residual quads of all eight (block, row) iterations are requested up front (the per-channel constants at kernel start):
+    // loaded where they are used, each iteration waited a full memory round trip for them behind the previous iteration's stores
+    f32x4 rq_[CB][4];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
+            const bool cok = co < P.cout;
+            rq_[cb][r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (HAS_AFFINE && rsb && P.v4 && pix_ok && cok)
+                rq_[cb][r] = *(const f32x4*)(rsb + (size_t)co * hw + (size_t)(oy + (odd ? 1 : 0)) * W + (ox - (odd ? 2 : 0)));
+        }
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        float rec[3] = {0.0f, 0.0f, 0.0f};                             // lane li < 4 collects the moment record of channel row r = li
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = cw * 16 * CB + cb * 16 + 4 * lk + r, co = co0 + col;
@@ -366,41 +399,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
                 sb[nu] = (acc[1 * 4 + nu][cb][r] - acc[2 * 4 + nu][cb][r]) - acc[3 * 4 + nu][cb][r];
             }
             const bool cok = co < P.cout;
-            const float bi = (P.bias && cok) ? P.bias[co] : 0.0f;
+            const float bi = bi_[cb][r];
             float y[4] = {(sa[0] + sa[1]) + sa[2], (sa[1] - sa[2]) - sa[3], (sb[0] + sb[1]) + sb[2], (sb[1] - sb[2]) - sb[3]};
-            if (ENC && P.scale) { const float sc = cok ? P.scale[co] : 1.0f;
+            if (HAS_AFFINE && P.scale) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] *= sc; }
+                for (int e = 0; e < 4; ++e) y[e] *= sc_[cb][r]; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] += bi;
-            if (ENC && P.stats) {
+            if (HAS_STATS && (EPI == 2 || P.stats)) {
                 // moments of v over this wave's 16 tiles x 4 pixels about a pivot (the wave's first value of the channel: valid
                 // whenever any of its tiles is, because tile 0 is the wave's top-left one), summed over the 16-lane row
                 const int y0b = __builtin_bit_cast(int, y[0]);                 // lane 0 of this lane's 16-lane row, without an LDS round trip
-                const int p01 = lk & 1 ? __builtin_amdgcn_readlane(y0b, 16) : __builtin_amdgcn_readlane(y0b, 0);
-                const int p23 = lk & 1 ? __builtin_amdgcn_readlane(y0b, 48) : __builtin_amdgcn_readlane(y0b, 32);
-                const float piv = __builtin_bit_cast(float, lk & 2 ? p23 : p01);
+                const int q0 = __builtin_amdgcn_readlane(y0b, 0), q1 = __builtin_amdgcn_readlane(y0b, 16);      // (all four, then selects:
+                const int q2 = __builtin_amdgcn_readlane(y0b, 32), q3 = __builtin_amdgcn_readlane(y0b, 48);     //  no divergent branches)
+                const float piv = __builtin_bit_cast(float, lk == 0 ? q0 : lk == 1 ? q1 : lk == 2 ? q2 : q3);
                 float s1 = 0.0f, s2 = 0.0f;
                 if (pix_ok) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float dv = y[e] - piv; s1 += dv; s2 += dv * dv; }
                 }
                 s1 = row16_sum(s1); s2 = row16_sum(s2);
-                // one (count, mean, M2) record per channel, patch and tile half, straight to memory: rpe_instnorm_apply / _finalize
-                // merge records in f64 anyway (the pivot is a sample, so s2 - s1^2/n loses at most a factor ~2 in f32)
-                if (li == 0 && cok) {
-                    float* st = P.stats + (((size_t)bz * (2 * gridDim.x) + 2 * pid + tw) * P.cout + co) * 3;      // (b, records, cout, 3)
-                    const float m = nvalid > 0.0f ? s1 / nvalid : 0.0f;
-                    st[0] = nvalid; st[1] = piv + m; st[2] = s2 - s1 * m;
-                }
+                // one (count, mean, M2) record per channel, patch and tile half: rpe_instnorm_apply / _finalize merge records in f64
+                // anyway (the pivot is a sample, so s2 - s1^2/n loses at most a factor ~2 in f32).  Every lane of the row has the
+                // totals; lane r keeps them, and the four records of a block leave together below (a store per record and value --
+                // 24 nearly empty store instructions per wave -- cost the epilogue more than the arithmetic)
+                const float m = s1 * inv_nvalid;
+                if (li == r) { rec[0] = nvalid; rec[1] = piv + m; rec[2] = s2 - s1 * m; }
             }
             if (P.mode == RPE_CONV_RELU) {                                   // NaN stays NaN, like torch.relu
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[e] = y[e] < 0.0f ? 0.0f : y[e];
             }
-            if (pix_ok && cok) {
+            if (P.v4) {
+                // the pair exchanges halves (DPP quad_perm [1,0,3,2]): the even lane ends with row 0 of both tiles, the odd lane with
+                // row 1: one 16-byte access per lane instead of two 8-byte ones (the store tail is issue-bound)
+                const float sA = odd ? y[0] : y[2], sB = odd ? y[1] : y[3];
+                const float rA = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sA), 0xB1, 0xF, 0xF, true));
+                const float rB = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sB), 0xB1, 0xF, 0xF, true));
+                f32x4 q = odd ? (f32x4){rA, rB, y[2], y[3]} : (f32x4){y[0], y[1], rA, rB};
+                if (pix_ok && cok) {
+                    const size_t e4 = (size_t)co * hw + (size_t)(oy + (odd ? 1 : 0)) * W + (ox - (odd ? 2 : 0));
+                    if (rsb) {                                               // ResidualBlock tail: relu(x + y)
+                        q += rq_[cb][r];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = q[e] < 0.0f ? 0.0f : q[e];
+                    }
+                    *(f32x4*)(ob + e4) = q;
+                    if (ob2) *(f32x4*)(ob2 + e4) = q;
+                }
+            } else if (pix_ok && cok) {
                 const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
-                if (rsb) {                                                   // ResidualBlock tail: relu(x + y)
+                if (rsb) {
                     const float2 ra = *(const float2*)(rsb + e0), rb2 = *(const float2*)(rsb + e0 + W);
                     y[0] += ra.x; y[1] += ra.y; y[2] += rb2.x; y[3] += rb2.y;
 #pragma unroll
@@ -411,6 +460,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
                 if (ob2) { *(float2*)(ob2 + e0) = make_float2(y[0], y[1]); *(float2*)(ob2 + e0 + W) = make_float2(y[2], y[3]); }
             }
         }
+        if (HAS_STATS && (EPI == 2 || P.stats)) {
+            const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + li;       // lanes 0-3 of each 16-lane row: four consecutive channels
+            if (li < 4 && co < P.cout) {
+                float* st = P.stats + (((size_t)bz * (2 * gridDim.x) + 2 * pid + tw) * P.cout + co) * 3;      // (b, records, cout, 3)
+                st[0] = rec[0]; st[1] = rec[1]; st[2] = rec[2];
+            }
+        }
+    }
 #ifdef WINO_PHASES
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && tid == 0) {
@@ -479,6 +536,8 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     P.x = d->x; P.xbs = d->x_batch_stride; P.wp = d->packed; P.cin = d->cin; P.cout = d->cout; P.coP = wino_cop(d->cout);
     P.H = d->h; P.W = d->w; P.bias = d->bias; P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.mode = d->mode;
+    auto a16 = [](const void* p, long long bs) { return !p || ((((uintptr_t)p) & 15) == 0 && (bs & 3) == 0); };
+    P.v4 = (d->w & 3) == 0 && a16(d->out, d->out_batch_stride) && a16(d->out2, d->out2_batch_stride) && a16(d->residual, d->residual_batch_stride);
     P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats; P.pre = d->pre_norm;
     // 64-channel tiles; a remainder of at most 32 channels (cout = 96) runs as one 32-channel tile instead of a half-empty 64
     const int rem = d->cout % WB_CO, tail32 = rem > 0 && rem <= 32;
@@ -486,16 +545,22 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     const unsigned gx = ceil_div(d->w, 2 * WB_TX) * ceil_div(d->h, 2 * WB_TY);
     hipStream_t s = (hipStream_t)stream;
     P.co_base = 0;
-    if (n64 > 0) {
-        if (d->pre_norm) hipLaunchKernelGGL((k_conv_wino<true, true, 2>), dim3(gx, n64, d->b), dim3(256), 0, s, P);
-        else if (enc) hipLaunchKernelGGL((k_conv_wino<true, false, 2>), dim3(gx, n64, d->b), dim3(256), 0, s, P);
-        else hipLaunchKernelGGL((k_conv_wino<false, false, 2>), dim3(gx, n64, d->b), dim3(256), 0, s, P);
-    }
+    // epilogue shape: 0 plain, 1 scale / residual (cnet), 2 moments (fnet), 3 anything else
+    const int epi = !enc ? 0 : (d->stats && !d->scale && !d->residual) ? 2 : !d->stats ? 1 : 3;
+    auto launch = [&](auto cbc, dim3 grid) {
+        constexpr int CBv = decltype(cbc)::value;
+#define WINO_LAUNCH(E, PR) hipLaunchKernelGGL((k_conv_wino<E, PR, CBv>), grid, dim3(256), 0, s, P)
+        if (d->pre_norm) { if (epi == 2) WINO_LAUNCH(2, true); else WINO_LAUNCH(3, true); }
+        else if (epi == 0) WINO_LAUNCH(0, false);
+        else if (epi == 1) WINO_LAUNCH(1, false);
+        else if (epi == 2) WINO_LAUNCH(2, false);
+        else WINO_LAUNCH(3, false);
+#undef WINO_LAUNCH
+    };
+    if (n64 > 0) launch(std::integral_constant<int, 2>{}, dim3(gx, n64, d->b));
     if (tail32) {
         P.co_base = n64 * WB_CO;
-        if (d->pre_norm) hipLaunchKernelGGL((k_conv_wino<true, true, 1>), dim3(gx, 1, d->b), dim3(256), 0, s, P);
-        else if (enc) hipLaunchKernelGGL((k_conv_wino<true, false, 1>), dim3(gx, 1, d->b), dim3(256), 0, s, P);
-        else hipLaunchKernelGGL((k_conv_wino<false, false, 1>), dim3(gx, 1, d->b), dim3(256), 0, s, P);
+        launch(std::integral_constant<int, 1>{}, dim3(gx, 1, d->b));
     }
     return rpe_check_launch();
 }

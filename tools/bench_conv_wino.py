@@ -69,11 +69,16 @@ with torch.no_grad():
         pc, pw = ops.PackedConv(w, None), ops.PackedWino(w, None)
         sd, sw = ops.conv_stats_buffer(nb, c, hh, ww, dev), ops.conv_wino_stats_buffer(nb, c, hh, ww, dev)
         flop = 2.0 * nb * hh * ww * c * c * 9
-        td = t(lambda: ops.conv_fused(x, pc, ops.CONV_LINEAR, o1, bias=bias, stats=sd))
-        tw = t(lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias, stats=sw))
-        tn = t(lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias))
         ones = torch.ones(c, device=dev)
-        te = t(lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias, scale=ones))
+        # (round-robin over the variants: a fixed order hands the last one a warmer, slower chip)
+        fns = [lambda: ops.conv_fused(x, pc, ops.CONV_LINEAR, o1, bias=bias, stats=sd), lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias, stats=sw),
+               lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias), lambda: ops.conv_wino(x, pw, ops.CONV_LINEAR, o2, bias=bias, scale=ones)]
+        acc = [[] for _ in fns]
+        for rep in range(3):
+            for i in ([0, 1, 2, 3], [3, 2, 1, 0], [1, 3, 0, 2])[rep]:
+                acc[i].append(t(fns[i], reps=6))
+        td, tw, tn, te = (sorted(a)[1] for a in acc)
+        fns[1]()                                          # (o2 = the moments variant's output for the comparison below)
         print('        (encoder instantiation without moments: %7.1f us)' % te)
         print('%-7s %3d ch %3dx%3d  direct %7.1f us (%5.1f TF)   winograd %7.1f us (%5.1f TF executed, %5.1f effective; without moments %7.1f us)   maxdiff %.1e' % (
             name, c, hh, ww, td, flop / td / 1e6, tw, flop / 2.25 / tw / 1e6, flop / tw / 1e6, tn, (o1 - o2).abs().max().item()))

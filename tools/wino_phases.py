@@ -14,6 +14,11 @@ for name, c, hh, ww, nb in (('layer1 64ch 256x320 x48', 64, 256, 320, 48), ('lay
     torch.cuda.synchronize(); phases(name + ' +moments')
     for _ in range(3): ops.conv_wino(x, pw, ops.CONV_RELU, o, bias=bias)
     torch.cuda.synchronize(); phases(name + ' plain')
+    ones = torch.ones(c, device=dev)
+    for _ in range(3): ops.conv_wino(x, pw, ops.CONV_RELU, o, bias=bias, scale=ones)
+    torch.cuda.synchronize(); phases(name + ' scale')
+    for _ in range(3): ops.conv_wino(x, pw, ops.CONV_RELU, o, bias=bias, scale=ones, residual=x)
+    torch.cuda.synchronize(); phases(name + ' scale+res')
 x = torch.randn(32, 256, 64, 80, device=dev); w = torch.randn(192, 256, 3, 3, device=dev) * 0.05
 o = torch.empty(32, 192, 64, 80, device=dev); pw = ops.PackedWino(w, torch.randn(192, device=dev))
 for _ in range(3): ops.conv_wino(x, pw, ops.CONV_RELU, o)
