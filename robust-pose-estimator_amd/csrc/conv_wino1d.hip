@@ -135,6 +135,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) acc[p][c][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
+    float bi_[2][4];                                            // per-channel bias, requested before the first DMA (conv_wino.hip explains)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+            bi_[cb][r] = P.bias ? P.bias[co < P.cout ? co : P.cout - 1] : 0.0f;
+        }
 
     // ---- prologue: everything the first steps need is requested at once (the groups the loop expects in flight, in its order);
     // the wave waits for U(0), raw(0), raw(1) only, V(0) is built, and raw(3) follows once raw(0)'s buffer is free
@@ -244,15 +252,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
         const int tile = tw * 32 + tb * 16 + li;
         const int oy = VERT ? y0 + 4 * (tile >> 4) + (li >> 2) : y0 + (tile >> 2), ox = VERT ? x0 + 4 * (li & 3) : x0 + 4 * (tile & 3);
         const bool pok = (oy < H) & (ox < W);                         // (W % 4 == 0: a quad is inside or outside as a whole)
-        auto ld4 = [&](const float* p, size_t e, float (&v)[4]) {
-            const f32x4 q = pok ? *(const f32x4*)(p + e) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-        };
         auto st4 = [&](float* p, size_t e, const float (&v)[4]) {
             if (pok) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
         };
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
+            // the four channel rows of a block: every operand of their gate arithmetic is requested first (loaded where it is used,
+            // each row waited a memory round trip behind the previous row's store -- the in-place h update keeps the compiler from
+            // moving loads across stores), then the arithmetic and the stores
+            f32x4 av_[4], xv_[4], hv_[4];
+            const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+                const bool ok = pok && co < P.cout;
+                const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
+                av_[r] = (addb && ok) ? *(const f32x4*)(addb + e0) : zero4;
+                xv_[r] = hv_[r] = zero4;
+                if (mode == RPE_CONV_GATE_ZR) { if (ok && co >= cg) xv_[r] = *(const f32x4*)(hb + e0 - (size_t)cg * hw); }
+                else if (mode == RPE_CONV_GATE_H) { if (ok) { xv_[r] = *(const f32x4*)(zb + e0); hv_[r] = *(const f32x4*)(hb + e0); } }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
@@ -270,28 +289,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                     v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
                 }
                 const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
-                const float bi = P.bias ? P.bias[co] : 0.0f;
-                float av[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (addb) ld4(addb, e0, av);
+                const float bi = bi_[cb][r];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] + av[i] + bi;
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + av_[r][i] + bi;
                 if (mode == RPE_CONV_GATE_ZR) {
                     // z = sigmoid(.) -> out (channels < gate_channels);  r = sigmoid(.), r * h -> out2 (the other half)
                     float sg[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sg[i] = sigmoid_f(v[i]);
                     if (co >= cg) {
-                        const size_t eh = e0 - (size_t)cg * hw;
-                        float hv[4]; ld4(hb, eh, hv);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sg[i] *= hv[i];
-                        st4(out2b, eh, sg);
+                        for (int i = 0; i < 4; ++i) sg[i] *= xv_[r][i];
+                        st4(out2b, e0 - (size_t)cg * hw, sg);
                     } else st4(outb, e0, sg);
                 } else if (mode == RPE_CONV_GATE_H) {
                     // h <- (1 - z) h + z tanh(.)
-                    float zv[4], hv[4]; ld4(zb, e0, zv); ld4(hb, e0, hv);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - zv[i]) * hv[i] + zv[i] * tanh_f(v[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - xv_[r][i]) * hv_[r][i] + xv_[r][i] * tanh_f(v[i]);
                     st4(outb, e0, v);
                 } else {
                     if (mode == RPE_CONV_RELU) {                                  // NaN stays NaN, like torch.relu
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                     if (out2b) st4(out2b, e0, v);
                 }
             }
+        }
     }
 }
 
