@@ -84,6 +84,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
     __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
     __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // PRE: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
+    // every kernel argument the set-up needs is fetched in ONE batch of scalar loads: left to the compiler they were three
+    // dependent fetch - wait rounds (6-9 k cycles before the first DMA could be issued, of a 16-step workgroup's 57 k)
+    asm volatile("" :: "s"(P.x), "s"(P.wp), "s"(P.out), "s"(P.bias), "s"(P.xbs), "s"(P.obs), "s"(P.cin), "s"(P.cout), "s"(P.coP), "s"(P.H),
+                 "s"(P.W), "s"(P.co_base), "s"(P.v4), "s"(P.mode), "s"(P.out2), "s"(P.o2bs));
+    if (EPI != 0) asm volatile("" :: "s"(P.scale), "s"(P.res), "s"(P.rbs), "s"(P.stats), "s"(P.pre));
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef WINO_PHASES
     const unsigned long long ph0 = __builtin_readcyclecounter();
@@ -211,10 +216,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     // ---- prologue: everything the first steps need is requested at once (the groups the loop expects in flight, in its order);
     // the wave waits for U(0), raw(0), raw(1) only, V(0) is built, and raw(3) follows once raw(0)'s buffer is free.  Raw
     // s_barrier + explicit waits: __syncthreads() would drain the DMA queue.
+#ifdef WINO_PHASES
+    const unsigned long long pha = __builtin_readcyclecounter();
+#endif
     dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
     dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
     dma_u(wslice + (size_t)clamped(2) * wstep, 2);
     if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F7B); else __builtin_amdgcn_s_waitcnt(0x0F77);     // vmcnt(4 + 3 + 4 | 2 + 3 + 2)
+#ifdef WINO_PHASES
+    const unsigned long long phb = __builtin_readcyclecounter();
+#endif
     patch_raw(0); patch_raw(1);
     __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && tid == 0) {
         const unsigned long long ph3 = __builtin_readcyclecounter();
-        g_wino_timing[0] = ph1 - ph0; g_wino_timing[1] = ph2 - ph1; g_wino_timing[2] = ph3 - ph2; g_wino_timing[3] = g_wino_timing[4] = g_wino_timing[5] = 0; g_wino_timing[6] = 1;
+        g_wino_timing[0] = ph1 - ph0; g_wino_timing[1] = ph2 - ph1; g_wino_timing[2] = ph3 - ph2; g_wino_timing[3] = pha - ph0; g_wino_timing[4] = phb - pha; g_wino_timing[5] = ph1 - phb; g_wino_timing[6] = 1;
     }
 #endif
 }

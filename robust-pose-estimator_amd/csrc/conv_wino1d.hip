@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     __shared__ __attribute__((aligned(16))) float Us[3][W1_USTEP];            // [ci][co][8 positions], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][W1_USTEP];            // [ci][tile][8 positions]
     __shared__ __attribute__((aligned(16))) float Rs[3][W1_RAWF];             // raw input patch [ci][row][column]
+    // every kernel argument in ONE batch of scalar loads (left to the compiler: three dependent fetch - wait rounds, 6-9 k cycles
+    // before the first DMA)
+    asm volatile("" :: "s"(P.x), "s"(P.wp), "s"(P.out), "s"(P.bias), "s"(P.xbs), "s"(P.obs), "s"(P.cin), "s"(P.cout), "s"(P.coP), "s"(P.H),
+                 "s"(P.W), "s"(P.mode), "s"(P.cgate));
+    asm volatile("" :: "s"(P.add), "s"(P.abs_), "s"(P.out2), "s"(P.o2bs), "s"(P.hid), "s"(P.hbs), "s"(P.z), "s"(P.zbs));
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ptx = (P.W + 15) / 16;
     // each XCD (workgroups are dealt round-robin by linear id) takes a contiguous run of patches: neighbours share halo and output lines in one L2
