@@ -352,6 +352,44 @@ def test_random_shapes_against_library(rpe):
         assert err < tol, (case, kh, kw, stride, cin, cout, h, w, b, err, tol)
 
 
+def test_winograd_random_shapes_against_library(rpe):
+    """Sixty seeded random problems for the two Winograd kernels (channel counts that are no multiple of anything, maps that end
+    inside tiles and inside border patches, one-tile maps, launches of one workgroup and of thousands) against the library's f32
+    convolution on the same GPU; every epilogue the plain instantiations have (bias, ReLU, second destination, add)."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(20261003)
+    for case in range(60):
+        kind = ('3x3', '1x5', '5x1')[case % 3]
+        cin = int(rng.integers(1, 48)) * 4
+        cout = int(rng.integers(1, 200))
+        if kind == '3x3':
+            h, w = int(rng.integers(1, 30)) * 2, int(rng.integers(1, 30)) * 2
+            kh, kw = 3, 3
+        else:
+            h, w = int(rng.integers(1, 50)), int(rng.integers(1, 16)) * 4
+            kh, kw = (1, 5) if kind == '1x5' else (5, 1)
+        b = int(rng.choice([1, 2, 3, 24]))
+        x = torch.from_numpy(rng.normal(size=(b, cin, h, w)).astype(np.float32)).cuda()
+        wt = torch.from_numpy((rng.normal(size=(cout, cin, kh, kw)) * 0.1).astype(np.float32)).cuda()
+        bias = torch.from_numpy(rng.normal(size=(cout,)).astype(np.float32)).cuda()
+        relu, two = bool(rng.integers(2)), bool(rng.integers(2))
+        ref = F.conv2d(x, wt, bias, padding=(kh // 2, kw // 2))
+        out = torch.full_like(ref, float('nan')); out2 = torch.full_like(ref, float('nan')) if two else None
+        if kind == '3x3':
+            ops.conv_wino(x, ops.PackedWino(wt, bias), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, out2=out2)
+        else:
+            add = torch.from_numpy(rng.normal(size=ref.shape).astype(np.float32)).cuda() if rng.integers(2) else None
+            if add is not None:
+                ref = ref + add
+            ops.conv_wino1d(x, ops.PackedWino1d(wt, bias), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, out2=out2, add=add)
+        ref = ref.clamp_min(0) if relu else ref
+        tol = 2e-5 * np.sqrt(cin * kh * kw) * float(x.abs().max()) * float(wt.abs().max()) + 1e-5
+        err = float((out - ref).abs().max())
+        assert err < tol, (case, kind, cin, cout, h, w, b, relu, err, tol)                     # (NaN left anywhere fails here too)
+        if two:
+            assert torch.equal(out, out2), (case, kind)
+
+
 @pytest.mark.parametrize('cout,bias_val', [(64, 50.0), (64, -50.0), (96, 50.0), (128, -50.0), (112, 50.0)])
 def test_instance_norm_statistics_survive_large_means(rpe, cout, bias_val):
     """Planes whose |mean| >> std (a conv bias of +-50, or a constant-plus-noise plane): E[x^2] - mean^2 from f32 sums
