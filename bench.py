@@ -142,12 +142,19 @@ def main():
         res = run_sequence(args, rank, world, dev, dist)
     else:
         res = run_batch(args, rank, world, dev, dist if distributed else None)
-    if rank == 0:
-        res['rccl_ranks'] = rccl_ranks
-        print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        res['rccl_ranks'] = rccl_ranks
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be
+        # flushed at exit, after Python's line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 def timed_region(step, steps, warmup, dev, dist):
