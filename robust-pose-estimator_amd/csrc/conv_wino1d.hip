@@ -8,7 +8,7 @@
 //     y = A^T [ (G g) .* (B^T d) ],  d = 8 consecutive inputs, g = the 5 taps, points {0, +-1, +-2, +-1/2, inf}
 //   (B^T is the 8-point matrix of F(6,3); every entry is dyadic, so B^T d is exact up to the usual rounding of its sums).
 // In f32 the result differs from a direct f32 accumulation by about as much as two different summation orders do
-// (measured on 256-channel sums: mean |err| 6e-6 against 2.4e-6 for a serial direct sum, tools note in DESIGN.md).
+// (measured on 256-channel sums: mean |err| 6e-6 against 2.4e-6 for a serial direct sum; tools/winograd_numerics.py).
 //
 // Workgroup = 4 waves = 64 output channels x 64 tiles (16 x 16 output pixels; a tile = 4 pixels along the filter axis);
 // wave = 32 channels x 32 tiles = 2 x 2 blocks of v_mfma_f32_16x16x4_f32 per position, 8 positions: 128 accumulator
