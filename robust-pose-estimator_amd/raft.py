@@ -136,7 +136,7 @@ def _fusable(conv, x):
     # the encoder instantiations have no small-tile variant
     wide = conv.out_channels % 128 != 0 and conv.out_channels % 128 <= 96
     tiles = -(-(hh // stride) * (ww // stride) // (128 if (s2 or not wide) else 256)) * -(-conv.out_channels // (128 if (s2 or not wide) else 64))
-    big = tiles * x.shape[0] >= 256
+    big = tiles * x.shape[0] >= 256                            # (measured: below that the library's stride-2 kernels win, 104.9 vs 104.0 frames/s)
     if s1 and WINOGRAD and hh % 2 == 0 and ww % 2 == 0 and conv.in_channels <= 128:
         # the Winograd kernel's workgroups are 16 x 8 pixels x 64 channels: it still wins over the library at a quarter of the chip
         big = big or -(-hh // 8) * -(-ww // 16) * -(-conv.out_channels // 64) * x.shape[0] >= int(os.environ.get('RPE_WINO_MIN_WG', '64'))
@@ -296,7 +296,7 @@ class BasicMotionEncoder(nn.Module):
                 packed['_enc_calls'] = calls
             _, cor, flo_buf, c1, c2, f2, cv_ = calls
             c1(); c2()
-            if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= 512:    # enough 32x8 patches to fill the chip
+            if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '64')):    # (the library wins only on tiny maps)
                 ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
             else:
                 ops.bias_act(cv(self.convf1, flow), self.convf1.bias, out=flo_buf)
