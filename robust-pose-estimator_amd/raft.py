@@ -9,7 +9,7 @@ What runs where (MI355X-first split), all hand-written HIP 
     blocks (3x3 stride 1 and 2, 1x1 stride-2 shortcut) with folded batch norm / instance-norm statistics, as f32-MFMA
     implicit GEMMs (csrc/conv.hip); the 7x7 stems and convf1 (csrc/stem.hip)
   * flow-head output layer, convex up-sampling, norm / bias passes (csrc/raft_ops.hip)
-  Left on PyTorch-ROCm (MIOpen): the encoders' final 1x1, the mask head (once per pass), and -- for map widths that
+  Left on PyTorch-ROCm (MIOpen / rocBLAS): the encoders' final 1x1, the mask head's 1x1 (once per pass), and -- for map widths that
   are not a multiple of 4 or launches too small to fill the chip -- the library route of the same layers.
 Exact re-associations used (results identical up to float rounding of the conv library):
   * convz/convr of each GRU half share their input, so their weights are stacked into one 256-channel conv
@@ -435,7 +435,20 @@ class BasicUpdateBlock(nn.Module):
         return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)      # coords1 + delta_flow
 
     def up_mask(self, net):
-        return .25 * self.mask(net)                                      # scale mask to balance gradients (upstream)
+        """.25 * mask(net) (upstream scales the mask to balance gradients).  The 3x3 layer + ReLU runs on the Winograd kernel, the
+        factor is folded into the 1x1 layer's parameters (a power of two: bit-identical to scaling the result)."""
+        c1, c2 = self.mask[0], self.mask[2]
+        key = tuple(p._version for p in self.mask.parameters()) + tuple(p.data_ptr() for p in self.mask.parameters())
+        cached = getattr(self, '_mask_packed', None)
+        if cached is None or cached[0] != key:
+            pw = ops.PackedWino(c1.weight, c1.bias) if WINOGRAD and c1.weight.is_cuda else None
+            self._mask_packed = cached = (key, pw, (0.25 * c2.weight).detach(), (0.25 * c2.bias).detach())
+        _, pw, w2, b2 = cached
+        if pw is not None and not torch.is_grad_enabled() and net.is_contiguous() and net.shape[-1] % 2 == 0 and net.shape[-2] % 2 == 0:
+            t = ops.conv_wino(net, pw, ops.CONV_RELU, torch.empty(net.shape[0], c1.out_channels, net.shape[2], net.shape[3], device=net.device))
+        else:
+            t = F.relu(c1(net))
+        return F.conv2d(t, w2, b2)
 
 
 def coords_grid(batch, ht, wd, device):
