@@ -11,6 +11,11 @@ What is imported unchanged from the reference:
       classes are seeded into ``sys.modules`` under those names; the objective, masks, normalisation,
       closure and the real ``torch.optim.LBFGS`` are the reference's)
   core/interpol/flow_utils.py, core/utils/pytorch.py, core/metrics/trajectory_metrics.py  (import as is)
+  core/unet/unet.py, core/pose/pose_net.py, core/pose/pose_estimator.py   (``gen_modules``: need an empty
+      ``torchvision`` module -- unet.py:4 imports it and never uses it -- and ``core.RAFT.core.raft.RAFT``,
+      the empty submodule, for which ``oracle.raft.RAFT`` stands in; everything else that runs -- TinyUNet,
+      PoseNet.infer / flow2depth / get_weight_maps / proj, PoseEstimator.forward / get_pose_f2f with its gate,
+      de-normalisation and chaining -- is the reference's own code)
 
 Usage:  python -m oracle.gen_golden            (from the repo root)
 """
@@ -314,11 +319,172 @@ def gen_backward(R):
         save(name + '.npz', **out)
 
 
+def load_reference_modules():
+    """The three reference files whose only missing imports are names, not arithmetic (see the module docstring)."""
+    from oracle import raft as oraft
+    sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+    for name in ('core.RAFT', 'core.RAFT.core'):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    m = types.ModuleType('core.RAFT.core.raft')
+    m.RAFT = oraft.RAFT
+    sys.modules['core.RAFT.core.raft'] = m
+    import core.unet.unet as ru
+    import core.pose.pose_net as rpn
+    import core.pose.pose_estimator as rpe
+    return dict(unet=ru, pose_net=rpn, pose_estimator=rpe)
+
+
+def _sub(t, step=4):
+    """Every ``step``-th pixel of the last two axes (keeps the fixtures small; the f64 moments cover the rest)."""
+    return t[..., ::step, ::step].contiguous()
+
+
+def _mom(t):
+    t = t.double()
+    t = torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0)
+    return torch.stack((t.sum(), t.abs().sum(), (t * t).sum()))
+
+
+def _pack(mask):
+    return np.packbits(mask.cpu().numpy().astype(bool).reshape(-1))
+
+
+def gen_modules(R):
+    """Pins oracle/unet.py, oracle/pose_net.py and oracle/tracker.py to the reference's own core/unet/unet.py:7-82,
+    core/pose/pose_net.py:60-135 and core/pose/pose_estimator.py:26-125.  Inputs and weights are regenerated from seeds
+    by the tests (oracle.synth.module_case / randomize_norms, the product package's synth.stereo_frames); the fixtures
+    hold f64 moments of the inputs (so a drifting generator is noticed) and the reference's outputs: small ones whole,
+    image-sized ones as every 4th pixel + f64 moments, masks bit-packed whole."""
+    import tempfile
+    from oracle import synth, se3 as ose3
+    from oracle import pose_net as opn
+    import rpe_amd
+    from rpe_amd import synth as psynth
+    M = load_reference_modules()
+    H, W = synth.MODULE_HW
+
+    # ---- TinyUNet: eval mode (folded running statistics) and train mode (batch statistics, n = 2)
+    out = {}
+    for cin in (264, 272):
+        x, sd = synth.unet_case(cin)
+        ref = M['unet'].TinyUNet(cin, (H, W))
+        ref.load_state_dict(sd, strict=True)
+        grabbed = {}
+        ref.head.register_forward_hook(lambda m, i, o, g=grabbed: g.__setitem__('head', o.detach().clone()))
+        for mode, xb in (('eval', x[:1]), ('train', x)):
+            ref.train(mode == 'train')
+            with torch.no_grad():
+                y = ref(xb)
+            out[f'u{cin}_{mode}_head'] = grabbed['head']
+            out[f'u{cin}_{mode}_sub'] = _sub(y)
+            out[f'u{cin}_{mode}_mom'] = _mom(y)
+            ref.load_state_dict(sd, strict=True)           # train mode moved the running statistics
+        out[f'u{cin}_x_mom'] = _mom(x)
+    save('unet.npz', **out)
+
+    # ---- PoseNet.infer / flow2depth / get_weight_maps / proj at 352x384, one frame pair, seeded weights
+    cfg, sd, a = synth.posenet_case(psynth, opn)
+    ref = M['pose_net'].PoseNet(cfg)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    out = {'in_mom': torch.stack([_mom(a[k]) for k in ('image1l', 'image2l', 'image2r', 'depth1', 'stereo_flow1')]),
+           'w_mom': _mom(torch.cat([v.reshape(-1).float() for v in sd.values()]))}
+    b = {k: v.clone() for k, v in a.items()}
+    with torch.no_grad():                                  # as its caller does (scripts/infer_trajectory.py:61)
+        pose, depth1, depth2, maps, time_flow, stereo_flow2 = ref.infer(**b, ret_details=True)
+    out.update(pose=pose.data.reshape(1, 7), mask2_after=_pack(b['mask2']),           # mutated in place, pose_net.py:77
+               depth2_sub=_sub(depth2), depth2_mom=_mom(depth2), w2d_sub=_sub(maps[0]), w2d_mom=_mom(maps[0]),
+               w3d_sub=_sub(maps[1]), w3d_mom=_mom(maps[1]), time_flow_sub=_sub(time_flow), time_flow_mom=_mom(time_flow),
+               stereo_flow2_sub=_sub(stereo_flow2), stereo_flow2_mom=_mom(stereo_flow2))
+    with torch.no_grad():
+        # the intermediates infer() does not return, from the reference's own methods on its own flow output
+        fp, hidden, context = ref.flow(torch.cat((a['image1l'], a['image2l'])), torch.cat((a['image2l'], a['image2r'])),
+                                       upsample=True)
+        pcl1 = ref.proj(a['depth1'], a['intrinsics'])
+        pcl2 = ref.proj(depth2, a['intrinsics'])
+        conf1, conf2, pcl2w, mask2w = ref.get_weight_maps(pcl1, pcl2, a['image1l'], a['image2l'], b['mask2'], fp[-1][:1],
+                                                          a['stereo_flow1'], fp[-1][1:], hidden[:1], context[:1])
+        assert torch.equal(conf1, maps[0]) and torch.equal(conf2, maps[1])
+        d, f, v = ref.flow2depth(a['image2l'], a['image2r'], a['baseline'])
+        ref.use_weights = False
+        u1, u2, _, _ = ref.get_weight_maps(pcl1, pcl2, a['image1l'], a['image2l'], b['mask2'], fp[-1][:1],
+                                           a['stereo_flow1'], fp[-1][1:], hidden[:1], context[:1])
+        ref.use_weights = True
+    out.update(pcl1_sub=_sub(pcl1), pcl1_mom=_mom(pcl1), pcl2w_sub=_sub(pcl2w), pcl2w_mom=_mom(pcl2w),
+               mask2w=_pack(mask2w), f2d_depth_sub=_sub(d), f2d_depth_mom=_mom(d), f2d_flow_mom=_mom(f), f2d_valid=_pack(v),
+               unit_w_mom=torch.stack((_mom(u1), _mom(u2))))
+    # the same solve with 20 iterations (configuration/infer_f2f.yaml:11) and without the weight heads (infer_f2f_nw.yaml:9)
+    for tag, (iters, use_w) in {'k20': (20, True), 'nw': (8, False)}.items():
+        ref.pose_head.problem.lbgfs_iters, ref.use_weights = iters, use_w
+        b = {k: v.clone() for k, v in a.items()}
+        with torch.no_grad():
+            out['pose_' + tag] = ref.infer(**b).data.reshape(1, 7)
+    save('posenet.npz', **out)
+
+    # ---- PoseEstimator (f2f), real model: three frames through the reference's own tracker
+    frames, K, bf = synth.tracker_case(psynth)
+    slam = dict(frame2frame=True, dist_thr=0.05, depth_clipping=[1, 250], debug=False, conf_weighing=True, average_pts=True,
+                lbgfs_iters=8)
+    with tempfile.TemporaryDirectory() as td:
+        ck = os.path.join(td, 'ck.pth')
+        torch.save({'config': {'model': dict(cfg)}, 'state_dict': {'module.' + k: v for k, v in sd.items()}}, ck)
+        est = M['pose_estimator'].PoseEstimator(slam, K, bf, ck, (W, H))
+    out = {'frames_mom': torch.stack([_mom(torch.cat((l, r))) for l, r, _ in frames])}
+    poses, depths, flows, masks = [], [], [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for l, r, m in frames:
+            with torch.no_grad():
+                P, scene, flow, weights = est(l.clone(), r.clone(), m.clone())
+            poses.append(P.data.reshape(7).clone())
+            depths.append(_mom(est.frame.depth))
+            flows.append(_mom(est.frame.flow))
+            masks.append(_pack(est.frame.mask))
+    out.update(abs_poses=torch.stack(poses), depth_mom=torch.stack(depths), flow_mom=torch.stack(flows),
+               masks=np.stack(masks), depth_last_sub=_sub(est.frame.depth))
+
+    # ---- PoseEstimator logic with prescribed relative poses: gate (NaN, |log| around 0.1), scale(250), chaining
+    rel = synth.gate_case()
+
+    class Scripted(torch.nn.Module):
+        """Stands in for PoseNet: hands back prescribed poses, so the reference's gate / scale / chain run on known input."""
+        def __init__(self):
+            super().__init__()
+            self.i = 0
+
+        def flow2depth(self, l, r, baseline):
+            return torch.ones_like(l[:, :1]), torch.zeros_like(l[:, :2]), torch.ones_like(l[:, :1], dtype=torch.bool)
+
+        def infer(self, *args, **kw):
+            p = ose3.SE3(rel[self.i:self.i + 1].clone())[0]
+            self.i += 1
+            one = torch.ones_like(args[0][:, :1])
+            return p, one, one, (one, one), torch.zeros_like(args[0][:, :2]), torch.zeros_like(args[0][:, :2])
+
+    est.model = Scripted()
+    est.frame = est.last_frame = None
+    est.last_pose = ose3.SE3.Identity(1)
+    tiny = torch.zeros(1, 3, 8, 8)
+    chain = []
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter('always')
+        for i in range(rel.shape[0] + 1):
+            P, *_ = est(tiny, tiny, torch.ones(1, 1, 8, 8, dtype=torch.bool))
+            chain.append(P.data.reshape(7).clone())
+    out.update(gate_rel=rel, gate_abs=torch.stack(chain), gate_warnings=np.int64(len(wl)))
+    save('tracker.npz', **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'backward':
         gen_backward(R)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'modules':
+        gen_modules(R)
         return
     gen_solver(R)
     gen_backward(R)
@@ -327,6 +493,7 @@ def main():
     gen_geometry(R)
     gen_metrics(R)
     gen_tartanair(R)
+    gen_modules(R)
 
 
 def gen_tartanair(R):

@@ -31,10 +31,14 @@ class PoseNet(nn.Module):
     @torch.no_grad()
     def flow2depth(self, imagel, imager, baseline, upsample=True):
         flow = self.flow(imagel, imager, upsample=upsample)[0][-1]
-        depth, valid = warp.flow2depth(flow, baseline)
-        if not upsample:
-            raise NotImplementedError
-        return depth, flow, valid
+        if upsample:
+            depth, valid = warp.flow2depth(flow, baseline)
+            return depth, flow, valid
+        depth = baseline[:, None, None] / -flow[:, 0]          # 1/8-resolution flow in 1/8-pixel units
+        depth = depth / 8.0                                    # "factor 8 of upsampling", pose_net.py:131-132
+        valid = (depth > 0) & (depth <= 1.0)
+        depth = torch.where(valid, depth, torch.ones_like(depth))
+        return depth.unsqueeze(1), flow, valid.unsqueeze(1)
 
     @torch.no_grad()
     def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1):

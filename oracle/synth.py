@@ -86,3 +86,73 @@ def solver_case(seed, n, h, w, sigma_t=0.005, sigma_r=0.01, noise=1e-3, unit_wei
 
 def solver_args(c):
     return (c['flow'], c['pcl1'], c['pcl2'], c['w1'], c['w2'], c['mask1'], c['mask2'], c['K'], c['loss_weight'])
+
+
+# ----------------------------------------------------------------------------- module-level cases (tests/golden/{unet,posenet,tracker}.npz)
+MODULE_HW = (352, 384)          # the smallest image the weight heads admit is 352x352 (1/8 grid 44x44, core/unet/unet.py)
+
+
+def randomize_norms(model, seed):
+    """Seeded non-trivial BatchNorm state (running mean / variance, scale, shift): freshly reset statistics (0, 1) would
+    make the frozen-BN folding of the context encoder and the weight heads invisible to a parity test."""
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                c = m.num_features
+                m.running_mean.copy_(torch.from_numpy(rng.normal(0, 0.2, c).astype(np.float32)))
+                m.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)))
+                m.weight.copy_(torch.from_numpy(rng.uniform(0.7, 1.3, c).astype(np.float32)))
+                m.bias.copy_(torch.from_numpy(rng.normal(0, 0.1, c).astype(np.float32)))
+    return model
+
+
+def unet_case(cin, seed=71):
+    """(x (2,cin,44,48) f32, state dict) of a TinyUNet(cin, MODULE_HW) with seeded weights and norm state."""
+    from .unet import TinyUNet
+    torch.manual_seed(seed + cin)
+    net = TinyUNet(cin, MODULE_HW)
+    for m in net.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            m.reset_parameters()
+    randomize_norms(net, seed + cin)
+    rng = np.random.default_rng(seed + cin + 1)
+    x = torch.from_numpy(rng.normal(0, 1, size=(2, cin, MODULE_HW[0] // 8, MODULE_HW[1] // 8)).astype(np.float32))
+    x[:, :8] *= 20.0                      # the eight geometry channels are not unit scale (disparities, 0..255 images)
+    return x, {k: v.clone() for k, v in net.state_dict().items()}
+
+
+def posenet_case(psynth, opn, seed=5):
+    """(config, state dict, PoseNet.infer arguments) for one 352x384 frame pair.  ``psynth`` = the product package's
+    synth module (the stereo renderer bench.py uses), ``opn`` = oracle.pose_net; weights = the seeded synthetic
+    initialisation + randomize_norms."""
+    H, W = MODULE_HW
+    cfg = psynth.model_config(H, W, iters=12, lbgfs_iters=8)
+    del cfg['solver'], cfg['mixed_precision']          # keys the reference's config does not have
+    om = randomize_norms(psynth.init_synthetic_weights(opn.PoseNet(cfg)), seed + 100).eval()
+    a = psynth.infer_args(psynth.stereo_frames(seed, 1, H, W))
+    return cfg, {k: v.clone() for k, v in om.state_dict().items()}, a
+
+
+def tracker_case(psynth, seed=9, n_frames=3):
+    """[(left, right, mask)] * n_frames + K (3,3) + bf (pixels * mm): consecutive stereo frames for PoseEstimator.
+    Frame i's left image is pair i's ``image1l``; right images come from the same renderer (pair i's ``image2r`` belongs to
+    ``image2l``, so the frames are taken from independent pairs' second views -- the tracker does not care)."""
+    H, W = MODULE_HW
+    s = psynth.stereo_frames(seed, n_frames, H, W)
+    frames = [(s['image2l'][i:i + 1], s['image2r'][i:i + 1], s['mask2'][i:i + 1]) for i in range(n_frames)]
+    return frames, s['K'][0], float(s['baseline'][0]) * 250.0
+
+
+def gate_case(seed=13):
+    """(m,7) f32 relative poses for the failure gate (core/pose/pose_estimator.py:81-87): ordinary ones, log components
+    just below / just above 0.1 in a translation and in a rotation entry, a NaN pose, and ordinary ones again."""
+    rng = np.random.default_rng(seed)
+    xi = np.concatenate((rng.normal(0, 0.01, size=(9, 3)), rng.normal(0, 0.02, size=(9, 3))), axis=1)
+    xi[2, 1] = 0.0999
+    xi[3, 1] = 0.1001
+    xi[4, 4] = -0.0999
+    xi[5, 4] = -0.1001
+    rel = _se3.se3_exp(torch.from_numpy(xi)).float()
+    rel[7] = float('nan')
+    return rel

@@ -3,9 +3,9 @@ image2r, mask1, mask2, stereo_flow1, ret_details)`` and ``.flow2depth(imagel, im
 reference's argument meaning (core/pose/pose_net.py:14-27,60-85,102-135) and parameter names (checkpoints load
 unchanged: ``flow.*``, ``weight_head_2d.0.*``, ``weight_head_3d.0.*``, ``loss_weight``).
 
-Per call: one batch-2n RAFT pass (HIP correlation / gates / up-sampling), one fused HIP pass for
-depth + back-projection + the four warps + both 1/8 stacks, the two TinyUNet heads on PyTorch-ROCm, and the
-device-resident SE(3) solve.  ``infer`` is generalised from the reference's hard-coded single frame
+Per call: one batch-2n RAFT pass (hand-written HIP throughout: raft.py), one fused HIP pass for depth + back-projection +
+the four warps + both 1/8 stacks, both TinyUNet heads as one HIP kernel chain (csrc/unet.hip; PyTorch-ROCm ops only when
+they train), and the device-resident SE(3) solve.  ``infer`` is generalised from the reference's hard-coded single frame
 (``flow_predictions[-1][0]`` / ``[1]``, :66-67) to n frames by splitting the RAFT batch in halves.
 """
 import torch
@@ -44,14 +44,14 @@ class PoseNet(nn.Module):
     @torch.no_grad()
     def flow2depth(self, imagel, imager, baseline, upsample=True, ret_cache=False):
         """pose_net.py:127-135 -> (depth (n,1,h,w), stereo flow (n,2,h,w), valid (n,1,h,w) bool).
+        ``upsample=False``: everything at 1/8 resolution, the flow in 1/8-pixel units and the depth divided by 8 (:131-132;
+        a division by a power of two commutes with the rounding of b / -flow.x, so the kernel is handed b / 8).
         ``ret_cache`` additionally returns the encoder outputs of ``imagel`` for reuse by the next ``infer``."""
-        if not upsample:
-            raise NotImplementedError('upsample=False is not on the inference path')
         n = imagel.shape[0]
         f = self.flow.encode_features(torch.cat((imagel, imager), dim=0))
         cn = self.flow.encode_context(imagel)
-        flow = self.flow(imagel, imager, upsample=True, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
-        depth, valid = ops.flow2depth(flow, baseline)
+        flow = self.flow(imagel, imager, upsample=upsample, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
+        depth, valid = ops.flow2depth(flow, baseline if upsample else baseline / 8.0)
         if ret_cache:
             return depth, flow, valid, dict(fmap=f[:n], cnet=cn)
         return depth, flow, valid

@@ -1,4 +1,6 @@
-"""TinyUNet weight head on the GPU: convolutions on PyTorch-ROCm (MIOpen), every epilogue a fused HIP pass.
+"""TinyUNet weight head: parameter tree + the blob ``rpe_unet_heads`` (csrc/unet.hip, the inference route PoseNet uses)
+reads; ``forward`` itself is the module-level route -- convolutions on PyTorch-ROCm, every epilogue a fused HIP pass --
+kept for training, for A/B runs (RPE_FUSED_HEADS=0) and for calling one head on its own.
 
 Host mirror of the reference's ``TinyUNet(in_channels, output_size)`` (core/unet/unet.py:80-82; architecture :7-77)
 with its parameter names (``encoder.enc_blocks.i.conv1/norm/conv2``, ``decoder.upconvs.i``, ``decoder.dec_blocks.i``,
@@ -6,8 +8,7 @@ with its parameter names (``encoder.enc_blocks.i.conv1/norm/conv2``, ``decoder.u
 the preceding conv bias, into one per-channel affine map applied by ``rpe_affine_act``:
     encoder stage : conv1 (no bias) -> [affine + ReLU]                 -> conv2            (conv-norm-relu-conv, :15-16)
     decoder stage : conv1 (no bias) -> [bias + ReLU] -> [affine]       -> conv2            (conv-relu-norm-conv, :18-20)
-The north star keeps the heads' convolutions on PyTorch-ROCm; they cost ~1 ms per 16-frame step.
-Training (gradients enabled): the same architecture on plain differentiable PyTorch-ROCm ops, batch norm in the module's
+Training (gradients enabled, or norms in train mode): the same architecture on plain differentiable PyTorch-ROCm ops, batch norm in the module's
 train/eval state -- the heads are what the reference trains (scripts/train_posenet.py:97-136)."""
 import torch
 import torch.nn as nn
@@ -79,8 +80,17 @@ class TinyUNet(nn.Module):
         self.head = nn.Conv2d(WIDTHS[0], 1, 1)
         self.out_sz = output_size
 
+    def _check_size(self, x):
+        if x.shape[-2] < 44 or x.shape[-1] < 44:
+            raise ValueError('TinyUNet needs a 1/8 grid of at least 44x44 (valid convolutions), as in the reference')
+
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        """Batch-statistics norms (module in train mode, with or without gradients -- a validation loop that forgot
+        ``.eval()`` runs batch statistics in the reference too) and anything that needs gradients take the differentiable
+        route; frozen norms without gradients take the folded inference route."""
+        self._check_size(x)
+        batch_stats = any(st.norm.training for st in list(self.encoder.enc_blocks) + list(self.decoder.dec_blocks))
+        if batch_stats or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.forward_train(x)
         with torch.no_grad():
             return self.forward_infer(x)
@@ -112,8 +122,6 @@ class TinyUNet(nn.Module):
             y = ops.affine_act(F.conv2d(x.contiguous(), st.conv1.weight), scale, shift, relu=True)
             x = F.conv2d(y, st.conv2.weight, st.conv2.bias)
             skips.append(x)
-            if x.shape[-1] < 2 or x.shape[-2] < 2:
-                raise ValueError('TinyUNet needs a 1/8 grid of at least 44x44 (valid convolutions), as in the reference')
             x = F.max_pool2d(x, 2)
         x = skips.pop()
         for upc, st in zip(self.decoder.upconvs, self.decoder.dec_blocks):

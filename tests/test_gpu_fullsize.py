@@ -3,8 +3,10 @@ seeded stereo pairs): config 2 geometry (640x512, PoseNet.infer end to end), con
 config 5 geometry (1280x1024: geometry pass, pose solve, one full infer) and config 4's collective under RCCL
 (process group of one rank on the GPU box; the two-rank logic is covered by tests/test_sharding_gloo.py).
 
-Tolerances (f32 network, different summation order only): flow <= 1e-3 px after 12 GRU iterations, pose <= 1e-5
-(north-star bar 1e-4), masks equal except where the oracle's own value sits on a decision boundary.
+Tolerances (f32 network, different summation order only): flow <= 1e-3 px after 12 GRU iterations; masks equal except
+at <= 50 pixels per batch whose decision value (stereo depth == 1, warp target == k + 0.5) the two float32 RAFT
+implementations put on different sides; end-to-end pose <= 5e-5 (north-star bar 1e-4) -- and <= 1e-6 once the oracle's
+masks are substituted into the HIP solve, which is the proof that the flipped pixels are the whole end-to-end gap.
 """
 import os
 import socket
@@ -41,8 +43,9 @@ def _check_infer(model, om, synth, h, w, n, seed):
         d = float((g[k].cpu() - o[k]).abs().max())
         print(f'{w}x{h} {k}: {d:.2e}')
         assert d < tol, k
-    assert float((g['mask2w'].cpu() != o['mask2w']).float().mean()) < 2e-3
-    assert float((g['mask2'].cpu() != o['mask2']).float().mean()) < 2e-3
+    f2, fw = int((g['mask2'].cpu() != o['mask2']).sum()), int((g['mask2w'].cpu() != o['mask2w']).sum())
+    print(f'{w}x{h} n={n}: mask2 differs at {f2}, mask2w at {fw} of {o["mask2"].numel()} pixels')
+    assert f2 <= 50 and fw <= 50
     m2 = a['mask2'].clone().cuda()
     pose = model.infer(**{k: (m2 if k == 'mask2' else v.cuda()) for k, v in a.items()})
     opose = om.infer(**{k: v.clone() for k, v in a.items()})
@@ -53,6 +56,14 @@ def _check_infer(model, om, synth, h, w, n, seed):
     # handful of pixels whose value sits on the decision boundary; measured 1.1e-5 .. 1.7e-5 at 640x512.  Bar: half the
     # north-star tolerance (1e-4 rad / 1e-4 translation-norm).
     assert d < 5e-5
+    # Proof of that attribution: the HIP solve on the HIP stages, with nothing but the oracle's warped mask substituted,
+    # lands on the oracle's pose.
+    lw = model.loss_weight.detach()[None, :].repeat(n, 1)
+    vec7, _ = model.pose_head(g['time_flow'], g['pcl1'], g['pcl2w'], g['w2d'], g['w3d'], a['mask1'].cuda(), o['mask2w'].cuda(),
+                              g['intrinsics'], lw)
+    ds = float((vec7[:, 0].cpu() - opose.reshape(n, 7)).abs().max())
+    print(f'{w}x{h} n={n}: pose diff with the oracle\'s mask2w substituted {ds:.2e}')
+    assert ds < 1e-6
     return a, o
 
 
