@@ -5,8 +5,12 @@ config 5 geometry (1280x1024: geometry pass, pose solve, one full infer) and con
 
 Tolerances (f32 network, different summation order only): flow <= 1e-3 px after 12 GRU iterations; masks equal except
 at <= 50 pixels per batch whose decision value (stereo depth == 1, warp target == k + 0.5) the two float32 RAFT
-implementations put on different sides; end-to-end pose <= 5e-5 (north-star bar 1e-4) -- and <= 1e-6 once the oracle's
-masks are substituted into the HIP solve, which is the proof that the flipped pixels are the whole end-to-end gap.
+implementations put on different sides (measured in round 3: 0 pixels at 640x512 n=2 and at 1280x1024); end-to-end pose
+<= 5e-5 (north-star bar 1e-4) -- and, per row, <= 1e-6 x max(1, |pose|) once the pixels with a differing discrete
+decision are excluded on both sides.  Round 2 attributed the 1.1e-5..1.7e-5 it measured at 640x512 to mask flips without
+testing that; the measurement says otherwise: no pixel flips, and the whole difference sits in row 1 of seed 21, whose
+8-iteration L-BFGS solve diverges on the random-init flow to a pose with |t| ~ 4 (the reference's gate rejects it) --
+the difference there is 6 float32 ulps of the output (2.9e-6 = 7e-7 relative); row 0 agrees to 1e-9.
 """
 import os
 import socket
@@ -52,18 +56,29 @@ def _check_infer(model, om, synth, h, w, n, seed):
     d = float((pose.data.cpu().reshape(-1) - opose.reshape(-1)).abs().max())
     print(f'{w}x{h} n={n}: end-to-end pose diff {d:.2e}')
     # On IDENTICAL solver inputs the HIP solve matches the oracle to 1e-8 (test_gpu_pose / test_gpu_pipeline).  End to end
-    # the flows differ by ~3e-5 px (summation order inside 40+ convolutions), which flips the discrete validity masks at a
-    # handful of pixels whose value sits on the decision boundary; measured 1.1e-5 .. 1.7e-5 at 640x512.  Bar: half the
-    # north-star tolerance (1e-4 rad / 1e-4 translation-norm).
+    # the flows differ by ~3e-5 px (summation order inside 40+ convolutions).  Bar: half the north-star tolerance
+    # (1e-4 rad / 1e-4 translation-norm); what is measured is in the module docstring.
     assert d < 5e-5
-    # Proof of that attribution: the HIP solve on the HIP stages, with nothing but the oracle's warped mask substituted,
-    # lands on the oracle's pose.
+    # Should a discrete decision ever flip (other hardware, other library versions): take every pixel at which a DISCRETE decision differs between the two runs -- the warped
+    # mask (pose_net.py:107-108) or the 2-D term's in-image test on pix + flow (pose_head.py:24) -- out of mask1 (which
+    # gates both residual terms) on BOTH sides and solve again: the poses then agree to 1e-6.
+    def in_image(flow):
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64) + 0.5, torch.arange(w, dtype=torch.float64) + 0.5, indexing='ij')
+        u, v = xs + flow[:, 0].double(), ys + flow[:, 1].double()
+        return ((u > 0) & (v > 0) & (u < w) & (v < h))[:, None]
+    differs = (g['mask2w'].cpu() != o['mask2w']) | (in_image(g['time_flow'].cpu()) != in_image(o['time_flow']))
+    m1 = a['mask1'] & ~differs
     lw = model.loss_weight.detach()[None, :].repeat(n, 1)
-    vec7, _ = model.pose_head(g['time_flow'], g['pcl1'], g['pcl2w'], g['w2d'], g['w3d'], a['mask1'].cuda(), o['mask2w'].cuda(),
-                              g['intrinsics'], lw)
-    ds = float((vec7[:, 0].cpu() - opose.reshape(n, 7)).abs().max())
-    print(f'{w}x{h} n={n}: pose diff with the oracle\'s mask2w substituted {ds:.2e}')
-    assert ds < 1e-6
+    vec7, _ = model.pose_head(g['time_flow'], g['pcl1'], g['pcl2w'], g['w2d'], g['w3d'], m1.cuda(), g['mask2w'], g['intrinsics'], lw)
+    To, _ = oph.lbfgs_solve(o['time_flow'], o['pcl1'], o['pcl2w'], o['w2d'], o['w3d'], m1, o['mask2w'], a['intrinsics'], lw.cpu(),
+                            iters=model.pose_head.problem.lbgfs_iters, coupled=False)
+    ref = oph.declarative_forward(To)[0][:, 0]
+    ds = (vec7[:, 0].cpu() - ref).abs().amax(dim=1)
+    de = (pose.data.cpu().reshape(n, 7) - opose.reshape(n, 7)).abs().amax(dim=1)
+    scale = ref.abs().amax(dim=1).clamp_min(1.0)
+    print(f'{w}x{h} n={n}: {int(differs.sum())} pixels with a differing discrete decision; per row: end-to-end diff {de.tolist()}, '
+          f'without those pixels {ds.tolist()}, max |pose component| {scale.tolist()}')
+    assert bool((ds < 1e-6 * scale).all())                    # float32 output: 1 ulp at |t| ~ 4 is 4.8e-7
     return a, o
 
 
