@@ -519,3 +519,86 @@ def test_winograd_encoder_epilogues_match_f64(rpe, c, h, w, b):
     ref3 = F.conv2d(xin, wt.double(), bias.double(), padding=1)
     got3 = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), pre_norm=m_i.cuda())
     assert (got3.cpu().double() - ref3).abs().max() < 3 * _tol(xin.float(), wt) + 1e-5
+
+
+# ------------------------------------------------------------------------------------ trained-like statistics (round 3)
+def _trained_like(rng, b, cin, cout, kh, kw, h, w, flow_channels=True):
+    """What the layers see with trained weights rather than N(0,1) test data: post-ReLU activations with a positive mean
+    (relu(N(2,1))), the two raw flow channels the motion encoder concatenates in front of the GRU at +-50 px, a hidden state
+    saturated at +-1, heavy-tailed weights (Student-t, 3 degrees of freedom) with a few 10x outliers."""
+    x = torch.from_numpy(rng.normal(2.0, 1.0, size=(b, cin, h, w)).astype(np.float32)).clamp_min(0)
+    q = cin // 4
+    x[:, :q] = torch.from_numpy(np.sign(rng.normal(size=(b, q, h, w))).astype(np.float32)) * (1 - 1e-3 * torch.rand(b, q, h, w))
+    if flow_channels:
+        smooth = F.interpolate(torch.from_numpy(rng.normal(size=(b, 2, 5, 6)).astype(np.float32)), size=(h, w), mode='bilinear', align_corners=True)
+        x[:, -2:] = 50.0 * smooth / smooth.abs().max()
+    wt = torch.from_numpy((rng.standard_t(3, size=(cout, cin, kh, kw)) * 0.02).astype(np.float32))
+    idx = rng.integers(0, wt.numel(), size=12)
+    wt.view(-1)[idx] *= 10.0
+    bias = torch.from_numpy(rng.normal(0, 0.3, size=cout).astype(np.float32))
+    return x, wt, bias
+
+
+def _errs(got, ref):
+    e = (got.cpu().double() - ref).abs()
+    return float(e.max()), float(torch.sqrt((e * e).mean()))
+
+
+@pytest.mark.parametrize('kind,cin,cout,h,w', [('3x3', 256, 192, 64, 80), ('3x3', 128, 256, 64, 80), ('3x3', 64, 64, 128, 160),
+                                               ('1x5', 256, 256, 64, 80), ('5x1', 256, 128, 64, 80), ('1x5', 256, 128, 44, 48)])
+@pytest.mark.parametrize('flow_channels', [False, True])
+def test_winograd_error_relative_to_direct_on_trained_like_statistics(rpe, kind, cin, cout, h, w, flow_channels):
+    """F(2x2,3x3) and F(4,5) are exact in real arithmetic but their transforms (constants up to 5.25) cost float32 bits that
+    depend on the data's statistics; zero-mean Gaussian test data is the friendliest case.  Here: trained-like statistics,
+    error of each Winograd kernel against the f64 convolution RELATIVE TO THE DIRECT f32 KERNEL'S OWN ERROR on the same data
+    (rpe_conv_fused: a plain f32 fma chain).  Bars: RMS ratio <= 3, max ratio <= 4."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout * 7 + h + 3 * len(kind) + ord(kind[0]) + int(flow_channels))
+    kh, kw = {'3x3': (3, 3), '1x5': (1, 5), '5x1': (5, 1)}[kind]
+    b = 2
+    x, wt, bias = _trained_like(rng, b, cin, cout, kh, kw, h, w, flow_channels)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=(kh // 2, kw // 2))
+    direct = ops.conv_fused(x.cuda(), ops.PackedConv(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    if kind == '3x3':
+        wino = ops.conv_wino(x.cuda(), ops.PackedWino(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    else:
+        wino = ops.conv_wino1d(x.cuda(), ops.PackedWino1d(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    dmax, drms = _errs(direct, ref)
+    wmax, wrms = _errs(wino, ref)
+    print(f'{kind} {cin}->{cout} flow_channels={flow_channels}: |out| {float(ref.abs().max()):.1f}; direct max {dmax:.2e} rms {drms:.2e}; '
+          f'winograd max {wmax:.2e} rms {wrms:.2e}; ratios {wmax / dmax:.2f} / {wrms / drms:.2f}')
+    assert wrms <= 3.0 * drms and wmax <= 4.0 * dmax
+
+
+@pytest.mark.parametrize('impl', ['direct', 'winograd'])
+def test_gru_gates_on_saturated_state_and_large_flow(rpe, impl):
+    """One SepConvGRU half on trained-like inputs: hidden state at +-1, the flow channels at +-50, pre-activations spread
+    over +-30 (so sigmoid / tanh run into both saturated ends on the hardware exp/rcp path).  Bar: absolute 2e-6 on the gate
+    (a saturated sigmoid must be 0 or 1 to rounding, not NaN / denormal garbage) and the f64 blend to the conv tolerance."""
+    from rpe_amd import ops
+    Packed, conv = (ops.PackedConv, ops.conv_fused) if impl == 'direct' else (ops.PackedWino1d, ops.conv_wino1d)
+    c, b, h, w = 128, 2, 64, 80
+    rng = np.random.default_rng(77)
+    hx, wzr, bzr = _trained_like(rng, b, 2 * c, 2 * c, 1, 5, h, w)
+    hx[:, :c] = torch.sign(hx[:, :c] - 1.0) * (1 - 1e-4 * torch.rand(b, c, h, w))          # saturated hidden state
+    _, wq, bq = _trained_like(rng, b, 2 * c, c, 1, 5, h, w)
+    azr = torch.from_numpy(rng.normal(0, 10.0, size=(b, 2 * c, h, w)).astype(np.float32))   # context terms push the gates to both ends
+    aq = torch.from_numpy(rng.normal(0, 10.0, size=(b, c, h, w)).astype(np.float32))
+    hid = hx[:, :c].double()
+    pre = _ref_conv(hx, wzr, bzr, azr)
+    zr = torch.sigmoid(pre)
+    z, r = zr[:, :c], zr[:, c:]
+    g_hx, g_rhx = hx.cuda(), hx.cuda().clone()
+    g_z = torch.empty(b, c, h, w, device='cuda')
+    conv(g_hx, Packed(wzr.cuda(), bzr.cuda()), ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
+    assert bool(torch.isfinite(g_z).all()) and float(g_z.min()) >= 0.0 and float(g_z.max()) <= 1.0
+    # sigmoid' <= 1/4: the gate error is a quarter of the pre-activation error + the exp/rcp path's 3e-7
+    tpre = _tol(hx, wzr) * (2 if impl == 'winograd' else 1)
+    assert float((g_z.cpu().double() - z).abs().max()) < 0.25 * tpre + 2e-6
+    assert float(pre.abs().max()) > 25 and float((z < 1e-9).float().mean()) > 0.001 and float((z > 1 - 1e-9).float().mean()) > 0.001
+    rh = g_rhx[:, :c].cpu()
+    q = torch.tanh(_ref_conv(torch.cat((rh, hx[:, c:]), 1), wq, bq, aq))
+    conv(g_rhx, Packed(wq.cuda(), bq.cuda()), ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)
+    hnew = (1 - g_z.cpu().double()) * hid + g_z.cpu().double() * q
+    assert bool(torch.isfinite(g_hx).all()) and float(g_hx[:, :c].abs().max()) <= 1.0 + 1e-6
+    assert float((g_hx[:, :c].cpu().double() - hnew).abs().max()) < _tol(hx, wq) * (2 if impl == 'winograd' else 1) + 4e-6

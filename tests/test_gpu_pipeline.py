@@ -210,3 +210,48 @@ def test_streaming_feature_reuse_is_exact(models):
             poses.append(P.data.reshape(7).cpu())
         out[reuse] = torch.stack(poses)
     assert float((out[True] - out[False]).abs().max()) < 1e-4          # mm scale after x250
+
+
+def test_raft_with_large_activations_matches_oracle(rpe):
+    """Trained networks do not keep activations at the O(1) of a fresh initialisation.  Here the motion encoder's, the GRU's and
+    the flow head's weights are scaled up and the context encoder's output layer x60, so the update block's activations reach
+    1e2..1e3, the gates saturate and the flow grows over the iterations -- the regime that stresses the Winograd transforms and
+    the hardware exp/rcp gates.  Bar: the flow of every iteration within 2e-5 of the largest update-block activation (relative
+    f32 accuracy of a 256-term sum) and within 1e-3 of the flow's own magnitude."""
+    from rpe_amd import pose_net, synth
+    cfg = synth.model_config(H, W, iters=12, lbgfs_iters=8)
+    model = synth.init_synthetic_weights(pose_net.PoseNet(cfg)).eval()
+    with torch.no_grad():
+        ub = model.flow.update_block
+        for m in (ub.encoder.convc1, ub.encoder.convc2, ub.encoder.convf1, ub.encoder.convf2, ub.encoder.conv):
+            m.weight.mul_(5.0)
+        for m in (ub.gru.convz1, ub.gru.convr1, ub.gru.convq1, ub.gru.convz2, ub.gru.convr2, ub.gru.convq2, ub.flow_head.conv1):
+            m.weight.mul_(2.0)
+        model.flow.cnet.conv2.weight.mul_(60.0)
+        model.flow.cnet.conv2.bias.mul_(60.0)
+    om = opn.PoseNet(cfg)
+    om.load_state_dict(model.state_dict())
+    om.eval()
+    model = model.cuda()
+    peak = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, k=k: peak.__setitem__(k, max(peak.get(k, 0.0), float(o.abs().max()))))
+             for k, m in (('convc1', om.flow.update_block.encoder.convc1), ('convc2', om.flow.update_block.encoder.convc2),
+                          ('conv', om.flow.update_block.encoder.conv), ('fh1', om.flow.update_block.flow_head.conv1),
+                          ('cnet', om.flow.cnet.conv2))]
+    fr = synth.stereo_frames(3, 1, H, W)
+    i1 = torch.cat((fr['image1l'], fr['image2l']))
+    i2 = torch.cat((fr['image2l'], fr['image2r']))
+    flows, hid, ctx = model.flow(i1.cuda(), i2.cuda(), all_flows=True)
+    with torch.no_grad():
+        oflows, ohid, octx = om.flow(i1, i2)
+    for h_ in hooks:
+        h_.remove()
+    act = max(peak.values())
+    print('peak activations', {k: round(v, 1) for k, v in peak.items()})
+    assert act > 100.0
+    for it in (0, 3, 11):
+        d = float((flows[it].cpu() - oflows[it]).abs().max())
+        mag = float(oflows[it].abs().max())
+        print(f'iteration {it}: flow diff {d:.2e} px, |flow| up to {mag:.1f} px')
+        assert d < max(2e-5 * act, 1e-3 * mag)
+    assert float((hid.cpu() - ohid).abs().max()) < 5e-3 and bool(torch.isfinite(hid).all())
