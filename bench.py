@@ -241,7 +241,10 @@ def run_batch(args, rank, world, dev, dist):
     real_lookup = rpe_amd.ops.CorrPyramid.lookup
     timing = {'on': False}
 
+    last_lookup = {}
+
     def timed_lookup(self, coords, out=None):
+        last_lookup['pyr'], last_lookup['coords'], last_lookup['out'] = self, coords, out
         if not timing['on']:
             return real_lookup(self, coords, out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -364,13 +367,14 @@ def run_batch(args, rank, world, dev, dist):
     lk_avg_s = sum(lk_ms) / max(1, len(lk_ms)) / 1e3
     alg = lookup_algorithmic_bytes(2 * B, H // 8, W // 8)
     achieved = alg / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
-    traffic = None                              # HBM bytes per launch from separate rocprofv3 --pmc passes
-    try:                                        # (profiles/pmc_traffic.json), valid for the default workload only
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['k_corr_lookup']
+    traffic = traffic_src = None                # HBM bytes per launch from separate rocprofv3 --pmc passes over THIS program
+    try:                                        # (tools/pmc_bench.sh -> profiles/pmc_traffic.json), valid for the default workload only
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))['k_corr_lookup_bench']
         if (B, H, W) == (16, 512, 640):
-            traffic = pmc['traffic_bytes_per_launch']
+            traffic, traffic_src = pmc['traffic_bytes_per_launch'], pmc['source']
     except (OSError, KeyError, ValueError):
         pass
+    rounds_own = lookup_rounds(last_lookup['pyr'], last_lookup['coords'])      # roughness of the coordinates this run looked up last
     res = {
         'metric': 'stereo-pair pose solves/sec (640x512, 8 solver iters)',
         'value': world * B * args.steps / elapsed,
@@ -386,7 +390,8 @@ def run_batch(args, rank, world, dev, dist):
                    'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
         'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
-                     'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms)},
+                     'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms), 'traffic_source': traffic_src,
+                     'coordinates': 'the final GRU iteration of this run (random-init RAFT: near-uniform drift)', **rounds_own},
         'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),
         'roofline_conv': conv_roofline(conv_events, args.steps),
         'roofline_conv_winograd_1d': wino_roofline(wino1d_events, args.steps, 'k_conv_wino1d'),
@@ -396,10 +401,50 @@ def run_batch(args, rank, world, dev, dist):
         'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
     }
     if world == 1 and not args.no_extras:             # deployment numbers, measured after the timed region on rank 0
+        res['roofline_lookup_realistic'] = lookup_realistic(last_lookup['pyr'], last_lookup['out'], B, H, W, dev)
         res.update(deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_events, timing))
     if args.cpu_frames > 0 and world == 1:            # CPU baseline on rank 0 at N = 1 only
         res['cpu_baseline'] = cpu_baseline(cfg, model, frames, args.cpu_frames, pose)
     return res
+
+
+def lookup_rounds(pyr, coords):
+    """Roughness of a set of lookup coordinates as the kernel sees it (rpe_corr_lookup_rounds, the kernel's own round rule):
+    mean staging rounds per (level, group of 8 queries) -- 1.0 = every group's windows fit one box -- the fraction of groups that
+    need more than one round, and the 128-B lines the loader requests relative to the single-round minimum of smooth flow."""
+    rounds, lines = pyr.rounds(coords)
+    r = rounds.float()
+    return {'mean_rounds_per_group': float(r.mean()), 'multi_round_group_fraction': float((r > 1).float().mean()),
+            'max_rounds': int(r.max()), 'loader_lines_requested': int(lines.sum())}
+
+
+def lookup_realistic(pyr, out, B, H, W, dev):
+    """The lookup kernel on coordinates a TRAINED network would produce: the ground-truth temporal flow (first B pairs) and stereo
+    flow (last B pairs: disparities 8..60 px with depth edges) of seeded synthetic scenes with foreground occluders
+    (synth.ground_truth_flows), sampled at the 1/8 grid's cell centres.  Same pyramid, same launch geometry, HIP events over 30 launches."""
+    from rpe_amd import synth
+    tf, sf = synth.ground_truth_flows(seed=777, n=B, h=H, w=W)
+    flow8 = torch.cat((tf, sf))[:, :, 4::8, 4::8].contiguous() / 8.0
+    h8, w8 = H // 8, W // 8
+    ys, xs = torch.meshgrid(torch.arange(h8, dtype=torch.float32), torch.arange(w8, dtype=torch.float32), indexing='ij')
+    coords = (torch.stack((xs, ys))[None] + flow8).contiguous().to(dev)
+    for _ in range(3):
+        pyr.lookup(coords, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 30
+    e0.record()
+    for _ in range(reps):
+        pyr.lookup(coords, out)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps / 1e3
+    alg = lookup_algorithmic_bytes(2 * B, h8, w8)
+    d = flow8[B:, 0]
+    return {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': alg / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': alg / t / 1e9 / HBM_PEAK_GBS, 'avg_launch_us': t * 1e6, 'algorithmic_bytes_per_launch': alg,
+            'coordinates': f'ground-truth flow of synthetic scenes with 3 occluders per frame: {B} temporal + {B} stereo pairs, '
+                           f'disparity {float(-d.max()) * 8:.0f}..{float(-d.min()) * 8:.0f} px',
+            **lookup_rounds(pyr, coords)}
 
 
 def deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_events, timing):

@@ -182,6 +182,12 @@ int rpe_corr_lookup(const void *pyramid, const float *coords, int b, int h8, int
  * y0[..,j,q] with y offset j-r) -- the very indices rpe_corr_lookup reads.  -1000000 marks a non-finite tap. */
 int rpe_corr_lookup_taps(const float *coords, int b, int h8, int w8, int levels, int32_t *x0, int32_t *y0,
                          void *stream);
+/* Diagnostic for the roofline claim of rpe_corr_lookup (bench.py): for these coordinates, per (batch item, level, group of 8
+ * x-neighbouring queries) the number of staging rounds the lookup takes (1 = the group's eight windows fit one 12 x 16 box:
+ * smooth flow) and the 128-B pyramid lines its loader requests.  rounds, lines: (b, levels, h8 * ceil(w8/8)) int32.  Same
+ * tap / round arithmetic as the lookup kernel (shared device code), no pyramid access. */
+int rpe_corr_lookup_rounds(const float *coords, int b, int h8, int w8, int levels, int32_t *rounds, int32_t *lines,
+                           void *stream);
 /* Copy one level of the pyramid out as a dense (b*h8*w8, h8>>l, w8>>l) f32 tensor (tests only). */
 int rpe_corr_export_level(const void *pyramid, int b, int h8, int w8, int levels, int level, float *dense,
                           void *stream);

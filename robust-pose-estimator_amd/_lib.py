@@ -55,6 +55,7 @@ SIGNATURES = {
     'rpe_corr_build_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup_taps': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'rpe_corr_lookup_rounds': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_corr_export_level': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_gru_gates_zr': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'rpe_gru_gates_h': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -502,6 +502,24 @@ __device__ __forceinline__ void lookup_pass(const LkCtx& C, const TapAxis& X, co
     }
 }
 
+// The round rule (shared by k_corr_lookup and the k_corr_rounds diagnostic): per group the staging box is anchored at the topmost
+// pending window row and, among the lanes within one row of it, the leftmost window column; a lane is served in this round when
+// its 11 x 11 window fits the 12 x 16 box.
+struct LkRound { int gx0, gy0, xoff, yoff, nslots, nrows; bool fits; };
+__device__ __forceinline__ LkRound plan_round(bool pending, int ylo, int sx, int needw, int needh) {
+    const int big = 0x3fffffff;
+    LkRound R;
+    const int gy0m = group_min(pending ? ylo : big);
+    const bool near_top = pending && ylo - gy0m <= 1;
+    const int gx0m = group_min(near_top ? sx : big);
+    const bool gany = gx0m != big;
+    R.gx0 = gany ? gx0m : 0; R.gy0 = gany ? gy0m : 0;
+    R.xoff = sx - R.gx0; R.yoff = ylo - R.gy0;
+    R.fits = near_top && R.xoff >= 0 && R.xoff + WIN + 2 <= LK_BOXW;
+    R.nslots = group_max(R.fits ? R.xoff + needw : 0); R.nrows = group_max(R.fits ? R.yoff + needh : 0);   // what the loader fetches
+    return R;
+}
+
 // One workgroup = 4 independent waves; a wave = 8 consecutive groups (64 queries) of one (batch item, level).
 __global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                                       float* __restrict__ out, PyrGeom G) {
@@ -560,14 +578,9 @@ __global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const fl
     bool pending = !empty;
     bool first = true;
     for (;;) {
-        const int gy0m = group_min(pending ? Y.lo : big);
-        const bool near_top = pending && Y.lo - gy0m <= 1;
-        const int gx0m = group_min(near_top ? sx : big);
-        const bool gany = gx0m != big;
-        const int gx0 = gany ? gx0m : 0, gy0 = gany ? gy0m : 0;
-        const int xoff_ = sx - gx0, yoff_ = Y.lo - gy0;
-        const bool fits = near_top && xoff_ >= 0 && xoff_ + WIN + 2 <= LK_BOXW;
-        const int nslots = group_max(fits ? xoff_ + needw : 0), nrows = group_max(fits ? yoff_ + needh : 0);   // what the loader fetches
+        const LkRound R = plan_round(pending, Y.lo, sx, needw, needh);
+        const int gx0 = R.gx0, gy0 = R.gy0, xoff_ = R.xoff, yoff_ = R.yoff, nslots = R.nslots, nrows = R.nrows;
+        const bool fits = R.fits;
         // box rows / slots that exist in the map and are needed, as bit masks (empty when nothing fits)
         int r_lo = -gy0 > 0 ? -gy0 : 0, r_hi = hl - gy0 < nrows ? hl - gy0 : nrows;
         int x_lo = -gx0 > 0 ? -gx0 : 0, x_hi = wp - gx0 < nslots ? wp - gx0 : nslots;
@@ -615,6 +628,49 @@ __global__ void k_corr_taps(const float* __restrict__ coords, int32_t* x0, int32
         size_t o = (((size_t)bz * G.levels + l) * WIN + i) * nq + q;
         x0[o] = ((X.bad >> i) & 1u) ? -1000000 : X.lo + i + (int)((X.dev >> i) & 1u);
         y0[o] = ((Y.bad >> i) & 1u) ? -1000000 : Y.lo + i + (int)((Y.dev >> i) & 1u);
+    }
+}
+
+// Diagnostic: how many rounds k_corr_lookup takes per (batch item, level, group) for these coordinates, and how many 128-B lines
+// its loader requests -- the same make_taps / plan_round / mask arithmetic, no loads.  rounds[(b*levels + l)*ngroups + g], lines likewise.
+__global__ void k_corr_rounds(const float* __restrict__ coords, int32_t* __restrict__ rounds, int32_t* __restrict__ lines, PyrGeom G) {
+    const int l = blockIdx.y, bz = blockIdx.z;
+    const int nq = G.h8 * G.w8;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave_g0 = (blockIdx.x * (blockDim.x >> 6) + wv) * 8;
+    if (wave_g0 >= G.ngroups) return;
+    const int grp = lane >> 3, k = lane & 7;
+    const int Gi = wave_g0 + grp;
+    const int qy = Gi / G.gx, qx = (Gi % G.gx) * GQ + k;
+    const bool qok = Gi < G.ngroups && qx < G.w8;
+    const int q = qok ? qy * G.w8 + qx : 0;
+    const int hl = G.h[l], wl = G.w[l], wp = G.wp[l], sk = G.sk[l];
+    const float inv = 1.0f / (float)(1 << l);
+    TapAxis X, Y;
+    make_taps(coords[((size_t)bz * 2 + 0) * nq + q] * inv, wl, X);
+    make_taps(coords[((size_t)bz * 2 + 1) * nq + q] * inv, hl, Y);
+    const int needw = WIN + 1 + (X.dev ? 1 : 0), needh = WIN + 1 + (Y.dev ? 1 : 0);
+    const bool empty = !qok || X.lo + WIN + 1 < 0 || X.lo >= wl || Y.lo + WIN + 1 < 0 || Y.lo >= hl;
+    const int sx = X.lo + sk - (k >> l);
+    bool pending = !empty;
+    int nr = 0, nl = 0;
+    for (;;) {
+        const LkRound R = plan_round(pending, Y.lo, sx, needw, needh);
+        int r_lo = -R.gy0 > 0 ? -R.gy0 : 0, r_hi = hl - R.gy0 < R.nrows ? hl - R.gy0 : R.nrows;
+        int x_lo = -R.gx0 > 0 ? -R.gx0 : 0, x_hi = wp - R.gx0 < R.nslots ? wp - R.gx0 : R.nslots;
+        r_lo = r_lo > 16 ? 16 : r_lo; x_lo = x_lo > 16 ? 16 : x_lo;
+        r_hi = r_hi < r_lo ? r_lo : r_hi; x_hi = x_hi < x_lo ? x_lo : x_hi;
+        r_hi = r_hi > 12 ? 12 : r_hi;
+        // 128-B lines = 4 slots: count the distinct lines the [x_lo, x_hi) slot run of each fetched row touches
+        const int s0 = R.gx0 + x_lo, s1 = R.gx0 + x_hi;
+        const int lines_row = x_hi > x_lo ? ((s1 + 3) >> 2) - (s0 >> 2) : 0;
+        if (group_max(R.fits ? 1 : 0)) { nr += 1; nl += lines_row * (r_hi - r_lo); }
+        pending = pending && !R.fits;
+        if (!__any(pending)) break;
+    }
+    if (k == 0 && Gi < G.ngroups) {
+        const size_t o = ((size_t)bz * G.levels + l) * G.ngroups + Gi;
+        rounds[o] = nr; lines[o] = nl;
     }
 }
 
@@ -679,6 +735,15 @@ extern "C" int rpe_corr_lookup_taps(const float* coords, int b, int h8, int w8, 
     if (!coords || !x0 || !y0 || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
     const int nq = h8 * w8;
     hipLaunchKernelGGL(k_corr_taps, dim3(ceil_div(nq, 256), levels, b), dim3(256), 0, (hipStream_t)stream, coords, x0, y0, G);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_corr_lookup_rounds(const float* coords, int b, int h8, int w8, int levels, int32_t* rounds, int32_t* lines,
+                                      void* stream) {
+    PyrGeom G;
+    if (!coords || !rounds || !lines || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
+    hipLaunchKernelGGL(k_corr_rounds, dim3(ceil_div(G.ngroups, 8 * LK_WAVES), levels, b), dim3(64 * LK_WAVES), 0, (hipStream_t)stream,
+                       coords, rounds, lines, G);
     return rpe_check_launch();
 }
 

@@ -249,6 +249,16 @@ class CorrPyramid:
               'rpe_corr_lookup_taps')
         return x0, y0
 
+    def rounds(self, coords):
+        """Diagnostic (rpe_corr_lookup_rounds): staging rounds and requested 128-B lines per (batch item, level, group)."""
+        co = _dev(coords, torch.float32, 'coords')
+        ng = self.h8 * ((self.w8 + 7) // 8)
+        rounds = torch.zeros(self.b, self.levels, ng, dtype=torch.int32, device=co.device)
+        lines = torch.zeros_like(rounds)
+        check(lib().rpe_corr_lookup_rounds(ptr(co), self.b, self.h8, self.w8, self.levels, ptr(rounds), ptr(lines), stream_ptr()),
+              'rpe_corr_lookup_rounds')
+        return rounds, lines
+
     def export_level(self, level):
         h, w = self.h8 >> level, self.w8 >> level
         dense = torch.empty(self.b * self.h8 * self.w8, h, w, dtype=torch.float32, device=self.buf.device)

@@ -63,6 +63,34 @@ def stereo_frames(seed, n, h, w, bf=7.2):
     return res
 
 
+def ground_truth_flows(seed, n, h, w, bf=7.2, occluders=3):
+    """What a TRAINED flow network converges to on a scene with depth edges (the lookup's realistic-coordinates roofline line in
+    bench.py): a smooth background at normalised depth 0.45..0.9 with ``occluders`` foreground ellipses at depth 0.12..0.3, so
+    the stereo disparities span 8..60 px with discontinuities, and the rigid temporal flow of a gate-sized camera motion
+    (same distribution as stereo_frames).  Returns (time_flow, stereo_flow), each (n,2,h,w) f32 in pixels."""
+    rng = np.random.default_rng(seed)
+    K = intrinsics(h, w)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5, indexing='ij')
+    tf, sf = [], []
+    for _ in range(n):
+        depth = 0.45 + 0.45 * _smooth(rng, 1, h, w, 5)[0]
+        for _ in range(occluders):
+            cx, cy = rng.uniform(0.15, 0.85) * w, rng.uniform(0.15, 0.85) * h
+            ax, ay = rng.uniform(0.05, 0.2) * w, rng.uniform(0.05, 0.25) * h
+            inside = ((xs - cx) / ax) ** 2 + ((ys - cy) / ay) ** 2 < 1.0
+            depth = torch.where(inside, torch.full_like(depth, float(rng.uniform(0.12, 0.3))) + 0.02 * (xs - cx) / ax, depth)
+        xi = np.concatenate((rng.normal(0, 0.005, 3), rng.normal(0, 0.01, 3))).astype(np.float32)
+        X = torch.stack(((xs - K[0, 2]) / K[0, 0] * depth, (ys - K[1, 2]) / K[1, 1] * depth, depth))
+        tau, phi = torch.from_numpy(xi[:3]), torch.from_numpy(xi[3:])
+        Xp = X + torch.cross(phi[:, None, None].expand_as(X), X, dim=0) + tau[:, None, None]
+        u = K[0, 0] * Xp[0] / Xp[2] + K[0, 2]
+        v = K[1, 1] * Xp[1] / Xp[2] + K[1, 2]
+        tf.append(torch.stack((u - xs, v - ys)))
+        disp = bf / depth
+        sf.append(torch.stack((-disp, torch.zeros_like(disp))))
+    return torch.stack(tf).contiguous(), torch.stack(sf).contiguous()
+
+
 def infer_args(s):
     return dict(image1l=s['image1l'], image2l=s['image2l'], intrinsics=s['K'], baseline=s['baseline'], depth1=s['depth1'],
                 image2r=s['image2r'], mask1=s['mask1'], mask2=s['mask2'], stereo_flow1=s['stereo_flow1'])
