@@ -224,12 +224,24 @@ int rpe_instnorm_act(const float *x, const float *bias, int b, int c, int hw, fl
                      const float *residual, float *out, void *stream);
 int rpe_affine_act(const float *x, const float *scale, const float *shift, int b, int c, int hw, int relu,
                    const float *residual, float *out, void *stream);
+/* dst[:, 0:c] = src[:, 0:c] for channel slices of NCHW buffers (pointer to the slice's first plane in batch item 0 + batch stride
+ * in floats): the slice assignments / clones around RAFT's update loop (core/RAFT/core/raft.py: net = tanh(net), coords1 = coords0
+ * .clone(), the returned hidden state) without a library copy kernel. */
+int rpe_copy_planes(const float *src, long long src_batch_stride, float *dst, long long dst_batch_stride, int b, int c, int hw,
+                    void *stream);
 /* FlowHead.conv2 (core/RAFT/core/update.py) + the coordinate update of RAFT.forward (core/RAFT/core/raft.py):
  * out (b,2,h,w) = conv3x3(x (b,c,h,w), weight (2,c,3,3), padding 1) + bias (2) [+ add (b,2,h,w), may be NULL = plain
  * convolution; pass coords1 to get coords1 + delta_flow].  out may alias add.  Two output channels make this a
  * streaming problem, not a GEMM. */
 int rpe_conv3x3_to2(const float *x, const float *weight, const float *bias, int b, int c, int h, int w,
                     const float *add, float *out, void *stream);
+/* The same with the flow bookkeeping of RAFT.forward's loop (core/RAFT/core/raft.py: coords1 = coords1 + delta_flow;
+ * flow = coords1 - coords0 with coords0 the integer pixel grid; the motion encoder concatenates flow behind its output) fused in:
+ * coords_out = conv + bias + coords, and flow = coords_out - grid is written to flow_out (b,2,h,w) and to the two-plane channel
+ * slices dst1 / dst2 (pointer to the first plane in batch item 0 + batch stride in floats; any of the three may be NULL). */
+int rpe_conv3x3_to2_flow(const float *x, const float *weight, const float *bias, int b, int c, int h, int w,
+                         const float *coords, float *coords_out, float *flow_out, float *dst1, long long dst1_batch_stride,
+                         float *dst2, long long dst2_batch_stride, void *stream);
 /* flow (b,2,h8,w8), mask (b,576,h8,w8) raw logits already scaled by .25 -> out (b,2,8*h8,8*w8). */
 int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int w8, float *out, void *stream);
 
@@ -241,6 +253,7 @@ int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int
  * buffer it lives in, so inputs and outputs can be slices of the concatenated (h | motion | flow) buffers.
  *   v = conv(x)[co][p] * scale[co] + add[co][p] + bias[co]           (scale, add, bias: each may be NULL)
  *   RPE_CONV_LINEAR : y = v;  RPE_CONV_RELU : y = max(v, 0);  then, if residual != NULL, y = max(residual + y, 0)
+ *   RPE_CONV_TANH   : y = tanh(v)   (rpe_conv_fused, plain epilogue only: no scale / residual / stats / stride 2)
  *                     (the encoder's ResidualBlock tail, core/RAFT/core/extractor.py); out = y (and out2 = y when
  *                     out2 != NULL).  If stats != NULL the kernel also writes per-tile moments of v,
  *                     stats[b][cout][rpe_conv_stats_tiles(cout,h,w,stride)][3] = (count, mean, sum of squared deviations
@@ -253,6 +266,7 @@ int rpe_upsample_convex(const float *flow, const float *mask, int b, int h8, int
 #define RPE_CONV_RELU 1
 #define RPE_CONV_GATE_ZR 2
 #define RPE_CONV_GATE_H 3
+#define RPE_CONV_TANH 4     /* y = tanh(v): the hidden-state half of the context encoder's output (core/RAFT/core/raft.py: net = tanh(net)) */
 typedef struct rpe_conv_desc {
     const float *x;      long long x_batch_stride;      /* input slice (b, cin, h, w)                              */
     const float *packed;                                 /* weights from rpe_conv_pack                              */

@@ -63,6 +63,8 @@ SIGNATURES = {
     'rpe_instnorm_act': (_i, [_vp, _vp, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
     'rpe_affine_act': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_conv3x3_to2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'rpe_conv3x3_to2_flow': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp]),
+    'rpe_copy_planes': (_i, [_vp, _ll, _vp, _ll, _i, _i, _i, _vp]),
     'rpe_upsample_convex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'rpe_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
     'rpe_conv_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
                             if (ok[r]) outb0[e[r]] = (1.0f - xv[r]) * yv[r] + xv[r] * tanh_f(v);
                         } else {
                             if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;    // NaN stays NaN, like torch.relu
+                            else if (mode == RPE_CONV_TANH) v = tanh_f(v);
                             if (ok[r]) { outb0[e[r]] = v; if (out2b0) out2b0[e[r]] = v; }
                         }
                     }
@@ -590,7 +591,9 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     if (!d || !d->x || !d->packed || !d->out || d->b <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return RPE_E_BADARG;
     if (d->kh < 1 || !(d->kh & 1) || (d->kw != 1 && d->kw != 3 && d->kw != 5)) return RPE_E_UNSUPPORTED;
     if ((d->w & 3) || !al16(d->x) || (d->x_batch_stride & 3)) return RPE_E_UNSUPPORTED;     // 16-B input loads
-    if (d->mode < RPE_CONV_LINEAR || d->mode > RPE_CONV_GATE_H) return RPE_E_BADARG;
+    if (d->mode < RPE_CONV_LINEAR || d->mode > RPE_CONV_TANH) return RPE_E_BADARG;
+    if (d->mode == RPE_CONV_TANH && (d->scale || d->residual || d->stats || d->pre_norm || (d->stride != 0 && d->stride != 1) ||
+                                     ((d->cout % 64) != 0 && (d->cout % 64) <= 32 && d->kw == 3))) return RPE_E_UNSUPPORTED;   // plain epilogue only
     if (d->mode == RPE_CONV_GATE_ZR && (!d->out2 || !d->hidden || d->gate_channels <= 0 || d->cout != 2 * d->gate_channels)) return RPE_E_BADARG;
     if (d->mode == RPE_CONV_GATE_H && (!d->hidden || !d->zgate)) return RPE_E_BADARG;
     if ((d->mode == RPE_CONV_GATE_ZR || d->mode == RPE_CONV_GATE_H) && (d->scale || d->residual || d->stats)) return RPE_E_BADARG;

@@ -21,6 +21,7 @@
 // channel | tile) row are contiguous, so a lane's fragments for four positions are one 16-B LDS read.
 #include "wino_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 #define WB_CO 64
 #define WB_TX 8
@@ -568,6 +569,14 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
         else WINO_LAUNCH(3, false);
 #undef WINO_LAUNCH
     };
+    // Small launches (sequential tracking: batch 1-2) would leave every CU with at most one workgroup = one wave per SIMD, whose
+    // K loop is a chain of DMA latencies: 32-channel tiles double the workgroups (two per CU hide each other's stalls).  At full
+    // occupancy the 64-channel tile is 15-17 % faster (one weight fragment feeds two matrix instructions), so only below the threshold.
+    static const long long small_wg = [] { const char* e = getenv("RPE_WINO_SMALL_WG"); return e ? atoll(e) : 512LL; }();
+    if ((long long)gx * ceil_div(d->cout, WB_CO) * d->b < small_wg) {
+        launch(std::integral_constant<int, 1>{}, dim3(gx, ceil_div(d->cout, 32), d->b));
+        return rpe_check_launch();
+    }
     if (n64 > 0) launch(std::integral_constant<int, 2>{}, dim3(gx, n64, d->b));
     if (tail32) {
         P.co_base = n64 * WB_CO;

@@ -559,7 +559,6 @@ __global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const fl
         for (int i = 0; i < WIN; ++i) { Y.a0[i] = 0.0f; Y.a1[i] = 0.0f; Y.a2[i] = 0.0f; }
     }
     const int sx = X.lo + sk - (k >> l);                              // window start in skewed columns
-    const int big = 0x3fffffff;
 
     LkCtx C;
     C.row_bytes = (unsigned)wp * GQ * 4; C.nq4 = (unsigned)nq * 4;

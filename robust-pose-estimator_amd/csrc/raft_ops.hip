@@ -90,6 +90,19 @@ __global__ __launch_bounds__(256) void k_bias_act(const float* x, const float* _
     }
 }
 
+// Channel-slice copy: c planes per batch item from a slice of one NCHW buffer to a slice of another (the copies torch's
+// ``out[:, a:b] = x[:, c:d]`` / ``.clone()`` would launch around the update block: initial hidden state, returned hidden state,
+// coords1 = coords0).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_copy_planes(const float* __restrict__ src, long long sbs, float* __restrict__ dst, long long dbs, size_t per) {
+    const int bz = blockIdx.y;
+    const float* sp = src + (size_t)bz * sbs;
+    float* dp = dst + (size_t)bz * dbs;
+    for (size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < per; e += (size_t)gridDim.x * blockDim.x * VEC) {
+        if (VEC == 4) *(float4*)(dp + e) = *(const float4*)(sp + e); else dp[e] = sp[e];
+    }
+}
+
 // ---- encoder epilogues (core/RAFT/core/extractor.py ResidualBlock / BasicEncoder): the normalisation, ReLU and
 // residual add that follow every encoder convolution, fused so each activation plane crosses HBM once in and once out
 // (torch runs statistics, normalise, bias add, ReLU and the residual add as 4-5 separate passes).
@@ -172,9 +185,15 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ x,
 // pixel, 64 consecutive x per wave: every tap is a coalesced 256-B row read and the 9 taps of a channel hit the same
 // three rows (L1), weights are wave-uniform scalar loads; the channel loop is split over the 4 waves of a workgroup
 // (each wave a quarter of the channels, combined through LDS) so the chip gets 4x more waves than pixels/64.
+// Optional extra destinations of the flow head (rpe_conv3x3_to2_flow): with add = coords1 the result is the new coords1, and
+// flow = coords1 - coords0 (coords0 = the integer pixel grid, core/RAFT/core/raft.py) is what the next iteration's motion encoder
+// reads and what sits in the last two channels of the GRU's input buffers: written here instead of by separate subtract / copy
+// launches.  p[i] = first of the two planes of destination i in batch item 0 (NULL = unused), bs[i] = its batch stride in floats.
+struct FlowDst { float* p[3]; long long bs[3]; };
+
 __global__ __launch_bounds__(256) void k_conv3x3_to2(const float* __restrict__ x, const float* __restrict__ wgt,
                                                      const float* __restrict__ bias, int C, int h, int w,
-                                                     const float* __restrict__ add, float* __restrict__ out) {
+                                                     const float* __restrict__ add, float* __restrict__ out, FlowDst F) {
     __shared__ float part[4][2][64];
     const int bz = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -213,6 +232,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_to2(const float* __restrict__ x
         a0 += bias ? bias[0] : 0.0f; a1 += bias ? bias[1] : 0.0f;
         if (add) { a0 += add[o]; a1 += add[o + hw]; }
         out[o] = a0; out[o + hw] = a1;
+        const float f0 = a0 - (float)px, f1 = a1 - (float)py;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (F.p[i]) { float* d = F.p[i] + (size_t)bz * F.bs[i] + p; d[0] = f0; d[hw] = f1; }
     }
 }
 
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_to2(const float* __restrict__ x
 #define TO2_WAVES 4                           // channel slices per workgroup: more waves in flight for a latency-bound loop
 __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* __restrict__ x, const float* __restrict__ wgt,
                                                         const float* __restrict__ bias, int C, int h, int w,
-                                                        const float* __restrict__ add, float* __restrict__ out) {
+                                                        const float* __restrict__ add, float* __restrict__ out, FlowDst F) {
     __shared__ float part[TO2_WAVES][8][64];
     const int bz = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: weights by scalar loads
@@ -304,6 +327,11 @@ __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* 
             const size_t idx = ((size_t)bz * 2 + o) * hw + (size_t)py * w + x0;
             if (add) { const float4 ad = *(const float4*)(add + idx); r4[0] += ad.x; r4[1] += ad.y; r4[2] += ad.z; r4[3] += ad.w; }
             *(float4*)(out + idx) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+            const float g0 = o == 0 ? (float)x0 : (float)py, gs = o == 0 ? 1.0f : 0.0f;      // coords0: x along the row, y constant
+            const float4 fl = make_float4(r4[0] - g0, r4[1] - (g0 + gs), r4[2] - (g0 + 2.0f * gs), r4[3] - (g0 + 3.0f * gs));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (F.p[i]) *(float4*)(F.p[i] + (size_t)bz * F.bs[i] + (size_t)o * hw + (size_t)py * w + x0) = fl;
         }
     }
 }
@@ -369,17 +397,33 @@ extern "C" int rpe_affine_act(const float* x, const float* scale, const float* s
     return rpe_check_launch();
 }
 
-extern "C" int rpe_conv3x3_to2(const float* x, const float* weight, const float* bias, int b, int c, int h, int w,
-                               const float* add, float* out, void* stream) {
+static int launch_to2(const float* x, const float* weight, const float* bias, int b, int c, int h, int w, const float* add, float* out,
+                      const FlowDst& F, void* stream) {
     if (!x || !weight || !out || b <= 0 || c <= 0 || h <= 0 || w <= 0) return RPE_E_BADARG;
+    bool fvec = true;
+    for (int i = 0; i < 3; ++i) fvec = fvec && (!F.p[i] || (vec_ok(F.p[i]) && (F.bs[i] & 3) == 0));
     // (the four-pixel kernel has a quarter of the workgroups: small launches -- one frame of sequential tracking -- keep the one-pixel one)
-    if ((w & 3) == 0 && vec_ok(x) && vec_ok(out) && (!add || vec_ok(add)) && (long long)ceil_div((size_t)h * w / 4, 64) * b >= 256)
+    if ((w & 3) == 0 && vec_ok(x) && vec_ok(out) && (!add || vec_ok(add)) && fvec && (long long)ceil_div((size_t)h * w / 4, 64) * b >= 256)
         hipLaunchKernelGGL(k_conv3x3_to2_x4, dim3(ceil_div((size_t)h * w / 4, 64), b), dim3(64 * TO2_WAVES), 0, (hipStream_t)stream, x, weight, bias,
-                           c, h, w, add, out);
+                           c, h, w, add, out, F);
     else
         hipLaunchKernelGGL(k_conv3x3_to2, dim3(ceil_div((size_t)h * w, 64), b), dim3(256), 0, (hipStream_t)stream, x, weight, bias,
-                           c, h, w, add, out);
+                           c, h, w, add, out, F);
     return rpe_check_launch();
+}
+
+extern "C" int rpe_conv3x3_to2(const float* x, const float* weight, const float* bias, int b, int c, int h, int w,
+                               const float* add, float* out, void* stream) {
+    FlowDst F = {{nullptr, nullptr, nullptr}, {0, 0, 0}};
+    return launch_to2(x, weight, bias, b, c, h, w, add, out, F, stream);
+}
+
+extern "C" int rpe_conv3x3_to2_flow(const float* x, const float* weight, const float* bias, int b, int c, int h, int w,
+                                    const float* coords, float* coords_out, float* flow_out, float* dst1, long long dst1_batch_stride,
+                                    float* dst2, long long dst2_batch_stride, void* stream) {
+    if (!coords) return RPE_E_BADARG;
+    FlowDst F = {{flow_out, dst1, dst2}, {2LL * h * w, dst1_batch_stride, dst2_batch_stride}};
+    return launch_to2(x, weight, bias, b, c, h, w, coords, coords_out, F, stream);
 }
 
 extern "C" int rpe_bias_act(const float* x, const float* bias, int b, int c, int hw, int relu, float* out1, int out1_channels,
@@ -391,6 +435,16 @@ extern "C" int rpe_bias_act(const float* x, const float* bias, int b, int c, int
     bool v4 = hw % 4 == 0 && vec_ok(x) && vec_ok(out1) && (!out2 || vec_ok(out2));
     if (v4) hipLaunchKernelGGL(k_bias_act<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, s, x, bias, c, hw, relu, out1, out1_channels, out1_offset, out2, out2_channels, out2_offset);
     else hipLaunchKernelGGL(k_bias_act<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, s, x, bias, c, hw, relu, out1, out1_channels, out1_offset, out2, out2_channels, out2_offset);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_copy_planes(const float* src, long long src_batch_stride, float* dst, long long dst_batch_stride, int b, int c, int hw,
+                               void* stream) {
+    if (!src || !dst || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
+    const size_t per = (size_t)c * hw;
+    const bool v4 = per % 4 == 0 && vec_ok(src) && vec_ok(dst) && (src_batch_stride & 3) == 0 && (dst_batch_stride & 3) == 0;
+    if (v4) hipLaunchKernelGGL(k_copy_planes<4>, dim3(min(ceil_div(per / 4, 256), 2048), b), dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, dst_batch_stride, per);
+    else hipLaunchKernelGGL(k_copy_planes<1>, dim3(min(ceil_div(per, 256), 2048), b), dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, dst_batch_stride, per);
     return rpe_check_launch();
 }
 

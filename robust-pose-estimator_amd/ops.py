@@ -347,6 +347,52 @@ def conv3x3_to2(x, weight, bias, add=None, out=None):
     return out
 
 
+def flow_update(x, weight, bias, coords, coords_out, flow_out=None, dst1=None, dst2=None, prepare=False):
+    """rpe_conv3x3_to2_flow: coords_out = conv3x3(x; weight (2,c,3,3)) + bias + coords, and flow = coords_out - pixel grid written to
+    ``flow_out`` (b,2,h,w) and into the two-channel slices ``dst1`` / ``dst2`` (e.g. hx[:, 254:256]).  ``prepare=True`` returns a launcher."""
+    _nchw(x, 'x')
+    b, c, hh, ww = x.shape
+    weight = _nchw(weight.detach() if weight.requires_grad else weight, 'weight')
+    if tuple(weight.shape) != (2, c, 3, 3):
+        raise _lib.RpeError('flow_update: weight must be (2,c,3,3)')
+    for name, t in (('coords', coords), ('coords_out', coords_out), ('flow_out', flow_out)):
+        if t is not None and tuple(_nchw(t, name).shape) != (b, 2, hh, ww):
+            raise _lib.RpeError(f'flow_update: {name} must be ({b},2,{hh},{ww})')
+    sl = []
+    for name, t in (('dst1', dst1), ('dst2', dst2)):
+        if t is None:
+            sl += [None, 0]
+            continue
+        if tuple(t.shape) != (b, 2, hh, ww):
+            raise _lib.RpeError(f'flow_update: {name} must be a ({b},2,{hh},{ww}) channel slice')
+        sl += list(_chan_slice(t, name))
+    args = (ptr(x), ptr(weight), ptr(bias), b, c, hh, ww, ptr(coords), ptr(coords_out), ptr(flow_out), sl[0], sl[1], sl[2], sl[3])
+    fn = lib().rpe_conv3x3_to2_flow
+    if prepare:
+        keep = (x, weight, bias, coords, coords_out, flow_out, dst1, dst2)
+
+        def launch():
+            st = fn(*args, stream_ptr())
+            if st != 0:
+                check(st, 'rpe_conv3x3_to2_flow')
+            return keep[4]
+        launch.keep = keep
+        return launch
+    check(fn(*args, stream_ptr()), 'rpe_conv3x3_to2_flow')
+    return coords_out
+
+
+def copy_planes(src, dst):
+    """dst[:, :c] = src for channel slices of NCHW buffers (rpe_copy_planes)."""
+    sp, sbs = _chan_slice(src, 'src')
+    dp, dbs = _chan_slice(dst, 'dst')
+    b, c, hh, ww = src.shape
+    if tuple(dst.shape) != (b, c, hh, ww):
+        raise _lib.RpeError('copy_planes: shape mismatch')
+    check(lib().rpe_copy_planes(sp, sbs, dp, dbs, b, c, hh * ww, stream_ptr()), 'rpe_copy_planes')
+    return dst
+
+
 def upsample_convex(flow, mask):
     fl, mk = _dev(flow, torch.float32, 'flow'), _dev(mask, torch.float32, 'mask')
     b, _, h8, w8 = fl.shape
@@ -358,7 +404,7 @@ def upsample_convex(flow, mask):
 
 
 # ------------------------------------------------------------------------- fused update-block convolutions
-CONV_LINEAR, CONV_RELU, CONV_GATE_ZR, CONV_GATE_H = 0, 1, 2, 3
+CONV_LINEAR, CONV_RELU, CONV_GATE_ZR, CONV_GATE_H, CONV_TANH = 0, 1, 2, 3, 4
 
 
 def _chan_slice(t, name):
@@ -415,12 +461,12 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
             raise _lib.RpeError(f'conv_fused: {name} has shape {tuple(t.shape)}')
         p, s = _chan_slice(t, name)
         setattr(d, name, p); setattr(d, name + '_batch_stride', s)
-    need = {CONV_LINEAR: pc.cout, CONV_RELU: pc.cout, CONV_GATE_ZR: gate_channels, CONV_GATE_H: pc.cout}[mode]
+    need = {CONV_LINEAR: pc.cout, CONV_RELU: pc.cout, CONV_GATE_ZR: gate_channels, CONV_GATE_H: pc.cout, CONV_TANH: pc.cout}[mode]
     if out.shape[1] < need or (mode == CONV_GATE_ZR and (out2 is None or out2.shape[1] < gate_channels or hidden.shape[1] < gate_channels)):
         raise _lib.RpeError('conv_fused: destination slice has too few channels')
     if mode == CONV_GATE_H and (hidden is None or zgate is None or hidden.shape[1] < pc.cout or zgate.shape[1] < pc.cout):
         raise _lib.RpeError('conv_fused: GATE_H needs hidden and zgate with cout channels')
-    if mode in (CONV_LINEAR, CONV_RELU) and out2 is not None and out2.shape[1] < pc.cout:
+    if mode in (CONV_LINEAR, CONV_RELU, CONV_TANH) and out2 is not None and out2.shape[1] < pc.cout:
         raise _lib.RpeError('conv_fused: out2 slice has too few channels')
     if stats is not None:
         tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride)
@@ -517,6 +563,9 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
         setattr(d, name, p); setattr(d, name + '_batch_stride', s)
     if stats is not None:
         tiles = lib().rpe_conv_wino_stats_tiles(hh, ww)
+        if not isinstance(stats, TileMajorStats):
+            raise _lib.RpeError('conv_wino: stats must come from conv_wino_stats_buffer (tile-major records)')
+        stats = stats.tensor
         if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, tiles, pw.cout, 3)):
             raise _lib.RpeError(f'conv_wino: stats must be a contiguous float32 ({b},{tiles},{pw.cout},3) GPU tensor (conv_wino_stats_buffer)')
     if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
@@ -538,12 +587,38 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
     return out
 
 
+class TileMajorStats:
+    """The (b, tiles, cout, 3) per-tile (count, mean, M2) records of rpe_conv_wino.  The layout is part of the TYPE, not an
+    attribute a view or clone could drop: instnorm_finalize / instnorm_apply take either this (tile-major) or a plain
+    (b, cout, tiles, 3) tensor (rpe_conv_fused's and rpe_stem_conv's channel-major records) and validate the shape for each."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def cpu(self):
+        return self.tensor.cpu()
+
+
 def conv_wino_stats_buffer(b, cout, hh, ww, device):
-    """Per-tile (count, mean, M2) records rpe_conv_wino fills when ``stats`` is given: TILE-MAJOR (b, tiles, cout, 3), marked so
-    that instnorm_apply / instnorm_finalize read it that way."""
-    t = torch.empty(b, lib().rpe_conv_wino_stats_tiles(hh, ww), cout, 3, dtype=torch.float32, device=device)
-    t.rpe_tile_major = True
-    return t
+    """Per-tile (count, mean, M2) records rpe_conv_wino fills when ``stats`` is given: TILE-MAJOR (b, tiles, cout, 3)."""
+    return TileMajorStats(torch.empty(b, lib().rpe_conv_wino_stats_tiles(hh, ww), cout, 3, dtype=torch.float32, device=device))
+
+
+def _stats_layout(stats, b, c, who):
+    """(tensor, signed tile count for the C ABI: negative = tile-major) after validating the records' shape against (b, c)."""
+    tile_major = isinstance(stats, TileMajorStats)
+    t = stats.tensor if tile_major else stats
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4 and t.shape[3] == 3):
+        raise _lib.RpeError(f'{who}: stats must be a contiguous float32 4-D GPU tensor of (count, mean, M2) records')
+    want = (b, t.shape[1], c) if tile_major else (b, c, t.shape[2])
+    if tuple(t.shape[:3]) != want or t.shape[1 if tile_major else 2] < 1:
+        raise _lib.RpeError(f'{who}: stats must be the (b,c,tiles,3) buffer of conv_fused / stem_conv or the TileMajorStats (b,tiles,c,3) of conv_wino; '
+                            f'got {tuple(t.shape)} for b={b}, c={c}')
+    return t, (-t.shape[1] if tile_major else t.shape[2])
 
 
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
@@ -551,15 +626,16 @@ def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
     return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 3, dtype=torch.float32, device=device)
 
 
-def instnorm_finalize(stats, hw, eps=1e-5):
-    """(b,c,2) = (mean, 1/std) per plane from conv_fused's partial sums: the ``pre_norm`` argument of the next conv_fused."""
-    if getattr(stats, 'rpe_tile_major', False):
-        b, tiles, c, _ = stats.shape
-        tiles = -tiles
-    else:
-        b, c, tiles, _ = stats.shape
-    mi = torch.empty(b, c, 2, dtype=torch.float32, device=stats.device)
-    check(lib().rpe_instnorm_finalize(ptr(stats), tiles, b, c, hw, float(eps), ptr(mi), stream_ptr()), 'rpe_instnorm_finalize')
+def instnorm_finalize(stats, hw, eps=1e-5, channels=None):
+    """(b,c,2) = (mean, 1/std) per plane from conv_fused's partial sums: the ``pre_norm`` argument of the next conv_fused.
+    ``channels`` (optional) is checked against the records' channel axis."""
+    b = stats.shape[0]
+    c = stats.shape[2] if isinstance(stats, TileMajorStats) else stats.shape[1]
+    if channels is not None and channels != c:
+        raise _lib.RpeError(f'instnorm_finalize: records hold {c} channels, expected {channels}')
+    t, tiles = _stats_layout(stats, b, c, 'instnorm_finalize')
+    mi = torch.empty(b, c, 2, dtype=torch.float32, device=t.device)
+    check(lib().rpe_instnorm_finalize(ptr(t), tiles, b, c, hw, float(eps), ptr(mi), stream_ptr()), 'rpe_instnorm_finalize')
     return mi
 
 
@@ -567,16 +643,11 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None):
     """Instance norm of x (b,c,h,w) from the partial sums of conv_fused(..., stats=stats): one read + one write pass."""
     _nchw(x, 'x')
     b, c, hh, ww = x.shape
-    tile_major = getattr(stats, 'rpe_tile_major', False)          # (b, tiles, c, 3): conv_wino's records
-    want = (b, stats.shape[1], c) if tile_major else (b, c, stats.shape[2])
-    if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and tuple(stats.shape[:3]) == want
-            and stats.shape[3] == 3):
-        raise _lib.RpeError('instnorm_apply: stats must be the (b,c,tiles,3) buffer of conv_fused or the (b,tiles,c,3) one of conv_wino')
+    t, tiles = _stats_layout(stats, b, c, 'instnorm_apply')
     if residual is not None and _nchw(residual, 'residual').shape != x.shape:
         raise _lib.RpeError('instnorm_apply: residual must have the shape of x')
     out = x if out is None else _nchw(out, 'out')
-    tiles = -stats.shape[1] if tile_major else stats.shape[2]
-    check(lib().rpe_instnorm_apply(ptr(x), ptr(stats), tiles, b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
+    check(lib().rpe_instnorm_apply(ptr(x), ptr(t), tiles, b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(out),
                                    stream_ptr()), 'rpe_instnorm_apply')
     return out
 
@@ -606,7 +677,13 @@ def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.
         out = torch.empty(b, ps.cout, hh // st_, ww // st_, dtype=torch.float32, device=image.device)
     elif tuple(_nchw(out, 'out').shape) != (b, ps.cout, hh // st_, ww // st_):
         raise _lib.RpeError('stem_conv: out has the wrong shape')
-    st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 3, dtype=torch.float32, device=image.device) if stats else None
+    if isinstance(stats, torch.Tensor):             # a caller-owned (batch slice of a) statistics buffer
+        st = stats
+        if not (st.is_cuda and st.dtype == torch.float32 and st.is_contiguous() and tuple(st.shape) == (b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 3)):
+            raise _lib.RpeError('stem_conv: stats buffer has the wrong shape')
+        stats = True
+    else:
+        st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 3, dtype=torch.float32, device=image.device) if stats else None
     check(lib().rpe_stem_conv(ptr(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), ptr(ps.packed), ps.cout, ptr(bias), ptr(scale),
                               int(bool(relu)), ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
     return (out, st) if stats else out

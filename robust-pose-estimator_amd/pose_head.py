@@ -72,11 +72,20 @@ class DPoseSE3Head:
         if not bool((fY.abs() <= eps).all()):
             warnings.warn('Non-zero objective function gradient at y:\n{}'.format(fY.detach().squeeze().cpu().numpy()))
             return zeros()
+        # ddn's _solve_linear_system (anucvml/ddn node.py, called at declerative_node_lie.py:58): batched Cholesky; rows it fails on
+        # are retried one by one and fall back to an LU solve; only when that fails too does the reference's ``except`` zero the
+        # gradients of the whole batch (:59-63)
+        rhs = -v.reshape(n, 6, 1).double()
         L, info = torch.linalg.cholesky_ex(H)
-        if bool((info != 0).any()):
-            warnings.warn('linear system is not positive definite ')
-            return zeros()
-        u = torch.cholesky_solve(-v.reshape(n, 6, 1).double(), L)[..., 0]
+        bad = info != 0
+        u = torch.cholesky_solve(rhs, torch.where(bad[:, None, None], torch.eye(6, dtype=H.dtype, device=H.device), L))
+        if bool(bad.any()):
+            lu, lu_info = torch.linalg.solve_ex(H[bad], rhs[bad])
+            if bool((lu_info != 0).any()) or not bool(torch.isfinite(lu).all()):
+                warnings.warn('linear system is not positive definite ')
+                return zeros()
+            u[bad] = lu
+        u = u[..., 0]
         u = torch.where(torch.isnan(u), torch.zeros_like(u), u)
         names = ('flow', 'pcl1', 'pcl2', 'w1', 'w2')
         want = [nm for nm, nd in zip(names, needs[:5]) if nd]

@@ -48,9 +48,9 @@ class PoseNet(nn.Module):
         a division by a power of two commutes with the rounding of b / -flow.x, so the kernel is handed b / 8).
         ``ret_cache`` additionally returns the encoder outputs of ``imagel`` for reuse by the next ``infer``."""
         n = imagel.shape[0]
-        f = self.flow.encode_features(torch.cat((imagel, imager), dim=0))
+        f = self.flow.encode_features((imagel, imager))
         cn = self.flow.encode_context(imagel)
-        flow = self.flow(imagel, imager, upsample=upsample, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
+        flow = self.flow(None, None, upsample=upsample, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
         depth, valid = ops.flow2depth(flow, baseline if upsample else baseline / 8.0)
         if ret_cache:
             return depth, flow, valid, dict(fmap=f[:n], cnet=cn)
@@ -100,22 +100,22 @@ class PoseNet(nn.Module):
         n = image1l.shape[0]
         intrinsics = intrinsics.expand(n, 3, 3).contiguous()
         baseline = baseline.expand(n).contiguous()
-        ref_imgs = torch.cat((image1l, image2l), dim=0)
-        trg_imgs = torch.cat((image2l, image2r), dim=0)
-        # image2l sits in both halves of the reference's batch-2 RAFT call (pose_net.py:63-64); the feature
-        # encoder uses per-sample instance norm, so it is encoded once and reused (3n encoder passes, not 4n)
+        # The reference's batch-2 RAFT call is (image1l, image2l) -> (image2l, image2r) (pose_net.py:63-64).  image2l sits in both
+        # halves and the feature encoder normalises per sample, so it is encoded once: f = (f1l | f2l | f2r) in ONE encoder batch
+        # whose overlapping slices f[:2n], f[n:] ARE the two operand batches of the correlation -- no torch.cat of images or maps
         if cache1 is None:
-            f = self.flow.encode_features(torch.cat((image1l, image2l, image2r), dim=0))
-            f1l, f2l, f2r = f[:n], f[n:2 * n], f[2 * n:]
-            cn = self.flow.encode_context(ref_imgs)
+            f = self.flow.encode_features((image1l, image2l, image2r))
+            f2l = f[n:2 * n]
+            fmaps = (f[:2 * n], f[n:])
+            cn = self.flow.encode_context((image1l, image2l))
             c2l = cn[n:]
         else:
-            f = self.flow.encode_features(torch.cat((image2l, image2r), dim=0))
-            f1l, f2l, f2r = cache1['fmap'], f[:n], f[n:]
+            f = self.flow.encode_features((image2l, image2r))
+            f2l = f[:n]
+            fmaps = (torch.cat((cache1['fmap'], f2l), dim=0), f)
             c2l = self.flow.encode_context(image2l)
             cn = torch.cat((cache1['cnet'], c2l), dim=0)
-        fmaps = (torch.cat((f1l, f2l), dim=0), torch.cat((f2l, f2r), dim=0))
-        flow_predictions, hidden, context = self.flow(ref_imgs, trg_imgs, upsample=True, fmaps=fmaps, cnet=cn)
+        flow_predictions, hidden, context = self.flow(None, None, upsample=True, fmaps=fmaps, cnet=cn)
         time_flow = flow_predictions[-1][:n].contiguous()
         stereo_flow2 = flow_predictions[-1][n:].contiguous()
         hidden, context = hidden[:n], context[:n]

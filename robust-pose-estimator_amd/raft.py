@@ -8,9 +8,13 @@ What runs where (MI355X-first split), all hand-written HIP 
   * every convolution of the update block with its bias / ReLU / concat / GRU-gate epilogue, the encoders' residual
     blocks (3x3 stride 1 and 2, 1x1 stride-2 shortcut) with folded batch norm / instance-norm statistics, as f32-MFMA
     implicit GEMMs (csrc/conv.hip); the 7x7 stems and convf1 (csrc/stem.hip)
-  * flow-head output layer, convex up-sampling, norm / bias passes (csrc/raft_ops.hip)
-  Left on PyTorch-ROCm (MIOpen / rocBLAS): the encoders' final 1x1, the mask head's 1x1 (once per pass), and -- for map widths that
-  are not a multiple of 4 or launches too small to fill the chip -- the library route of the same layers.
+  * the update block's and the encoders' 3x3 stride-1 layers as Winograd F(2x2,3x3) (csrc/conv_wino.hip), the GRU's 1x5 / 5x1
+    layers with their gate epilogues as Winograd F(4,5) (csrc/conv_wino1d.hip); the encoders' final 1x1 (cnet's with its
+    tanh | ReLU split in the epilogue) and the mask head's 1x1 on the implicit GEMM
+  * flow-head output layer with the coords / flow bookkeeping of the loop, convex up-sampling, norm / bias passes, slice copies
+    (csrc/raft_ops.hip)
+  On PyTorch-ROCm (MIOpen / rocBLAS) only as the fallback route of the same layers: map widths that are not a multiple of 4, odd
+  maps, and the encoders' stride-2 layers of launches too small to fill the chip.
 Exact re-associations used (results identical up to float rounding of the conv library):
   * convz/convr of each GRU half share their input, so their weights are stacked into one 256-channel conv
   * the GRU input is (h | inp | motion | flow) and the context `inp` is the same in all 12 iterations, so the
@@ -206,34 +210,75 @@ class BasicEncoder(nn.Module):
         self.in_planes = dim
         return nn.Sequential(l1, l2)
 
-    def _stem(self, image):
-        """conv1 + norm1 + ReLU on the RAW 0..255 image: the normalisation 2*(x/255)-1 happens while the kernel stages its
+    def _stem_pack(self):
+        """conv1 + norm1 + ReLU run on the RAW 0..255 image: the normalisation 2*(x/255)-1 happens while the kernel stages its
         input patch (rpe_stem_conv)."""
         key = (self.conv1.weight._version, self.conv1.weight.data_ptr())
         if getattr(self, '_stem_packed', None) is None or self._stem_packed[0] != key:
             self._stem_packed = (key, ops.PackedStem(self.conv1.weight))
-        ps = self._stem_packed[1]
-        if isinstance(self.norm1, nn.BatchNorm2d):
+        return self._stem_packed[1]
+
+    def _stem_many(self, images):
+        """The stem over several image batches, written into batch slices of ONE output (no torch.cat of the inputs)."""
+        ps = self._stem_pack()
+        n = sum(im.shape[0] for im in images)
+        hh, ww = images[0].shape[-2:]
+        out = torch.empty(n, 64, hh // 2, ww // 2, device=images[0].device)
+        bn = isinstance(self.norm1, nn.BatchNorm2d)
+        if bn:
             if self.norm1.training:
                 raise RuntimeError('the RAFT encoders run with frozen batch norm (RAFT.freeze_bn, pose_net.py:22)')
             scale, shift = _bn_affine(self.conv1, self.norm1)
-            return ops.stem_conv(image, ps, bias=shift, scale=scale, relu=True)
-        pre, stats = ops.stem_conv(image, ps, bias=self.conv1.bias.detach(), relu=False, stats=True)
-        return ops.instnorm_apply(pre, stats, eps=self.norm1.eps, relu=True)
-
-    def forward(self, x, raw255=False):
-        """``raw255``: x is the raw 0..255 image (RAFT.forward's normalisation is then done inside the first kernel)."""
-        x = x.contiguous()
-        if raw255:
-            hh, ww = x.shape[-2:]
-            if hh % 2 == 0 and ww % 2 == 0 and ((hh // 2) * (ww // 2)) % 4 == 0 and isinstance(self.norm1, (nn.BatchNorm2d, nn.InstanceNorm2d)):
-                x = self._stem(x)
+        stats = None if bn else torch.empty(n, 64, ops.lib().rpe_stem_tiles(hh, ww, 2), 3, device=out.device)
+        i = 0
+        for im in images:
+            k = im.shape[0]
+            if bn:
+                ops.stem_conv(im.contiguous(), ps, bias=shift, scale=scale, relu=True, out=out[i:i + k])
             else:
-                x = conv_norm_act(self.conv1, self.norm1, 2 * (x / 255.0) - 1.0, relu=True)
+                ops.stem_conv(im.contiguous(), ps, bias=self.conv1.bias.detach(), relu=False, stats=stats[i:i + k], out=out[i:i + k])
+            i += k
+        if bn:
+            return out
+        return ops.instnorm_apply(out, stats, eps=self.norm1.eps, relu=True)
+
+    def _final(self, x, split_act):
+        """conv2, the 1x1 output layer (128 -> output_dim), on the implicit GEMM.  ``split_act`` (the context encoder as RAFT uses
+        it, core/RAFT/core/raft.py: net, inp = split(cnet); net = tanh(net); inp = relu(inp)): channels [0, 128) leave through
+        tanh, the rest through ReLU, in the convolution's epilogue."""
+        m = self.conv2
+        b, _, hh, ww = x.shape
+        half = m.out_channels // 2
+        if ww % 4 == 0 and x.is_contiguous():
+            key = (m.weight._version, m.weight.data_ptr(), m.bias._version)
+            cached = getattr(self, '_final_packed', None)
+            if cached is None or cached[0] != key:
+                w, bv = m.weight.detach(), m.bias.detach()
+                self._final_packed = cached = (key, ops.PackedConv(w, bv), ops.PackedConv(w[:half].contiguous(), bv[:half].contiguous()),
+                                               ops.PackedConv(w[half:].contiguous(), bv[half:].contiguous()))
+            out = torch.empty(b, m.out_channels, hh, ww, device=x.device)
+            if not split_act:
+                return ops.conv_fused(x, cached[1], ops.CONV_LINEAR, out)
+            ops.conv_fused(x, cached[2], ops.CONV_TANH, out[:, :half])
+            ops.conv_fused(x, cached[3], ops.CONV_RELU, out[:, half:])
+            return out
+        y = m(x)
+        return torch.cat((torch.tanh(y[:, :half]), torch.relu(y[:, half:])), dim=1) if split_act else y
+
+    def forward(self, x, raw255=False, split_act=False):
+        """``raw255``: x is the raw 0..255 image (RAFT.forward's normalisation is then done inside the first kernel), or a list of
+        such image batches, encoded as one batch.  ``split_act``: see _final."""
+        many = isinstance(x, (list, tuple))
+        first = x[0] if many else x
+        hh, ww = first.shape[-2:]
+        stem_ok = raw255 and hh % 2 == 0 and ww % 2 == 0 and ((hh // 2) * (ww // 2)) % 4 == 0 and isinstance(self.norm1, (nn.BatchNorm2d, nn.InstanceNorm2d))
+        if stem_ok:
+            x = self._stem_many(list(x) if many else [x])
         else:
-            x = conv_norm_act(self.conv1, self.norm1, x, relu=True)
+            x = (torch.cat(list(x), dim=0) if many else x).contiguous()
+            x = conv_norm_act(self.conv1, self.norm1, 2 * (x / 255.0) - 1.0 if raw255 else x, relu=True)
         x = self.layer3(self.layer2(self.layer1(x)))
-        return self.conv2(x)
+        return self._final(x, split_act)
 
 
 class FlowHead(nn.Module):
@@ -271,7 +316,7 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr, cat_buf, hx, rhx, packed=None):
+    def forward(self, flow, corr, cat_buf, hx, rhx, packed=None, flow_in_place=False):
         """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [128,256) of hx and rhx.
         ``packed`` (BasicUpdateBlock.packed_convs) selects the fused HIP convolutions (conv + bias + ReLU + cat in
         one kernel each); otherwise the library convolution runs without bias and rpe_bias_act does the rest."""
@@ -307,7 +352,8 @@ class BasicMotionEncoder(nn.Module):
             flo = ops.bias_act(cv(self.convf1, flow), self.convf1.bias)
             ops.bias_act(cv(self.convf2, flo), self.convf2.bias, out=cat_buf, out_offset=192)
             ops.bias_act(cv(self.conv, cat_buf), self.conv.bias, out=hx, out_offset=128, out2=rhx, out2_offset=128)
-        ops.bias_act(flow, None, relu=False, out=hx, out_offset=254, out2=rhx, out2_offset=254)
+        if not flow_in_place:                                   # (the fused flow head has already written flow behind the motion features)
+            ops.bias_act(flow, None, relu=False, out=hx, out_offset=254, out2=rhx, out2_offset=254)
 
 
 class BasicUpdateBlock(nn.Module):
@@ -390,18 +436,23 @@ class BasicUpdateBlock(nn.Module):
             self._packed = (key, P)
         return self._packed[1]
 
-    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1):
+    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=False):
         """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
         Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (h_buf is written by the library
-        path only: the fused flow head reads the slice directly)."""
+        path only: the fused flow head reads the slice directly).  ``in_place`` (fused route only): ``coords1`` and ``flow`` are
+        persistent buffers; the flow head's output layer updates coords1 in place and writes flow = coords1 - grid into ``flow``
+        and behind the motion features of hx / rhx, so the loop runs without subtract / copy launches."""
         c = self.hidden_dim
         P = self.packed_convs(hx.shape[-1])
-        self.encoder(flow, corr, cat_buf, hx, rhx, packed=P)
+        if in_place and P is None:
+            raise RuntimeError('in_place update needs the fused route')
+        self.encoder(flow, corr, cat_buf, hx, rhx, packed=P, flow_in_place=in_place)
         fh = self.flow_head
         if P is not None:
             # each GRU half = two implicit-GEMM convolutions whose epilogues are the gates:
             #   z = s(convz hx + ctx), r*h -> rhx ;  h <- (1-z) h + z tanh(convq rhx + ctx)   (in place on hx[:, :c])
-            key = (hx.data_ptr(), rhx.data_ptr(), z_buf.data_ptr(), tuple(ctx[k].data_ptr() for k in ('zr1', 'q1', 'zr2', 'q2')), tuple(hx.shape))
+            key = (hx.data_ptr(), rhx.data_ptr(), z_buf.data_ptr(), tuple(ctx[k].data_ptr() for k in ('zr1', 'q1', 'zr2', 'q2')), tuple(hx.shape),
+                   (coords1.data_ptr(), flow.data_ptr()) if in_place else None)
             calls = P.get('_gru_calls')
             if calls is None or calls[0] != key:
                 seq = []
@@ -414,7 +465,14 @@ class BasicUpdateBlock(nn.Module):
                     seq.append(ops.conv_wino(hx[:, :c], P['wino']['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
                 else:
                     seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+                if in_place:
+                    seq.append(ops.flow_update(P['fh_buf'](hx), fh.conv2.weight, fh.conv2.bias.detach(), coords1, coords1, flow_out=flow,
+                                               dst1=hx[:, 2 * c - 2:], dst2=rhx[:, 2 * c - 2:], prepare=True))
                 P['_gru_calls'] = calls = (key, seq)
+            if in_place:
+                for launch in calls[1]:
+                    launch()
+                return coords1
             for launch in calls[1][:-1]:
                 launch()
             t = calls[1][-1]()
@@ -442,12 +500,16 @@ class BasicUpdateBlock(nn.Module):
         cached = getattr(self, '_mask_packed', None)
         if cached is None or cached[0] != key:
             pw = ops.PackedWino(c1.weight, c1.bias) if WINOGRAD and c1.weight.is_cuda else None
-            self._mask_packed = cached = (key, pw, (0.25 * c2.weight).detach(), (0.25 * c2.bias).detach())
-        _, pw, w2, b2 = cached
-        if pw is not None and not torch.is_grad_enabled() and net.is_contiguous() and net.shape[-1] % 2 == 0 and net.shape[-2] % 2 == 0:
-            t = ops.conv_wino(net, pw, ops.CONV_RELU, torch.empty(net.shape[0], c1.out_channels, net.shape[2], net.shape[3], device=net.device))
+            w2, b2 = (0.25 * c2.weight).detach(), (0.25 * c2.bias).detach()
+            self._mask_packed = cached = (key, pw, w2, b2, ops.PackedConv(w2, b2) if c2.weight.is_cuda else None)
+        _, pw, w2, b2, p2 = cached
+        hh, ww = net.shape[-2:]
+        if pw is not None and not torch.is_grad_enabled() and hh % 2 == 0 and ww % 2 == 0:      # (net may be a channel slice: hx[:, :128])
+            t = ops.conv_wino(net, pw, ops.CONV_RELU, torch.empty(net.shape[0], c1.out_channels, hh, ww, device=net.device))
         else:
-            t = F.relu(c1(net))
+            t = F.relu(c1(net.contiguous()))
+        if p2 is not None and ww % 4 == 0 and not torch.is_grad_enabled():
+            return ops.conv_fused(t, p2, ops.CONV_LINEAR, torch.empty(net.shape[0], c2.out_channels, hh, ww, device=net.device))
         return F.conv2d(t, w2, b2)
 
 
@@ -503,56 +565,72 @@ class RAFT(nn.Module):
             e = lambda ch: torch.empty(n, ch, h8, w8, device=device)
             self._ws[key] = dict(hx=e(2 * c), rhx=e(2 * c), z=e(c), cat=e(2 * c),
                                  corr=e(self.corr_levels * (2 * self.corr_radius + 1) ** 2),
-                                 ctx=dict(zr1=e(2 * c), q1=e(c), zr2=e(2 * c), q2=e(c)))
+                                 ctx=dict(zr1=e(2 * c), q1=e(c), zr2=e(2 * c), q2=e(c)),
+                                 coords0=coords_grid(n, h8, w8, device), coords1=e(2), flow=e(2),
+                                 zero2=torch.zeros(n, 2, h8, w8, device=device))
         return self._ws[key]
 
     @torch.no_grad()
     def encode_features(self, images):
-        """fnet on raw 0..255 images (normalised like forward does)."""
+        """fnet on raw 0..255 images (normalised like forward does); one batch or a list of batches encoded as one."""
         return self.fnet(images, raw255=True).float()
 
     @torch.no_grad()
     def encode_context(self, images):
-        """cnet on raw 0..255 images: (N,256,H/8,W/8) = (hidden | context) pre-activations."""
-        return self.cnet(images, raw255=True)
+        """cnet on raw 0..255 images (one batch or a list of batches): (N,256,H/8,W/8) = (tanh(net) | relu(inp)), the initial
+        hidden state and the context features of core/RAFT/core/raft.py, activated in the output layer's epilogue."""
+        return self.cnet(images, raw255=True, split_act=True)
 
     @torch.no_grad()
     def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None, cnet=None):
         """image1, image2: (N,3,H,W) in 0..255.  Inference only (the reference freezes RAFT, train.yaml:51).
         ``fmaps`` / ``cnet`` accept encoder outputs computed elsewhere (both encoders normalise per sample -- instance
-        norm / frozen batch norm -- so a caller may encode every distinct image once and reuse it)."""
+        norm / frozen batch norm -- so a caller may encode every distinct image once and reuse it); with both given the
+        images may be None.  ``cnet`` is encode_context's output: (tanh(net) | relu(inp))."""
         iters = self.iters if iters is None else iters
-        N, _, H, W = image1.shape
-        h8, w8 = H // 8, W // 8
-        dev = image1.device
+        if image1 is None:                                    # encoder outputs given: the images are not needed again
+            (N, _, h8, w8), dev = fmaps[0].shape, fmaps[0].device
+        else:
+            N, _, H, W = image1.shape
+            h8, w8 = H // 8, W // 8
+            dev = image1.device
         if fmaps is None:
-            f = self.encode_features(torch.cat((image1, image2), dim=0))
+            f = self.encode_features((image1, image2))
             fmap1, fmap2 = f[:N], f[N:]
         else:
             fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
         pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision)
         if cnet is None:
-            cnet = self.encode_context(image1)
+            cnet = self.encode_context(image1)                # (tanh(net) | relu(inp))
         c = self.hidden_dim
         ws = self._workspace(N, h8, w8, dev)
         hx, rhx, z_buf, cat_buf, corr = ws['hx'], ws['rhx'], ws['z'], ws['cat'], ws['corr']   # hx = (h | motion | flow)
         h_buf = torch.empty(N, c, h8, w8, device=dev)         # returned to the caller: fresh
-        torch.tanh(cnet[:, :c], out=hx[:, :c])
-        inp = torch.relu(cnet[:, c:])
+        ops.copy_planes(cnet[:, :c], hx[:, :c])
+        inp = cnet[:, c:]
         ctx = self.update_block.context_terms(inp, out=ws['ctx'])
-        coords0 = coords_grid(N, h8, w8, dev)
-        coords1 = coords0.clone()
+        coords0 = ws['coords0']
         flow_predictions = []
+        fused = self.update_block.packed_convs(w8) is not None
+        if fused:
+            # coords1 and flow = coords1 - coords0 live in persistent buffers which the flow head's output layer updates in place
+            coords1, flow = ops.copy_planes(coords0, ws['coords1']), ops.copy_planes(ws['zero2'], ws['flow'])
+            ops.copy_planes(ws['zero2'], hx[:, 2 * c - 2:])
+            ops.copy_planes(ws['zero2'], rhx[:, 2 * c - 2:])
+        else:
+            coords1 = coords0.clone()
         for itr in range(iters):
             pyr.lookup(coords1, out=corr)
-            flow = coords1 - coords0
-            coords1 = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1)
+            if fused:
+                self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=True)
+            else:
+                flow = coords1 - coords0
+                coords1 = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1)
             if all_flows or itr == iters - 1:
-                lowres = coords1 - coords0
+                lowres = flow if fused else coords1 - coords0
                 if upsample:
-                    h_buf.copy_(hx[:, :c])                     # contiguous hidden state for the mask head
-                    flow_predictions.append(ops.upsample_convex(lowres, self.update_block.up_mask(h_buf)))
+                    flow_predictions.append(ops.upsample_convex(lowres, self.update_block.up_mask(hx[:, :c])))
                 else:
-                    flow_predictions.append(lowres)
-        h_buf.copy_(hx[:, :c])
+                    flow_predictions.append(ops.copy_planes(lowres, torch.empty_like(lowres)) if fused else lowres)
+        ops.copy_planes(hx[:, :c], h_buf)
         return flow_predictions, h_buf, inp

@@ -115,6 +115,26 @@ def test_winograd_1d_matches_f64(rpe, cin, cout, kh, kw, h, w, b, relu):
     assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all()            # neighbours untouched
 
 
+@pytest.mark.parametrize('cin,cout,h,w,b', [(128, 128, 64, 80, 32), (128, 128, 64, 80, 1), (128, 576, 44, 48, 2)])
+def test_1x1_output_layers_and_tanh_epilogue(rpe, cin, cout, h, w, b):
+    """The encoders' / mask head's 1x1 output layers on rpe_conv_fused, and RPE_CONV_TANH (the hidden-state half of the context
+    encoder: net = tanh(net)) on the hardware exp / rcp path: absolute 1e-6 on tanh of pre-activations spread over +-8."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + b)
+    x, wt, bias = _rand(rng, b, cin, h, w, s=2.0), _rand(rng, cout, cin, 1, 1, s=0.1), _rand(rng, cout, s=0.5)
+    ref = _ref_conv(x, wt, bias, None)
+    pc = ops.PackedConv(wt.cuda(), bias.cuda())
+    buf = torch.full((b, cout + 3, h, w), -7.0, device='cuda')
+    ops.conv_fused(x.cuda(), pc, ops.CONV_TANH, buf[:, 1:1 + cout])
+    assert float(ref.abs().max()) > 6.0
+    assert float((buf[:, 1:1 + cout].cpu().double() - torch.tanh(ref)).abs().max()) < _tol(x, wt) + 1e-6
+    assert bool((buf[:, 0] == -7.0).all()) and bool((buf[:, 1 + cout:] == -7.0).all())
+    lin = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    assert float((lin.cpu().double() - ref).abs().max()) < _tol(x, wt)
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):                      # plain epilogue only
+        ops.conv_fused(x.cuda(), pc, ops.CONV_TANH, torch.empty(b, cout, h, w, device='cuda'), scale=torch.ones(cout, device='cuda'))
+
+
 def test_winograd_1d_rejects_what_it_cannot_do(rpe):
     from rpe_amd import ops
     with pytest.raises(rpe.RpeError):

@@ -241,6 +241,60 @@ def test_flow_head_last_layer(rpe):
         assert torch.allclose(got2, coords + ref, atol=2e-4, rtol=1e-4)
 
 
+def test_flow_head_with_fused_bookkeeping(rpe):
+    """rpe_conv3x3_to2_flow: coords1 updated in place, flow = coords1 - coords0 (the integer grid) written to a plain buffer and
+    behind the motion features of two 256-channel buffers -- bit-identical to the separate conv + subtract + copies."""
+    from rpe_amd import ops
+    torch.manual_seed(6)
+    for (b, c, h, w) in ((32, 256, 64, 80), (1, 256, 64, 80), (2, 256, 44, 48), (1, 20, 13, 37)):
+        x = torch.randn(b, c, h, w).cuda()
+        wt, bias = (torch.randn(2, c, 3, 3) * 0.05).cuda(), torch.randn(2).cuda()
+        coords0 = oraft.coords_grid(b, h, w).cuda()
+        coords1 = (coords0 + torch.randn(b, 2, h, w).cuda() * 10).contiguous()
+        want = ops.conv3x3_to2(x, wt, bias, add=coords1)
+        hx, rhx = torch.full((b, 256, h, w), -7.0, device='cuda'), torch.full((b, 256, h, w), -7.0, device='cuda')
+        flow = torch.empty(b, 2, h, w, device='cuda')
+        got = ops.flow_update(x, wt, bias, coords1, coords1, flow_out=flow, dst1=hx[:, 254:], dst2=rhx[:, 254:])
+        assert got is coords1 and torch.equal(coords1, want)
+        assert torch.equal(flow, want - coords0)
+        assert torch.equal(hx[:, 254:], flow) and torch.equal(rhx[:, 254:], flow)
+        assert bool((hx[:, :254] == -7.0).all()) and bool((rhx[:, :254] == -7.0).all())
+        again = ops.flow_update(x, wt, bias, want, torch.empty_like(want), prepare=True)()      # no extra destinations, prepared launcher
+        assert torch.equal(again, ops.conv3x3_to2(x, wt, bias, add=want))
+
+
+def test_copy_planes(rpe):
+    from rpe_amd import ops
+    src = torch.randn(3, 10, 7, 12, device='cuda')
+    dst = torch.full((3, 16, 7, 12), 5.0, device='cuda')
+    ops.copy_planes(src[:, 2:7], dst[:, 9:14])
+    assert torch.equal(dst[:, 9:14], src[:, 2:7]) and bool((dst[:, :9] == 5.0).all()) and bool((dst[:, 14:] == 5.0).all())
+    odd = torch.randn(2, 3, 5, 7, device='cuda')                                                # plane size not a multiple of 4
+    assert torch.equal(ops.copy_planes(odd[:, 1:], torch.empty(2, 2, 5, 7, device='cuda')), odd[:, 1:])
+    with pytest.raises(rpe.RpeError):
+        ops.copy_planes(src[:, :2], dst[:, :3])
+
+
+def test_lookup_round_diagnostic(rpe):
+    """rpe_corr_lookup_rounds: one round per group for smooth flow; a flow discontinuity inside a group costs extra rounds."""
+    from rpe_amd import ops
+    b, h8, w8 = 2, 32, 40
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda')
+    c0 = oraft.coords_grid(b, h8, w8).cuda()
+    rounds, lines = pyr.rounds((c0 + 0.3).contiguous())
+    assert rounds.shape == (b, 4, h8 * 5) and int(rounds.min()) == int(rounds.max()) == 1 and int(lines.min()) > 0
+    jump = c0.clone()
+    jump[:, 0, :, 20:] += 9.0                                  # queries 20.. of every row jump 9 px: groups 2 (x 16..23) straddle it
+    r2, l2 = pyr.rounds(jump)
+    r2 = r2.reshape(b, 4, h8, 5)
+    assert int(r2[:, 0, :, 2].min()) == 2 and int(r2[:, 0, :, [0, 1, 3, 4]].max()) == 1
+    l1g, l2g = lines.reshape(b, 4, h8, 5)[:, 0, 4:-4, 2], l2.reshape(b, 4, h8, 5)[:, 0, 4:-4, 2]
+    assert bool((l2g > l1g).all())                              # the straddling groups fetch more lines (interior rows)
+    far = (c0 + 1.0e4).contiguous()                             # every window outside its map: nothing to fetch
+    r3, l3 = pyr.rounds(far)
+    assert int(r3.max()) == 0 and int(l3.max()) == 0
+
+
 @pytest.mark.parametrize('b,h8,w8', [(2, 32, 40), (1, 17, 23), (1, 128, 160)])
 def test_fp16_feature_pyramid_matches_oracle(rpe, b, h8, w8):
     """BASELINE config 5 ("fp16 features"): feature maps rounded to fp16, 16-bit MFMA with f32 accumulation, f32 pyramid --

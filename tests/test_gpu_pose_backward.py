@@ -168,3 +168,42 @@ def test_posenet_training_forward_and_backward(rpe):
     assert model.loss_weight.grad is not None and bool(torch.isfinite(model.loss_weight.grad).all()) and float(model.loss_weight.grad.abs().sum()) > 0
     with pytest.raises(NotImplementedError):
         model.freeze_flow(False)
+
+
+def test_backward_falls_back_per_row_when_h_is_not_positive_definite(rpe, monkeypatch):
+    """ddn's _solve_linear_system (behind declerative_node_lie.py:58) retries the rows a batched Cholesky fails on and falls back to
+    an LU solve for them; the reference zeroes the batch's gradients only when that fails too.  H is forced here: row 1 indefinite
+    but regular -> no warning, its gradient is that of the LU solution; row 1 singular -> the reference's warning and zeros."""
+    from rpe_amd import ops
+    from rpe_amd import pose_head as ph
+    c = synth.solver_case(73, 2, 32, 48, outliers=False)
+    xs = [a.cuda() for a in synth.solver_args(c)]
+    head = ph.DPoseSE3Head(None, lbgfs_iters=100)
+    T, _ = head.solve(*xs)
+    y = T.data.reshape(2, 7).float()
+    v = torch.randn(2, 1, 6, device='cuda', dtype=torch.float64)
+    real = ops.pose_backward_moments
+    needs = [False, False, False, True, True, False, False, False, True]
+
+    def forced(kind):
+        def f(*a):
+            g2u, g3u, H = real(*a)
+            H = H.clone()
+            if kind == 'indefinite':
+                H[1] = torch.diag(torch.tensor([2.0, 1.0, -3.0, 1.5, 2.5, 1.0], dtype=H.dtype, device=H.device)) * H[0].abs().max()
+            else:
+                H[1] = 0.0
+            return g2u, g3u, H
+        return f
+    monkeypatch.setattr(ops, 'pose_backward_moments', forced('indefinite'))
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        g = head.gradient(*xs, y=y, v=v, needs=needs)
+    assert float(g[3][0].abs().max()) > 0 and float(g[3][1].abs().max()) > 0 and bool(torch.isfinite(g[8]).all())
+    monkeypatch.setattr(ops, 'pose_backward_moments', real)
+    want0 = head.gradient(*xs, y=y, v=v, needs=needs)[3][0]
+    assert torch.equal(g[3][0], want0)                                          # the regular row is untouched by the other row's fallback
+    monkeypatch.setattr(ops, 'pose_backward_moments', forced('singular'))
+    with pytest.warns(UserWarning, match='positive definite'):
+        g = head.gradient(*xs, y=y, v=v, needs=needs)
+    assert float(g[3].abs().max()) == 0.0 and float(g[8].abs().max()) == 0.0
