@@ -210,6 +210,13 @@ def run_sequence(args, rank, world, dev, dist):
             warnings.simplefilter('ignore')                 # unrelated synthetic frames: many pairs fail the |log| gate
             return tracker.track(F, rank, world)
     elapsed, (poses, rel, ok) = timed_region(step, args.steps, args.warmup, dev, dist)
+    # every rank must hold the SAME trajectory after the all-gather + prefix product: MIN and MAX over ranks of a checksum agree
+    chk = torch.nan_to_num(poses.double()).mul(torch.arange(1, poses.numel() + 1, device=dev, dtype=torch.float64).reshape(poses.shape)).sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
     return {
         'metric': 'sequence tracking frames/sec (640x512, frame-to-frame, L-BFGS 20), frames sharded over ranks + RCCL all-gather',
         'value': F * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -220,6 +227,7 @@ def run_sequence(args, rank, world, dev, dist):
                                f'batch 1 per frame, {args.raft_iters} GRU iters, {args.solver} x20 solve, one all-gather of (frames,8) f32',
                    'frames': F, 'frames_per_gpu': Fg, 'parallelism': f'sequence blocks x{world}'},
         'poses_finite': bool(torch.isfinite(poses).all()), 'pairs_accepted': int(ok.sum()), 'poses_shape': list(poses.shape),
+        'poses_equal_on_all_ranks': bool(float(lo) == float(hi)), 'poses_checksum': float(chk),
     }
 
 

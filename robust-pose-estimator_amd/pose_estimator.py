@@ -72,7 +72,8 @@ class PoseEstimator(torch.nn.Module):
         self.register_buffer('intrinsics', intrinsics.unsqueeze(0).float(), persistent=False)
         self.register_buffer('scale', torch.tensor(1 / config['depth_clipping'][1]), persistent=False)
         self.register_buffer('baseline', torch.tensor(baseline).unsqueeze(0).float(), persistent=False)
-        self.last_pose = SE3.Identity(1) if init_pose is None else init_pose.float()
+        self._init_pose = SE3.Identity(1) if init_pose is None else init_pose.float()
+        self.last_pose = self._init_pose
         self.frame = None
         self.last_frame = None
         # streaming: encoder outputs of the current left image, reused as image1l's on the next call (exact: both
@@ -83,6 +84,13 @@ class PoseEstimator(torch.nn.Module):
     @property
     def device(self):
         return self.intrinsics.device
+
+    def reset(self):
+        """Forget the sequence (frames, chained pose, cached encoder outputs): the next call is a first frame again."""
+        self.last_pose = self._init_pose
+        self.frame = self.last_frame = None
+        self._enc_cache = None
+        return self
 
     @torch.no_grad()
     def forward(self, limg, rimg, mask):

@@ -79,25 +79,40 @@ def track_sharded(n_frames, run_block, chain_fn, rank=0, world=1, group=None, sc
 
 class SequenceTracker:
     """GPU driver of track_sharded on top of PoseEstimator: every rank walks its block of frames one at a time
-    (the reference's per-frame semantics, batch 1), starting from the halo frame."""
+    (the reference's per-frame semantics, batch 1), starting from the halo frame.  The estimator is built ONCE per tracker
+    (model build / weight load / GPU allocation) and reset between blocks."""
 
-    def __init__(self, make_estimator, get_frame):
-        """make_estimator() -> a fresh PoseEstimator on this rank's GPU; get_frame(t) -> (limg, rimg, mask)."""
+    def __init__(self, make_estimator, get_frame, flow2depth=None, chain=None):
+        """make_estimator() -> a PoseEstimator on this rank's GPU (called once, lazily); get_frame(t) -> (limg, rimg, mask).
+        ``flow2depth(flow, baseline) -> (depth, valid)`` and ``chain(rel, scale) -> poses`` default to the HIP entry points
+        (rpe_flow2depth, rpe_se3_chain); the CPU tests inject the oracle's so that the same driver runs without a GPU."""
         self.make_estimator, self.get_frame = make_estimator, get_frame
+        self._flow2depth, self._chain = flow2depth, chain
+        self._est = None
+
+    @property
+    def estimator(self):
+        if self._est is None:
+            self._est = self.make_estimator()
+        return self._est
 
     def run_block(self, first_pair, last_pair):
-        from . import ops
-        est = self.make_estimator()
+        est = self.estimator
+        est.reset()
         rels, oks = [], []
         if last_pair <= first_pair:
             dev = est.device
             return torch.zeros(0, 7, device=dev), torch.zeros(0, dtype=torch.bool, device=dev)
+        flow2depth = self._flow2depth
+        if flow2depth is None:
+            from . import ops
+            flow2depth = ops.flow2depth
         l, r, m = self.get_frame(first_pair)
         est(l, r, m)                                   # halo / first frame: stereo depth only
         if first_pair > 0:
             # in the serial run this frame was the "current" frame of pair first_pair-1, whose infer() ANDed its
             # mask with the stereo validity (pose_net.py:77); reproduce that for the halo frame
-            _, valid = ops.flow2depth(est.frame.flow, est.baseline * est.scale)
+            _, valid = flow2depth(est.frame.flow, est.baseline * est.scale)
             est.frame.mask &= valid
         for t in range(first_pair, last_pair):
             l, r, m = self.get_frame(t + 1)
@@ -107,11 +122,14 @@ class SequenceTracker:
         return torch.cat(rels), torch.cat(oks)
 
     def track(self, n_frames, rank=0, world=1, group=None, scale=None):
-        """``scale`` defaults to the depth-clipping distance of the estimators this tracker builds."""
-        from . import ops
-        est_scale = float(self.make_estimator().config['depth_clipping'][1])     # the distance PoseEstimator normalises by (pose_estimator.py:40-43)
+        """``scale`` defaults to the depth-clipping distance of the estimator this tracker builds."""
+        est_scale = float(self.estimator.config['depth_clipping'][1])     # the distance PoseEstimator normalises by (pose_estimator.py:40-43)
         if scale is None:
             scale = est_scale
         elif abs(scale - est_scale) > 1e-6 * est_scale:
             raise ValueError(f'SequenceTracker.track: scale {scale} != the estimator\'s depth_clipping {est_scale}')
-        return track_sharded(n_frames, self.run_block, lambda rel, s: ops.se3_chain(rel, scale=s), rank, world, group, scale)
+        chain = self._chain
+        if chain is None:
+            from . import ops
+            chain = lambda rel, s: ops.se3_chain(rel, scale=s)
+        return track_sharded(n_frames, self.run_block, chain, rank, world, group, scale)

@@ -129,3 +129,95 @@ def test_bench_refuses_mismatched_world_size():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64'], env=env, capture_output=True, text=True)
     assert r.returncode == 2 and 'GPU(s) are visible' in r.stderr
+
+
+# ------------------------------------------------------------------------------------ SequenceTracker itself, world size 4
+class _FrameProxy:
+    def __init__(self, d):
+        object.__setattr__(self, '_d', d)
+
+    def __getattr__(self, k):
+        return self._d[k]
+
+    def __setattr__(self, k, v):
+        self._d[k] = v
+
+
+class _OracleEstimator:
+    """oracle.tracker.PoseEstimator behind the interface SequenceTracker drives (the product PoseEstimator's): callable per
+    frame, ``reset``, ``frame.flow / .mask``, ``baseline``, ``scale``, ``last_rel_pose.data``, ``success``, ``config``, ``device``."""
+
+    def __init__(self, model, K, bf):
+        self._args = (model, K, bf)
+        self.config = {'depth_clipping': [1, 250.0]}
+        self.device = torch.device('cpu')
+        self.reset()
+
+    def reset(self):
+        from oracle import tracker
+        self._t = tracker.PoseEstimator(*self._args)
+        self.baseline, self.scale = self._t.baseline, self._t.scale
+        return self
+
+    def __call__(self, l, r, m):
+        from types import SimpleNamespace
+        self._t.forward(l, r, m)
+        self.success = self._t.success[-1]
+        self.last_rel_pose = SimpleNamespace(data=self._t.rel_poses[-1])
+
+    @property
+    def frame(self):
+        return _FrameProxy(self._t.frame)
+
+
+def _oracle_tracker(n_frames):
+    import rpe_amd.sharding as sh
+    from oracle import pose_net as opn
+    from oracle import tracker, warp
+    from rpe_amd import synth
+    h, w = 128, 160
+    cfg = synth.model_config(h, w, iters=3, lbgfs_iters=4, use_weights=False)
+    torch.manual_seed(0)
+    model = synth.init_synthetic_weights(opn.PoseNet(cfg)).eval()
+    fr = synth.stereo_frames(123, n_frames, h, w)
+    get = lambda t: (fr['image2l'][t:t + 1], fr['image2r'][t:t + 1], fr['mask2'][t:t + 1].clone())
+    make = lambda: _OracleEstimator(model, fr['K'][0], 7.2 * 250.0)
+    return sh.SequenceTracker(make, get, flow2depth=warp.flow2depth, chain=tracker.chain)
+
+
+def _worker_seq(rank, world, port, n_frames, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    tr = _oracle_tracker(n_frames)
+    built = []
+    real = tr.make_estimator
+    tr.make_estimator = lambda: (built.append(1), real())[1]
+    poses, rel, ok = tr.track(n_frames, rank, world)
+    tr.run_block(0, 0)                                        # a second block on the same tracker: no second estimator
+    out[rank] = (poses, rel, ok, len(built))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_frames', [4, 6])
+def test_sequence_tracker_four_ranks_uneven_blocks(n_frames):
+    """SequenceTracker (the driver bench.py --mode sequence runs) over four gloo ranks with the ORACLE as the per-pair solver:
+    4 frames = 3 pairs (one rank has no pair at all), 6 frames = 5 pairs (blocks of 2, 1, 1, 1).  Every rank ends with the serial
+    trajectory; the halo handling (stereo validity ANDed into the halo frame's mask) makes the relative poses those of the
+    serial run; the estimator is built once per rank."""
+    world = 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_seq, args=(world, _free_port(), n_frames, out), nprocs=world, join=True)
+    torch.set_num_threads(2)
+    serial, rel_s, ok_s = _oracle_tracker(n_frames).track(n_frames)
+    assert serial.shape == (n_frames, 7) and bool(torch.isfinite(serial).all())
+    for r in range(world):
+        poses, rel, ok, built = out[r]
+        assert built == 1
+        assert torch.equal(ok, ok_s) and float((rel - rel_s).abs().max()) <= 1e-6
+        assert float((poses - serial).abs().max()) <= 1e-3 * max(1.0, float(serial.abs().max()))
+        assert torch.equal(poses, out[0][0])                  # bitwise the same trajectory on every rank
