@@ -96,6 +96,13 @@ class ResidualBlock(nn.Module):
         return conv_norm_act(self.conv2, self.norm2, y, relu=True, residual=x)
 
 
+def _bounded_put(cache, key, value, keep=2):
+    """Insert into a small insertion-ordered cache, evicting the oldest entries (and the buffers / launch descriptors they pin)."""
+    while len(cache) >= keep:
+        cache.pop(next(iter(cache)))
+    cache[key] = value
+
+
 def _bn_affine(conv, norm):
     """Eval-mode BatchNorm2d folded with the conv bias: y = conv_nobias(x) * scale + shift (cached per module)."""
     key = tuple(t._version for t in (conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var)) + (norm.weight.data_ptr(),)
@@ -324,8 +331,9 @@ class BasicMotionEncoder(nn.Module):
             return F.conv2d(x, m.weight, None, m.stride, m.padding)
         if packed is not None:
             key = (corr.data_ptr(), cat_buf.data_ptr(), hx.data_ptr(), rhx.data_ptr(), tuple(corr.shape))
-            calls = packed.get('_enc_calls')
-            if calls is None or calls[0] != key:                      # descriptors checked once per buffer set (the 12 iterations reuse it)
+            cache = packed.setdefault('_enc_calls', {})               # one entry per workspace (a tracker alternates between batch n and 2n)
+            calls = cache.get(key)
+            if calls is None:                                         # descriptors checked once per buffer set (the 12 iterations reuse it)
                 cor = packed['cor_buf'](corr)
                 flo = packed['flo_buf'](corr)
                 wino = packed['wino'] if corr.shape[-1] % 2 == 0 and corr.shape[-2] % 2 == 0 else {}
@@ -338,7 +346,7 @@ class BasicMotionEncoder(nn.Module):
                          ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, cor, prepare=True),
                          c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
                          c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
-                packed['_enc_calls'] = calls
+                _bounded_put(cache, key, calls)
             _, cor, flo_buf, c1, c2, f2, cv_ = calls
             c1(); c2()
             if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '64')):    # (the library wins only on tiny maps)
@@ -425,10 +433,10 @@ class BasicUpdateBlock(nn.Module):
                 P['ctx_' + n] = (ops.PackedWino1d if WINOGRAD else ops.PackedConv)(W[n][1], W[n][2])
             scratch = {}
 
-            def buf(name, like, c):                            # per-shape scratch for intermediate activations
+            def buf(name, like, c):                            # per-shape scratch for intermediate activations (two shapes kept, like RAFT._ws)
                 k = (name, like.shape[0], c, like.shape[2], like.shape[3], like.device)
                 if k not in scratch:
-                    scratch[k] = torch.empty(like.shape[0], c, like.shape[2], like.shape[3], device=like.device)
+                    _bounded_put(scratch, k, torch.empty(like.shape[0], c, like.shape[2], like.shape[3], device=like.device), keep=6)
                 return scratch[k]
             P['cor_buf'] = lambda like: buf('cor', like, 256)
             P['fh_buf'] = lambda like: buf('fh', like, 256)
@@ -453,8 +461,9 @@ class BasicUpdateBlock(nn.Module):
             #   z = s(convz hx + ctx), r*h -> rhx ;  h <- (1-z) h + z tanh(convq rhx + ctx)   (in place on hx[:, :c])
             key = (hx.data_ptr(), rhx.data_ptr(), z_buf.data_ptr(), tuple(ctx[k].data_ptr() for k in ('zr1', 'q1', 'zr2', 'q2')), tuple(hx.shape),
                    (coords1.data_ptr(), flow.data_ptr()) if in_place else None)
-            calls = P.get('_gru_calls')
-            if calls is None or calls[0] != key:
+            cache = P.setdefault('_gru_calls', {})
+            calls = cache.get(key)
+            if calls is None:
                 seq = []
                 gconv = ops.conv_wino1d if isinstance(P['zr1'], ops.PackedWino1d) else ops.conv_fused
                 for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
@@ -468,7 +477,8 @@ class BasicUpdateBlock(nn.Module):
                 if in_place:
                     seq.append(ops.flow_update(P['fh_buf'](hx), fh.conv2.weight, fh.conv2.bias.detach(), coords1, coords1, flow_out=flow,
                                                dst1=hx[:, 2 * c - 2:], dst2=rhx[:, 2 * c - 2:], prepare=True))
-                P['_gru_calls'] = calls = (key, seq)
+                calls = (key, seq)
+                _bounded_put(cache, key, calls)
             if in_place:
                 for launch in calls[1]:
                     launch()
