@@ -320,6 +320,12 @@ int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
  *   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y,0); if (residual) y = max(residual + y, 0).  out may alias x. */
 int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                        const float *residual, float *out, void *stream);
+/* The same with a residual that is itself the RAW output of an instance-normalised convolution: residual_mean_inv (b,c,2) =
+ * (mean, 1/sqrt(var + eps)) from rpe_instnorm_finalize, and the residual term becomes relu((residual - mean) * inv) -- the first
+ * residual block of fnet then reads the stem's raw output twice (as input through `pre_norm`, as shortcut through this) and the
+ * stem's normalised output is never written (BasicEncoder.forward: relu1(norm1(conv1 x)) -> layer1, core/RAFT/core/extractor.py). */
+int rpe_instnorm_apply_ex(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
+                          const float *residual, const float *residual_mean_inv, float *out, void *stream);
 /* mean_inv (b,c,2) = (mean, 1/sqrt(var + eps)) of each plane from the same partial sums: the `pre_norm` input of the
  * next rpe_conv_fused, which then normalises its input on the fly (no separate pass for norm1 + ReLU of a ResidualBlock). */
 int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw, float eps, float *mean_inv, void *stream);

@@ -78,6 +78,7 @@ SIGNATURES = {
     'rpe_conv_wino1d': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
+    'rpe_instnorm_apply_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp, _vp]),
     'rpe_instnorm_finalize': (_i, [_vp, _i, _i, _i, _i, _c.c_float, _vp, _vp]),
     'rpe_unet_params_floats': (_sz, [_i]),
     'rpe_unet_workspace_bytes': (_sz, [_i, _i, _i]),

@@ -525,8 +525,11 @@ __global__ __launch_bounds__(64) void k_instnorm_finalize(const float* __restric
 // Instance norm from the per-tile (n, mean, M2) records k_conv_igemm / k_stem7x7 left behind: one workgroup per (b, c)
 // plane combines them in f64 (biased variance), then normalises in ONE read + write pass:
 //   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y, 0); if (residual) y = max(residual + y, 0)
+// ``res_mi`` (b, C, 2) = (mean, 1/std) of the residual's own instance norm: the residual is then the RAW output of an earlier
+// convolution and relu((r - mean) * inv) is applied to it here (the stem's normalised output never exists as a tensor).
 __global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict__ x, const float* __restrict__ partials, int tiles, int C, int hw,
-                                                        float eps, int relu, const float* __restrict__ residual, float* __restrict__ out) {
+                                                        float eps, int relu, const float* __restrict__ residual, const float* __restrict__ res_mi,
+                                                        float* __restrict__ out) {
     const int plane = blockIdx.x;
     __shared__ double sh[8];
     double dmean, dvar;
@@ -535,10 +538,15 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict_
     const float4* xp = (const float4*)(x + (size_t)plane * hw);
     const float4* rp = residual ? (const float4*)(residual + (size_t)plane * hw) : nullptr;
     float4* op = (float4*)(out + (size_t)plane * hw);
+    const bool rnorm = res_mi != nullptr;
+    const float rmean = rnorm ? res_mi[(size_t)plane * 2] : 0.0f, rinv = rnorm ? res_mi[(size_t)plane * 2 + 1] : 1.0f;
     auto fin = [&](float v, float r) -> float {
         float y = (v - mean) * inv;
         if (relu) y = y < 0.0f ? 0.0f : y;
-        if (rp) { y = r + y; y = y < 0.0f ? 0.0f : y; }
+        if (rp) {
+            if (rnorm) { r = (r - rmean) * rinv; r = r < 0.0f ? 0.0f : r; }
+            y = r + y; y = y < 0.0f ? 0.0f : y;
+        }
         return y;
     };
     for (int i = threadIdx.x; i < (hw >> 2); i += blockDim.x) {
@@ -647,12 +655,18 @@ extern "C" int rpe_conv_stats_tiles(int cout, int h, int w, int stride) {
     return ceil_div((int64_t)h * w, conv_wide(cout) ? 256 : 128);     // (a statistics launch is never a "small" 64x64 one)
 }
 
+extern "C" int rpe_instnorm_apply_ex(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,
+                                     const float* residual, const float* residual_mean_inv, float* out, void* stream) {
+    if (!x || !partials || !out || tiles == 0 || b <= 0 || c <= 0 || hw <= 0 || (residual_mean_inv && !residual)) return RPE_E_BADARG;
+    if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, c, hw, eps, relu, residual,
+                       residual_mean_inv, out);
+    return rpe_check_launch();
+}
+
 extern "C" int rpe_instnorm_apply(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,
                                   const float* residual, float* out, void* stream) {
-    if (!x || !partials || !out || tiles == 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
-    if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, c, hw, eps, relu, residual, out);
-    return rpe_check_launch();
+    return rpe_instnorm_apply_ex(x, partials, tiles, b, c, hw, eps, relu, residual, nullptr, out, stream);
 }
 
 extern "C" int rpe_instnorm_finalize(const float* partials, int tiles, int b, int c, int hw, float eps, float* mean_inv, void* stream) {

@@ -61,11 +61,20 @@ class ResidualBlock(nn.Module):
             self.norm3 = _norm(norm_fn, planes)
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
-    def forward(self, x):
+    def takes_raw_input(self, x):
+        """Can this block read its input as the RAW output of an instance-normalised convolution (+ its (mean, 1/std)), i.e. run
+        conv1 with the loader-side normalisation and normalise the shortcut inside the last pass?  (fnet's first block behind the stem.)"""
+        return (isinstance(self.norm1, nn.InstanceNorm2d) and self.downsample is None and _fusable(self.conv1, x) and x.shape[-1] % 4 == 0
+                and _wino(self.conv1, x) is not None)
+
+    def forward(self, x, x_norm=None):
         """relu(x' + relu(norm2(conv2(relu(norm1(conv1 x)))))), x' = x or norm3(conv1x1 x); every convolution with its
         (bias, norm, ReLU, residual) epilogue fused (conv_norm_act).  With instance norm (fnet) norm1 + ReLU never exist
-        as a tensor: conv1 leaves its raw output and partial sums, and conv2 normalises that input while staging it."""
+        as a tensor: conv1 leaves its raw output and partial sums, and conv2 normalises that input while staging it.
+        ``x_norm`` (b,c,2): x is a raw convolution output whose relu((x - mean) * inv) is this block's real input (takes_raw_input)."""
         fused_in = isinstance(self.norm1, nn.InstanceNorm2d) and _fusable(self.conv1, x) and x.shape[-1] // self.conv1.stride[0] % 4 == 0
+        if x_norm is not None and not (fused_in and self.takes_raw_input(x)):
+            raise RuntimeError('ResidualBlock: x_norm needs the fused stride-1 Winograd route')
         if fused_in:
             b, _, hh, ww = x.shape
             st = self.conv1.stride[0]
@@ -73,7 +82,7 @@ class ResidualBlock(nn.Module):
             raw1 = torch.empty(b, self.conv1.out_channels, hh // st, ww // st, device=x.device)
             if w1 is not None:                                 # stride 1: Winograd, moments per 16x8-pixel patch
                 stats1 = ops.conv_wino_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device)
-                ops.conv_wino(x, w1, ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1)
+                ops.conv_wino(x, w1, ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1, pre_norm=x_norm)
             else:
                 stats1 = ops.conv_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device, stride=st)
                 ops.conv_fused(x, _packed(self.conv1), ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1, stride=st)
@@ -89,7 +98,7 @@ class ResidualBlock(nn.Module):
             else:
                 stats2 = ops.conv_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
                 ops.conv_fused(raw1, _packed(self.conv2), ops.CONV_LINEAR, raw2, bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
-            return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x)
+            return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x, residual_norm=x_norm)
         y = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         if self.downsample is not None:
             x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
@@ -246,8 +255,10 @@ class BasicEncoder(nn.Module):
                 ops.stem_conv(im.contiguous(), ps, bias=self.conv1.bias.detach(), relu=False, stats=stats[i:i + k], out=out[i:i + k])
             i += k
         if bn:
-            return out
-        return ops.instnorm_apply(out, stats, eps=self.norm1.eps, relu=True)
+            return out, None
+        if self.layer1[0].takes_raw_input(out):               # norm1 + ReLU happen inside layer1's first block (its loader and its last pass)
+            return out, ops.instnorm_finalize(stats, (hh // 2) * (ww // 2), eps=self.norm1.eps)
+        return ops.instnorm_apply(out, stats, eps=self.norm1.eps, relu=True), None
 
     def _final(self, x, split_act):
         """conv2, the 1x1 output layer (128 -> output_dim), on the implicit GEMM.  ``split_act`` (the context encoder as RAFT uses
@@ -279,12 +290,14 @@ class BasicEncoder(nn.Module):
         first = x[0] if many else x
         hh, ww = first.shape[-2:]
         stem_ok = raw255 and hh % 2 == 0 and ww % 2 == 0 and ((hh // 2) * (ww // 2)) % 4 == 0 and isinstance(self.norm1, (nn.BatchNorm2d, nn.InstanceNorm2d))
+        x_norm = None
         if stem_ok:
-            x = self._stem_many(list(x) if many else [x])
+            x, x_norm = self._stem_many(list(x) if many else [x])
         else:
             x = (torch.cat(list(x), dim=0) if many else x).contiguous()
             x = conv_norm_act(self.conv1, self.norm1, 2 * (x / 255.0) - 1.0 if raw255 else x, relu=True)
-        x = self.layer3(self.layer2(self.layer1(x)))
+        x = self.layer1[1](self.layer1[0](x, x_norm))
+        x = self.layer3(self.layer2(x))
         return self._final(x, split_act)
 
 

@@ -622,3 +622,30 @@ def test_gru_gates_on_saturated_state_and_large_flow(rpe, impl):
     hnew = (1 - g_z.cpu().double()) * hid + g_z.cpu().double() * q
     assert bool(torch.isfinite(g_hx).all()) and float(g_hx[:, :c].abs().max()) <= 1.0 + 1e-6
     assert float((g_hx[:, :c].cpu().double() - hnew).abs().max()) < _tol(hx, wq) * (2 if impl == 'winograd' else 1) + 4e-6
+
+
+def test_instnorm_apply_with_a_raw_residual(rpe):
+    """rpe_instnorm_apply_ex: the shortcut of fnet's first residual block is the stem's RAW output, normalised + ReLU'd while the
+    block's last pass reads it -- against the f64 evaluation, and bit-identical to normalising the shortcut in a pass of its own."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(9)
+    b, c, h, w = 2, 64, 32, 48
+    x, wt, bias = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, s=0.5)
+    res_raw = _rand(rng, b, c, h, w, s=2.0) + 1.0
+    rm, rv = res_raw.double().mean((2, 3), keepdim=True), res_raw.double().var((2, 3), unbiased=False, keepdim=True)
+    res_mi = torch.stack(((rm[:, :, 0, 0]).float(), (1 / torch.sqrt(rv[:, :, 0, 0] + 1e-5)).float()), dim=-1).contiguous().cuda()
+    pw = ops.PackedWino(wt.cuda(), None)
+    stats = ops.conv_wino_stats_buffer(b, c, h, w, 'cuda')
+    raw = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=stats)
+    got = ops.instnorm_apply(raw.clone(), stats, eps=1e-5, relu=True, residual=res_raw.cuda(), residual_norm=res_mi)
+    pre = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    shortcut = ((res_raw.double() - rm) / torch.sqrt(rv + 1e-5)).clamp_min(0)
+    ref = (shortcut + ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)).clamp_min(0)
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert float((got.cpu().double() - ref).abs().max()) < (3 * _tol(x, wt) + 2e-6) * inv * 2 + 2e-6
+    own = ((res_raw.cuda() - res_mi[..., 0][:, :, None, None]) * res_mi[..., 1][:, :, None, None]).clamp_min(0)
+    two_pass = ops.instnorm_apply(raw.clone(), stats, eps=1e-5, relu=True, residual=own)
+    assert torch.equal(got, two_pass)
+    with pytest.raises(rpe.RpeError):
+        ops.instnorm_apply(raw.clone(), stats, residual_norm=res_mi)              # a norm without a residual
