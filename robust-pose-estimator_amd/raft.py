@@ -35,6 +35,11 @@ import torch.nn.functional as F
 from . import ops
 
 WINOGRAD = os.environ.get('RPE_WINOGRAD', '1') != '0'      # 3x3 layers of the update block as F(2x2,3x3) (A/B switch for measurements)
+# The motion encoder's flow branch (convf1 -> convf2) on a side stream beside lookup -> convc1 -> convc2.  Measured (MI355X, 640x512):
+# batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
+# launch fills the chip on its own), so it is used for small passes only.  RPE_SIDE_STREAM=0 switches it off.
+SIDE_STREAM = os.environ.get('RPE_SIDE_STREAM', '1') != '0'
+SIDE_STREAM_MAX = 8 * 5120                                     # queries per pass (batch * h/8 * w/8) up to which the side stream is used
 
 
 def _norm(kind, ch):
@@ -336,37 +341,52 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
-    def forward(self, flow, corr, cat_buf, hx, rhx, packed=None, flow_in_place=False):
+    def _calls(self, corr, cat_buf, hx, rhx, packed):
+        """Prepared launchers of the fused route for one buffer set (descriptors checked once; the 12 iterations reuse them)."""
+        key = (corr.data_ptr(), cat_buf.data_ptr(), hx.data_ptr(), rhx.data_ptr(), tuple(corr.shape))
+        cache = packed.setdefault('_enc_calls', {})               # one entry per workspace (a tracker alternates between batch n and 2n)
+        calls = cache.get(key)
+        if calls is None:
+            cor = packed['cor_buf'](corr)
+            flo = packed['flo_buf'](corr)
+            wino = packed['wino'] if corr.shape[-1] % 2 == 0 and corr.shape[-2] % 2 == 0 else {}
+
+            def c3(name, x, out, out2=None):            # a 3x3 layer: Winograd when available, else the direct implicit GEMM
+                if name in wino:
+                    return ops.conv_wino(x, wino[name], ops.CONV_RELU, out, out2=out2, prepare=True)
+                return ops.conv_fused(x, packed[name], ops.CONV_RELU, out, out2=out2, prepare=True)
+            calls = (key, cor, flo,
+                     ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, cor, prepare=True),
+                     c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
+                     c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
+            _bounded_put(cache, key, calls)
+        return calls
+
+    def flow_branch(self, flow, corr, cat_buf, hx, rhx, packed):
+        """convf1 -> convf2 (fused route): depends on the flow only, not on the correlation lookup, so RAFT.forward may run it on a
+        side stream beside lookup -> convc1 -> convc2."""
+        _, cor, flo_buf, c1, c2, f2, cv_ = self._calls(corr, cat_buf, hx, rhx, packed)
+        if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '64')):    # (the library wins only on tiny maps)
+            ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
+        else:
+            ops.bias_act(F.conv2d(flow, self.convf1.weight, None, self.convf1.stride, self.convf1.padding), self.convf1.bias, out=flo_buf)
+        f2()
+
+    def forward(self, flow, corr, cat_buf, hx, rhx, packed=None, flow_in_place=False, flow_branch_done=None):
         """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [128,256) of hx and rhx.
         ``packed`` (BasicUpdateBlock.packed_convs) selects the fused HIP convolutions (conv + bias + ReLU + cat in
-        one kernel each); otherwise the library convolution runs without bias and rpe_bias_act does the rest."""
+        one kernel each); otherwise the library convolution runs without bias and rpe_bias_act does the rest.
+        ``flow_branch_done``: an event recorded behind flow_branch() on another stream (it then is not run here)."""
         def cv(m, x):
             return F.conv2d(x, m.weight, None, m.stride, m.padding)
         if packed is not None:
-            key = (corr.data_ptr(), cat_buf.data_ptr(), hx.data_ptr(), rhx.data_ptr(), tuple(corr.shape))
-            cache = packed.setdefault('_enc_calls', {})               # one entry per workspace (a tracker alternates between batch n and 2n)
-            calls = cache.get(key)
-            if calls is None:                                         # descriptors checked once per buffer set (the 12 iterations reuse it)
-                cor = packed['cor_buf'](corr)
-                flo = packed['flo_buf'](corr)
-                wino = packed['wino'] if corr.shape[-1] % 2 == 0 and corr.shape[-2] % 2 == 0 else {}
-
-                def c3(name, x, out, out2=None):            # a 3x3 layer: Winograd when available, else the direct implicit GEMM
-                    if name in wino:
-                        return ops.conv_wino(x, wino[name], ops.CONV_RELU, out, out2=out2, prepare=True)
-                    return ops.conv_fused(x, packed[name], ops.CONV_RELU, out, out2=out2, prepare=True)
-                calls = (key, cor, flo,
-                         ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, cor, prepare=True),
-                         c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
-                         c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
-                _bounded_put(cache, key, calls)
-            _, cor, flo_buf, c1, c2, f2, cv_ = calls
+            _, cor, flo_buf, c1, c2, f2, cv_ = self._calls(corr, cat_buf, hx, rhx, packed)
             c1(); c2()
-            if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '64')):    # (the library wins only on tiny maps)
-                ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
+            if flow_branch_done is None:
+                self.flow_branch(flow, corr, cat_buf, hx, rhx, packed)
             else:
-                ops.bias_act(cv(self.convf1, flow), self.convf1.bias, out=flo_buf)
-            f2(); cv_()
+                torch.cuda.current_stream().wait_event(flow_branch_done)
+            cv_()
         else:
             cor = ops.bias_act(cv(self.convc1, corr), self.convc1.bias)
             ops.bias_act(cv(self.convc2, cor), self.convc2.bias, out=cat_buf, out_offset=0)
@@ -457,7 +477,7 @@ class BasicUpdateBlock(nn.Module):
             self._packed = (key, P)
         return self._packed[1]
 
-    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=False):
+    def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=False, flow_branch_done=None):
         """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
         Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (h_buf is written by the library
         path only: the fused flow head reads the slice directly).  ``in_place`` (fused route only): ``coords1`` and ``flow`` are
@@ -467,7 +487,7 @@ class BasicUpdateBlock(nn.Module):
         P = self.packed_convs(hx.shape[-1])
         if in_place and P is None:
             raise RuntimeError('in_place update needs the fused route')
-        self.encoder(flow, corr, cat_buf, hx, rhx, packed=P, flow_in_place=in_place)
+        self.encoder(flow, corr, cat_buf, hx, rhx, packed=P, flow_in_place=in_place, flow_branch_done=flow_branch_done)
         fh = self.flow_head
         if P is not None:
             # each GRU half = two implicit-GEMM convolutions whose epilogues are the gates:
@@ -566,6 +586,13 @@ class RAFT(nn.Module):
             if isinstance(m, nn.BatchNorm2d):
                 m.eval()
 
+    def _side_stream(self, device):
+        s = getattr(self, '_side', None)
+        if s is None or s[0].device != device:
+            with torch.cuda.device(device):
+                self._side = s = (torch.cuda.Stream(device=device), torch.cuda.Event(), torch.cuda.Event())
+        return s
+
     def _pyramid(self, b, h8, w8, device):
         p = self._pyr
         if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device:
@@ -642,10 +669,21 @@ class RAFT(nn.Module):
             ops.copy_planes(ws['zero2'], rhx[:, 2 * c - 2:])
         else:
             coords1 = coords0.clone()
+        side = self._side_stream(dev) if fused and SIDE_STREAM and N * h8 * w8 <= SIDE_STREAM_MAX else None
         for itr in range(iters):
+            done = None
+            if side is not None:
+                # the motion encoder's flow branch (convf1 -> convf2) needs only the flow: it runs on a side stream beside
+                # lookup -> convc1 -> convc2 and fills the partly idle last rounds of those launches
+                stream, ev_flow, done = side
+                ev_flow.record()
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ev_flow)
+                    self.update_block.encoder.flow_branch(flow, corr, cat_buf, hx, rhx, self.update_block.packed_convs(w8))
+                    done.record()
             pyr.lookup(coords1, out=corr)
             if fused:
-                self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=True)
+                self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=True, flow_branch_done=done)
             else:
                 flow = coords1 - coords0
                 coords1 = self.update_block.step(hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1)
