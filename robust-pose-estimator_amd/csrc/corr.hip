@@ -115,30 +115,41 @@ __device__ __forceinline__ void scatter_level(const float* __restrict__ src, int
     const int x0 = px * PW, y0 = band * R;
     const unsigned rowB = (unsigned)wp * 32;                      // bytes per pyramid row; a level of one batch item is < 4 GB
     char* lv = (char*)lvl + (size_t)bz * G.ngroups * hl * rowB;
-    // Slot t = (g*R + yy)*S + s of query k = tid & 7 is visited by thread (t & 31) in iteration t >> 5, so that consecutive
-    // lanes store consecutive floats.  (row = g*R + yy, s) advance incrementally: no division in the loop.
-    const int k = tid & 7, kq = k >> L;
-    int s = (tid >> 3) % S, row = (tid >> 3) / S;
-    constexpr int NIT = (8 * R * S + 31) / 32;
-#pragma unroll 4
+    // Item u = 2 * t + half: slot t = (g*R + yy)*S + s, queries k = 4*half .. 4*half+3 -- one 16-byte piece of the slot's 32 bytes.
+    // Consecutive lanes take consecutive pieces (coalesced 16-byte stores); a piece whose four queries all have something to write
+    // (data of this patch, or the zero padding outside the map) leaves as ONE store, the pieces at the patch's skewed edges --
+    // where some of the four columns belong to the neighbouring patch -- as up to four 4-byte stores.  (Round 2 moved one float per
+    // lane and iteration: 4x the iterations of this loop, whose index arithmetic -- not the stores -- is what the epilogue costs.)
+    constexpr int NITEM = 2 * 8 * R * S, NIT = (NITEM + 255) / 256;
+#pragma unroll 1
     for (int it = 0; it < NIT; ++it) {
+        const int u = tid + 256 * it;
+        const int half = u & 1, t = u >> 1;
+        const int row = t / S, sl = t - row * S;                  // (S is a compile-time constant: multiply-shift)
         const int g = row / R, yy = row % R;                      // (R is a power of two)
-        const int y = y0 + yy, xs = x0 + s, Gi = g0 + g;
-        const int xx = s - SK + kq, x = x0 + xx;
-        const bool valid = (row < 8 * R) & (Gi < G.ngroups) & (y < hl) & (xs < wp);
-        const bool data = (xx >= 0) & (xx < PW) & (x < wl), zero = (x < 0) | (x >= wl);
-        if (valid & (data | zero)) {                              // else: inside the map but another patch's column
-            const float v = data ? src[(g * 8 + k) * pitch + yy * PW + xx] : 0.0f;
-            *(float*)(lv + (size_t)(((unsigned)(Gi * hl + y) * (unsigned)wp + (unsigned)xs) * 32u + (unsigned)k * 4u)) = v;
+        const int y = y0 + yy, xs = x0 + sl, Gi = g0 + g;
+        const bool valid = (u < NITEM) & (Gi < G.ngroups) & (y < hl) & (xs < wp);
+        float v[4]; bool wr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * half + e;
+            const int xx = sl - SK + (k >> L), x = x0 + xx;
+            const bool data = (xx >= 0) & (xx < PW) & (x < wl), zero = (x < 0) | (x >= wl);
+            v[e] = (valid & data) ? src[(g * 8 + k) * pitch + yy * PW + xx] : 0.0f;
+            wr[e] = valid & (data | zero);                        // else: inside the map but another patch's column
         }
-        s += 32 % S; row += 32 / S;
-        if (s >= S) { s -= S; row += 1; }
+        float* dst = (float*)(lv + (size_t)(((unsigned)(Gi * hl + y) * (unsigned)wp + (unsigned)xs) * 32u + (unsigned)half * 16u));
+        if (wr[0] & wr[1] & wr[2] & wr[3]) *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (wr[e]) dst[e] = v[e];
+        }
     }
     if (px == G.npx - 1) {                                       // row padding right of the last patch's slots: zeros
         const int xe = x0 + S, ne = wp - xe;                      // x' in [xe, wp): x >= x0 + PW >= w_l for every k
         if (ne > 0) {
             for (int idx = tid; idx < 8 * R * ne * 8; idx += 256) {
-                const int t = idx >> 3;
+                const int t = idx >> 3, k = idx & 7;
                 const int se = t % ne, t2 = t / ne;
                 const int yy = t2 % R, g = t2 / R;
                 const int y = y0 + yy, Gi = g0 + g;
@@ -195,17 +206,21 @@ __device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* smem,
         }
         __syncthreads();
         const int g0 = (m0 + hh * 64) >> 3;
+#ifndef CB_NO_SCATTER0
         scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
+#endif
+#ifndef CB_NO_SCATTER123
         if (G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
         if (G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
         if (G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
+#endif
     }
 }
 
 #define SMEM_FLOATS (64 * TP + 64 * 33 + 64 * 9 + 64 * 3)
 
 // A: (b, K, mp) fmap1 in group order;  B: (b, K, np) fmap2 in patch order.  grid = (nbands, mp/128, b).
-__global__ __launch_bounds__(256, 2) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
+__global__ __launch_bounds__(256, 3) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
                                                     int K, float scale, PyrGeom G) {
     // main loop: As[2][BK][BM] | Bs[2][BK][BN] (32 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
