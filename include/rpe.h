@@ -382,6 +382,13 @@ int rpe_resize_crop_mask(const uint8_t *in, int h, int w, int resized_h, int res
 int rpe_remap_nearest(const void *src, int src_is_u8, int c, int h, int w, const float *mapx, const float *mapy, int out_h,
                       int out_w, void *dst, void *stream);
 
+/* Pseudo-rectification of the right image (dataset/rectification.py:55-58 mode='pseudo' -> dataset/preprocess/stereo_rectify.py:
+ * 52-59 pseudo_rectify_2d): dst = cv2.warpAffine(src, [[1,0,tx],[0,1,ty]], (w,h)), i.e. INTER_LINEAR with source coordinates
+ * rounded to 1/32 pixel (fixed point, AB_BITS = 10), OpenCV's 5-bit bilinear table (uint8: integer weights summing to 2^15,
+ * (sum + 2^14) >> 15; float32: float weights), BORDER_CONSTANT 0.  tx = lkmat[0][2] - rkmat[0][2], ty = lkmat[1][2] - rkmat[1][2]
+ * as float32 (the reference builds the matrix with .astype(np.float32)).  Planar (c,h,w) uint8 or float32. */
+int rpe_shift_bilinear(const void *src, int src_is_u8, int c, int h, int w, float tx, float ty, void *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

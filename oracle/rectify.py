@@ -70,3 +70,40 @@ def remap_nearest(img, mapx, mapy):
             if 0 <= sx < w and 0 <= sy < h:
                 out[:, y, x] = img[:, sy, sx]
     return out
+
+
+def warp_affine_shift(img, tx, ty):
+    """cv2.warpAffine(img, [[1,0,tx],[0,1,ty]], (w,h)) = dataset/preprocess/stereo_rectify.py:52-59 pseudo_rectify_2d, one pixel at a
+    time: img (C,H,W) uint8 or float32.  OpenCV 4.x imgwarp.cpp restated (PARITY UNPINNED like the rest of this file): the inverse
+    map source = dst - t in fixed point (AB_BITS 10), rounded to 1/32 pixel; the 5-bit bilinear table (integer weights x 32 summing
+    to 2^15 for uint8, float weights for float32); constant-0 border."""
+    tx, ty = float(np.float32(tx)), float(np.float32(ty))
+    c, h, w = img.shape
+    out = np.zeros_like(img)
+    rnd = lambda v: int(np.rint(v))                              # cvRound: half to even
+    X0 = rnd(-tx * 1024.0) + 16
+    for y in range(h):
+        Y0 = rnd((y - ty) * 1024.0) + 16
+        Y = Y0 >> 5
+        sy, ay = max(-32768, min(32767, Y >> 5)), Y & 31
+        for x in range(w):
+            X = (X0 + x * 1024) >> 5
+            sx, ax = max(-32768, min(32767, X >> 5)), X & 31
+
+            def tap(yy, xx, ch):
+                return img[ch, yy, xx] if 0 <= yy < h and 0 <= xx < w else img.dtype.type(0)
+            for ch in range(c):
+                p = [tap(sy, sx, ch), tap(sy, sx + 1, ch), tap(sy + 1, sx, ch), tap(sy + 1, sx + 1, ch)]
+                if img.dtype == np.uint8:
+                    wts = [(32 - ax) * (32 - ay) * 32, ax * (32 - ay) * 32, (32 - ax) * ay * 32, ax * ay * 32]
+                    v = (sum(int(a) * int(b) for a, b in zip(wts, p)) + (1 << 14)) >> 15
+                    out[ch, y, x] = min(255, max(0, v))
+                else:
+                    fx, fy = np.float32(ax) * np.float32(1 / 32), np.float32(ay) * np.float32(1 / 32)
+                    one = np.float32(1)
+                    wts = [(one - fy) * (one - fx), (one - fy) * fx, fy * (one - fx), fy * fx]
+                    acc = np.float32(p[0]) * wts[0]
+                    for a, b in zip(wts[1:], p[1:]):
+                        acc = np.float32(acc + np.float32(np.float32(b) * a))
+                    out[ch, y, x] = acc
+    return out

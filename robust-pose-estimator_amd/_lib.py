@@ -91,6 +91,7 @@ SIGNATURES = {
     'rpe_resize_crop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop_mask': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_remap_nearest': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    'rpe_shift_bilinear': (_i, [_vp, _i, _i, _i, _i, _c.c_float, _c.c_float, _vp, _vp]),
 }
 
 _lib = None

@@ -164,3 +164,51 @@ extern "C" int rpe_remap_nearest(const void* src, int src_is_u8, int c, int h, i
     else hipLaunchKernelGGL(k_remap_nearest<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, c, h, w, mapx, mapy, out_h, out_w, (float*)dst);
     return rpe_check_launch();
 }
+
+// Pseudo-rectification (dataset/preprocess/stereo_rectify.py:52-59 pseudo_rectify_2d, used by dataset/rectification.py:55-58 for
+// mode='pseudo'): cv2.warpAffine(img, [[1, 0, tx], [0, 1, ty]], (w, h)) with its defaults INTER_LINEAR / BORDER_CONSTANT(0).
+// OpenCV 4.x imgwarp.cpp, restated: the matrix is inverted (source = dst - t), source coordinates are fixed point with
+// AB_BITS = 10 and rounded to 1/32 pixel -- X = (cvRound(-tx * 1024) + 16 + 1024 x) >> 5, integer part X >> 5, fraction X & 31 --
+// and the four taps are blended with the 5-bit bilinear table: integer weights (32-a)(32-b), a(32-b), (32-a)b, ab times 32
+// (sum 2^15), result (sum + 2^14) >> 15 for uint8; float images use the table's float weights and a float sum.  Taps outside
+// the image contribute the border value 0.  host side passes X0 = cvRound(-tx*1024) + 16, Y0c = the per-row constants' -ty term:
+// Y0(y) = cvRound((y - ty) * 1024) + 16 is computed per row in double, as OpenCV does.
+template <typename T>
+__global__ __launch_bounds__(256) void k_shift_bilinear(const T* __restrict__ src, int c, int h, int w, int X0, double mty, T* __restrict__ dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int Y0 = (int)__double2ll_rn(((double)y + mty) * 1024.0) + 16;       // saturate_cast<int>(double) = cvRound: round half to even
+    const int X = (X0 + x * 1024) >> 5, Y = Y0 >> 5;                           // arithmetic shifts: floor
+    int sx = X >> 5, sy = Y >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx); sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);   // saturate_cast<short>
+    const int ax = X & 31, ay = Y & 31;
+    const bool x0ok = sx >= 0 && sx < w, x1ok = sx + 1 >= 0 && sx + 1 < w, y0ok = sy >= 0 && sy < h, y1ok = sy + 1 >= 0 && sy + 1 < h;
+    const size_t o = (size_t)y * w + x;
+    for (int ch = 0; ch < c; ++ch) {
+        const T* p = src + (size_t)ch * h * w;
+        const T p00 = (x0ok && y0ok) ? p[(size_t)sy * w + sx] : (T)0, p01 = (x1ok && y0ok) ? p[(size_t)sy * w + sx + 1] : (T)0;
+        const T p10 = (x0ok && y1ok) ? p[(size_t)(sy + 1) * w + sx] : (T)0, p11 = (x1ok && y1ok) ? p[(size_t)(sy + 1) * w + sx + 1] : (T)0;
+        if constexpr (sizeof(T) == 1) {
+            const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+            const int v = (w00 * (int)p00 + w01 * (int)p01 + w10 * (int)p10 + w11 * (int)p11 + (1 << 14)) >> 15;
+            dst[(size_t)ch * h * w + o] = (T)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        } else {
+            const float fx = (float)ax * (1.0f / 32.0f), fy = (float)ay * (1.0f / 32.0f);
+            const float w00 = (1.0f - fy) * (1.0f - fx), w01 = (1.0f - fy) * fx, w10 = fy * (1.0f - fx), w11 = fy * fx;
+            dst[(size_t)ch * h * w + o] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p00, w00), __fmul_rn(p01, w01)), __fmul_rn(p10, w10)), __fmul_rn(p11, w11));
+        }
+    }
+}
+
+extern "C" int rpe_shift_bilinear(const void* src, int src_is_u8, int c, int h, int w, float tx, float ty, void* dst, void* stream) {
+    if (!src || !dst || c <= 0 || h <= 0 || w <= 0 || !(tx == tx) || !(ty == ty)) return RPE_E_BADARG;
+    // the inverse of [[1,0,tx],[0,1,ty]] in double, as warpAffine computes it: b1 = -tx, b2 = -ty (exact)
+    const double mtx = -(double)tx, mty = -(double)ty;
+    const double sx = mtx * 1024.0;
+    if (!(fabs(sx) < 2.0e9) || !(fabs(mty) < 1.0e6)) return RPE_E_UNSUPPORTED;
+    const int X0 = (int)llrint(sx) + 16;                                      // cvRound: round half to even (default FP environment)
+    dim3 grid(ceil_div(w, 256), h), block(256);
+    if (src_is_u8) hipLaunchKernelGGL(k_shift_bilinear<uint8_t>, grid, block, 0, (hipStream_t)stream, (const uint8_t*)src, c, h, w, X0, mty, (uint8_t*)dst);
+    else hipLaunchKernelGGL(k_shift_bilinear<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, c, h, w, X0, mty, (float*)dst);
+    return rpe_check_launch();
+}

@@ -268,10 +268,24 @@ def remap_nearest(img, mapx, mapy):
     return out
 
 
+def shift_bilinear(img, tx, ty):
+    """cv2.warpAffine(img, [[1,0,tx],[0,1,ty]], (w,h)) on the GPU (rpe_shift_bilinear: INTER_LINEAR in OpenCV's 1/32-pixel fixed
+    point, constant-0 border): img (C,H,W) uint8 / float32.  The pseudo-rectification of dataset/preprocess/stereo_rectify.py:52-59."""
+    img = _gpu(img, 'img')
+    if img.dim() != 3 or img.dtype not in (torch.uint8, torch.float32):
+        raise _lib.RpeError('shift_bilinear: img must be (C,H,W) uint8 or float32')
+    c, h, w = img.shape
+    out = torch.empty_like(img)
+    check(lib().rpe_shift_bilinear(ptr(img), int(img.dtype == torch.uint8), c, h, w, float(np.float32(tx)), float(np.float32(ty)), ptr(out),
+                                   stream_ptr()), 'rpe_shift_bilinear')
+    return out
+
+
 class StereoRectifier:
     """dataset/rectification.py:11-77, same constructor, call and get_rectified_calib().  Images are (3,H,W) GPU tensors (uint8
     or float32) and stay on the GPU; `calib_file` may also be an already-loaded calibration dict (keys lkmat, rkmat, ld, rd, R,
-    T, img_size).  mode='pseudo' (cv2.warpAffine's fixed-point bilinear shift, used for SCARED only) is not built."""
+    T, img_size).  mode='pseudo' (configuration/infer_scared.yaml:17): the left image passes through, the right one is shifted by
+    the difference of the principal points (cv2.warpAffine -> rpe_shift_bilinear)."""
 
     def __init__(self, calib_file, img_size_new=None, mode='conventional', device='cuda'):
         import os
@@ -284,8 +298,6 @@ class StereoRectifier:
                 raise NotImplementedError
             cal = loaders[ext](calib_file)
         assert mode in ['conventional', 'pseudo']
-        if mode == 'pseudo':
-            raise NotImplementedError("mode='pseudo' (cv2.warpAffine) is not built; the hot path uses 'conventional'")
         self.mode = mode
         self.scale = 1.0
         if img_size_new is not None:
@@ -305,6 +317,9 @@ class StereoRectifier:
         self._gpu_maps = {k: torch.from_numpy(v).to(device) for k, v in self.maps.items()} if torch.cuda.is_available() else None
 
     def __call__(self, img_left, img_right):
+        if self.mode == 'pseudo':                              # rectification.py:55-58
+            lk, rk = self.cal['lkmat'], self.cal['rkmat']
+            return _gpu(img_left, 'img_left'), shift_bilinear(img_right, lk[0][-1] - rk[0][-1], lk[1][-1] - rk[1][-1])
         m = self._gpu_maps
         if m is None:
             raise _lib.RpeError('StereoRectifier: no GPU (the HIP path has no CPU fallback)')
@@ -312,7 +327,10 @@ class StereoRectifier:
 
     def get_rectified_calib(self):
         calib = {'intrinsics': {'left': self.l_intr[:3, :3], 'right': self.r_intr[:3, :3]}, 'extrinsics': np.eye(4)}
-        calib['extrinsics'][:3, 3] = np.array([self.r_intr[0, 3] / self.r_intr[0, 0], 0., 0.])       # Tx*f (rectification.py:71-72)
+        if self.mode == 'conventional':
+            calib['extrinsics'][:3, 3] = np.array([self.r_intr[0, 3] / self.r_intr[0, 0], 0., 0.])   # Tx*f (rectification.py:71-72)
+        else:
+            calib['extrinsics'][:3, 3] = np.asarray(self.cal['T'], np.float64).reshape(3)            # rectification.py:73-74
         calib['bf'] = np.sqrt(np.sum(calib['extrinsics'][:3, 3] ** 2)) * self.l_intr[0, 0]
         calib['bf_orig'] = calib['bf'] / self.scale
         calib['img_size'] = self.img_size

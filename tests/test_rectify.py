@@ -132,8 +132,11 @@ def test_rectifier_interface_and_calibration_files(pp, tmp_path):
     half = pp.StereoRectifier(dict(c), img_size_new=(160, 120))
     assert half.scale == 0.5 and abs(half.cal['lkmat'][1, 2] - (c['lkmat'][1, 2] * 0.5 - 4)) < 1e-12 and half.maps['lmap1'].shape == (120, 160)
     assert abs(half.get_rectified_calib()['bf_orig'] - half.get_rectified_calib()['bf'] / 0.5) < 1e-12
-    with pytest.raises(NotImplementedError):
-        pp.StereoRectifier(dict(c), mode='pseudo')
+    pseudo = pp.StereoRectifier(dict(c), mode='pseudo')          # (rectification.py:73-74: the calibration's own T as the baseline)
+    pc = pseudo.get_rectified_calib()
+    assert pseudo.maps == {} and np.array_equal(pc['intrinsics']['left'], c['lkmat']) and np.allclose(pc['extrinsics'][:3, 3], c['T'])
+    with pytest.raises(AssertionError):
+        pp.StereoRectifier(dict(c), mode='other')
 
 
 def test_oracle_remap_known_answers():
@@ -175,3 +178,47 @@ def test_gpu_rectifier_matches_oracle_and_aligns_rows(pp):
     _, R2, _, P2 = pp.stereo_rectify(c['lkmat'], c['ld'], c['rkmat'], c['rd'], c['img_size'], c['R'], c['T'], alpha=0)
     ox, oy = orc.undistort_rectify_map(c['rkmat'], c['ld'], R2, P2, c['img_size'])
     assert np.abs(rect.maps['rmap1'] - ox).max() <= 8e-6 and np.abs(rect.maps['rmap2'] - oy).max() <= 8e-6
+
+
+def test_oracle_pseudo_shift_known_answers():
+    """cv2.warpAffine with a pure translation, restated (oracle/rectify.py::warp_affine_shift): an integer shift moves pixels exactly
+    (zeros enter at the border), a half-pixel shift averages neighbours with OpenCV's rounding ((a + b + 1) >> 1 for uint8), a
+    1/32-pixel shift uses the weights 31/32 and 1/32, and anything finer than 1/64 rounds to the grid of 1/32."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(2, 9, 12)).astype(np.uint8)
+    out = orc.warp_affine_shift(img, 3.0, -2.0)                      # dst(x, y) = src(x - 3, y + 2)
+    assert np.array_equal(out[:, :7, 3:], img[:, 2:, :9]) and not out[:, 7:].any() and not out[:, :, :3].any()
+    half = orc.warp_affine_shift(img, 0.5, 0.0)
+    a, b = img[:, :, :-1].astype(int), img[:, :, 1:].astype(int)
+    assert np.array_equal(half[:, :, 1:], ((a + b + 1) >> 1).astype(np.uint8))
+    fine = orc.warp_affine_shift(img, 1.0 / 32.0, 0.0)               # src = x - 1/32: weights 1/32 on the left neighbour, 31/32 on x
+    want = (31 * 32 * 32 * img[:, :, 1:].astype(int) + 32 * 32 * img[:, :, :-1].astype(int) + (1 << 14)) >> 15
+    assert np.array_equal(fine[:, :, 1:], want.astype(np.uint8))
+    assert np.array_equal(orc.warp_affine_shift(img, 1.0 / 256.0, 0.0), img)          # below half a grid step: no shift at all
+    f = img.astype(np.float32)
+    assert np.array_equal(orc.warp_affine_shift(f, 3.0, -2.0)[:, :7, 3:], f[:, 2:, :9])
+    assert np.allclose(orc.warp_affine_shift(f, 0.25, 0.0)[:, :, 1:], 0.75 * f[:, :, 1:] + 0.25 * f[:, :, :-1], atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['uint8', 'float32'])
+def test_gpu_pseudo_rectification_bit_exact(pp, dtype):
+    """rpe_shift_bilinear against the scalar oracle, bit for bit: fractional shifts in both axes, shifts that leave the image, the
+    rounding of the shift itself (the reference builds the matrix in float32), and through StereoRectifier(mode='pseudo')."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(3, 37, 52)).astype(np.uint8)
+    if dtype == 'float32':
+        img = (img.astype(np.float32) * np.float32(1.37)) - np.float32(20.0)
+    g = torch.from_numpy(img).cuda()
+    for tx, ty in ((3.0, -2.0), (0.5, 0.0), (-7.3125, 1.71875), (12.3456789, -0.0151), (100.0, 0.0), (0.0, -40.2), (1e-3, 1e-3)):
+        got = pp.shift_bilinear(g, tx, ty).cpu().numpy()
+        assert np.array_equal(got, orc.warp_affine_shift(img, tx, ty)), (tx, ty)
+    cal = _calib(4, size=(52, 37))
+    rect = pp.StereoRectifier(dict(cal), mode='pseudo')
+    left, right = rect(g, g)
+    assert left.data_ptr() == g.data_ptr() or torch.equal(left, g)
+    tx, ty = cal['lkmat'][0, 2] - cal['rkmat'][0, 2], cal['lkmat'][1, 2] - cal['rkmat'][1, 2]
+    assert np.array_equal(right.cpu().numpy(), orc.warp_affine_shift(img, tx, ty))
+    calib = rect.get_rectified_calib()
+    assert np.array_equal(calib['intrinsics']['left'], cal['lkmat']) and np.allclose(calib['extrinsics'][:3, 3], cal['T'])
+    assert abs(calib['bf'] - np.linalg.norm(cal['T']) * cal['lkmat'][0, 0]) < 1e-9
