@@ -574,10 +574,19 @@ def cpu_baseline(cfg, model, frames, n_frames, gpu_pose):
         poses.append(om.infer(**a))
     dt = time.perf_counter() - t0
     gp = gpu_pose.data.reshape(-1, 7)[:n_frames].cpu()
-    diff = float((torch.cat(poses).reshape(-1, 7) - gp).abs().max())
+    cp = torch.cat(poses).reshape(-1, 7)
+    diff = float((cp - gp).abs().max())
+    # BASELINE.json's "ATE-RMSE vs ref": both sets of relative poses chained into trajectories the way the tracker does
+    # (pose_estimator.py:90-91, x250 de-normalised, i.e. millimetres) and compared with the reference's own metric definitions
+    from oracle import tracker as otracker
+    from rpe_amd import trajectory
+    Tc, Tg = (trajectory.pose_matrices(otracker.chain(x.float(), 250.0).numpy()) for x in (cp, gp))
+    ate, _ = trajectory.absolute_trajectory_error(Tc, Tg, prealign=False)
+    rpe_t, rpe_r = trajectory.relative_pose_error(Tc, Tg)
     return {'value': n_frames / dt, 'unit': 'pose solves/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_frames} frame pairs of the same batch, one at a time, torch CPU f32 + f64 L-BFGS',
-            'max_abs_pose_diff_vs_gpu': diff}
+            'max_abs_pose_diff_vs_gpu': diff, 'ate_rmse_gpu_vs_cpu_mm': ate, 'rpe_trans_gpu_vs_cpu_mm': float(rpe_t.mean()),
+            'rpe_rot_gpu_vs_cpu_rad': float(rpe_r.mean())}
 
 
 if __name__ == '__main__':

@@ -214,3 +214,31 @@ def test_history_shift_and_tolerances(rpe):
     T, _, _, info = ops.pose_solve(*dev(args), iters=140)
     assert info[:, 0].cpu().tolist() == iod['n_iter'].tolist() and info[:, 2].cpu().tolist() == iod['stop'].tolist()
     assert float((T.cpu() - Td).abs().max()) < 1e-7
+
+
+def test_solve_is_graph_capturable(rpe):
+    """A whole solve is 2N + 2 launches on one stream with no host synchronisation (the reference synchronises every iteration
+    through float(loss)): it can be captured into a HIP graph and replayed on new inputs in the same buffers."""
+    from rpe_amd import ops
+    c = synth.solver_case(8, 2, 64, 80)
+    args = [a.clone() for a in dev(synth.solver_args(c))]
+    eager = ops.pose_solve(*args, iters=8)[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.pose_solve(*args, iters=8)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        T, vec7, log6, info = ops.pose_solve(*args, iters=8)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(T, eager)
+    c2 = synth.solver_case(9, 2, 64, 80)
+    for dst, src in zip(args, dev(synth.solver_args(c2))):
+        dst.copy_(src)
+    graph.replay()
+    torch.cuda.synchronize()
+    want = ops.pose_solve(*dev(synth.solver_args(c2)), iters=8)[0]
+    assert torch.equal(T, want) and info[:, 0].tolist() == [8, 8]
