@@ -45,7 +45,7 @@ def conv_roofline(events, steps):
     ms = sum(a.elapsed_time(b) for a, b, _ in events)
     flop = sum(f for _, _, f in events)
     tf = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {'kernel': 'k_conv_igemm', 'bound': 'mfma', 'achieved': tf, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+    return {'kernel': 'k_conv_igemm + k_conv1x1', 'bound': 'mfma', 'achieved': tf, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tf / F32_MFMA_PEAK_TFLOPS, 'launches_per_step': len(events) // max(1, steps), 'ms_per_step': ms / max(1, steps),
             'tflop_per_step': flop / max(1, steps) / 1e12}
 

@@ -311,6 +311,13 @@ int rpe_conv_wino(const rpe_conv_desc *desc, void *stream);
 size_t rpe_conv_wino1d_packed_floats(int cout, int cin);
 int rpe_conv_wino1d_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv_wino1d(const rpe_conv_desc *desc, void *stream);
+/* 1x1 stride-1 convolutions as plain GEMMs with LDS-DMA operand rings (csrc/conv1x1.hip; BasicMotionEncoder.convc1 behind the
+ * correlation lookup, the mask head's and the encoders' 1x1 output layers, core/RAFT/core/update.py / extractor.py).  Same
+ * descriptor; supported fields: bias, out, out2, mode LINEAR / RELU / TANH; h * w % 4 == 0, 16-byte aligned input slice.  desc->packed
+ * must come from rpe_conv1x1_pack (rpe_conv1x1_packed_floats floats).  Anything else -> RPE_E_UNSUPPORTED (use rpe_conv_fused). */
+size_t rpe_conv1x1_packed_floats(int cout, int cin);
+int rpe_conv1x1_pack(const float *weight, int cout, int cin, float *packed, void *stream);
+int rpe_conv1x1(const rpe_conv_desc *desc, void *stream);
 /* number of pixel tiles (= moment records per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input);
  * the launcher and this function share one tile-width rule */
 int rpe_conv_stats_tiles(int cout, int h, int w, int stride);

@@ -68,11 +68,14 @@ SIGNATURES = {
     'rpe_upsample_convex': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'rpe_conv_packed_floats': (_sz, [_i, _i, _i, _i]),
     'rpe_conv_pack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_conv1x1_packed_floats': (_sz, [_i, _i]),
+    'rpe_conv1x1_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_fused': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_wino_packed_floats': (_sz, [_i, _i]),
     'rpe_conv_wino_stats_tiles': (_i, [_i, _i]),
     'rpe_conv_wino_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino': (_i, [_c.POINTER(ConvDesc), _vp]),
+    'rpe_conv1x1': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_wino1d_packed_floats': (_sz, [_i, _i]),
     'rpe_conv_wino1d_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino1d': (_i, [_c.POINTER(ConvDesc), _vp]),

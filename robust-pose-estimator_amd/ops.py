@@ -436,6 +436,45 @@ class PackedConv:
         return kh % 2 == 1 and kw in (1, 3, 5) and width % 4 == 0
 
 
+class PackedConv1x1:
+    """Weights of a 1x1 stride-1 convolution in rpe_conv1x1's layout ([co tile][16-channel step][k][128 co]); same attributes as
+    PackedConv, so conv_fused(..., entry='rpe_conv1x1') builds the descriptor."""
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        if (self.kh, self.kw) != (1, 1):
+            raise _lib.RpeError('PackedConv1x1: weight must be (cout, cin, 1, 1)')
+        self.packed = torch.empty(lib().rpe_conv1x1_packed_floats(self.cout, self.cin), dtype=torch.float32, device=w.device)
+        check(lib().rpe_conv1x1_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv1x1_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(h, w):
+        return (h * w) % 4 == 0 and h * w >= 4
+
+
+def conv1x1(x, pc, mode, out, out2=None, prepare=False):
+    """rpe_conv1x1: out = act(W x + bias) for a PackedConv1x1 (LINEAR / RELU / TANH), channel-slice destinations like conv_fused."""
+    return conv_fused(x, pc, mode, out, out2=out2, prepare=prepare, entry='rpe_conv1x1')
+
+
+class Conv1x1:
+    """A 1x1 layer with both packings: launches of at least 512 workgroups of 128 x 128 run on rpe_conv1x1 (LDS-DMA GEMM: convc1
+    337 -> 260 us at batch 32), smaller ones on rpe_conv_fused, whose 64 x 64 tiles fill the chip better (batch 2: 29 vs 32 us)."""
+
+    def __init__(self, weight, bias=None):
+        self.fused, self.gemm = PackedConv(weight, bias), PackedConv1x1(weight, bias)
+        self.cin, self.cout = self.fused.cin, self.fused.cout
+
+    def __call__(self, x, mode, out, out2=None, prepare=False):
+        b, _, hh, ww = x.shape
+        big = b * -(-(hh * ww) // 128) * -(-self.cout // 128) >= 512 and PackedConv1x1.supported(hh, ww)
+        if big:
+            return conv1x1(x, self.gemm, mode, out, out2=out2, prepare=prepare)
+        return conv_fused(x, self.fused, mode, out, out2=out2, prepare=prepare)
+
+
 def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, gate_channels=0, scale=None, bias='packed',
                residual=None, stats=None, stride=1, pre_norm=None, prepare=False, entry='rpe_conv_fused'):
     """rpe_conv_fused: out = epilogue(conv(x; pc) * scale + add + bias).  All tensors are channel slices of NCHW buffers.

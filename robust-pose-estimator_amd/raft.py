@@ -277,13 +277,13 @@ class BasicEncoder(nn.Module):
             cached = getattr(self, '_final_packed', None)
             if cached is None or cached[0] != key:
                 w, bv = m.weight.detach(), m.bias.detach()
-                self._final_packed = cached = (key, ops.PackedConv(w, bv), ops.PackedConv(w[:half].contiguous(), bv[:half].contiguous()),
-                                               ops.PackedConv(w[half:].contiguous(), bv[half:].contiguous()))
+                self._final_packed = cached = (key, ops.Conv1x1(w, bv), ops.Conv1x1(w[:half].contiguous(), bv[:half].contiguous()),
+                                               ops.Conv1x1(w[half:].contiguous(), bv[half:].contiguous()))
             out = torch.empty(b, m.out_channels, hh, ww, device=x.device)
             if not split_act:
-                return ops.conv_fused(x, cached[1], ops.CONV_LINEAR, out)
-            ops.conv_fused(x, cached[2], ops.CONV_TANH, out[:, :half])
-            ops.conv_fused(x, cached[3], ops.CONV_RELU, out[:, half:])
+                return cached[1](x, ops.CONV_LINEAR, out)
+            cached[2](x, ops.CONV_TANH, out[:, :half])
+            cached[3](x, ops.CONV_RELU, out[:, half:])
             return out
         y = m(x)
         return torch.cat((torch.tanh(y[:, :half]), torch.relu(y[:, half:])), dim=1) if split_act else y
@@ -356,7 +356,7 @@ class BasicMotionEncoder(nn.Module):
                     return ops.conv_wino(x, wino[name], ops.CONV_RELU, out, out2=out2, prepare=True)
                 return ops.conv_fused(x, packed[name], ops.CONV_RELU, out, out2=out2, prepare=True)
             calls = (key, cor, flo,
-                     ops.conv_fused(corr, packed['convc1'], ops.CONV_RELU, cor, prepare=True),
+                     packed['convc1_1x1'](corr, ops.CONV_RELU, cor, prepare=True),
                      c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
                      c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
             _bounded_put(cache, key, calls)
@@ -459,6 +459,7 @@ class BasicUpdateBlock(nn.Module):
             P['wino'] = {n: ops.PackedWino(m.weight, m.bias) for n, m in zip(('convc2', 'convf2', 'conv', 'fh1'), mods[1:])
                          if ops.PackedWino.supported(m.weight, 2, 2)} if WINOGRAD else {}
             P['convf1'] = ops.PackedStem(e.convf1.weight)
+            P['convc1_1x1'] = ops.Conv1x1(e.convc1.weight, e.convc1.bias)
             for n in ('zr1', 'q1', 'zr2', 'q2'):
                 # the loop-varying 256 channels: Winograd F(4,5) along the filter axis (rpe_conv_wino1d: 2.5x fewer matrix FLOPs), else the
                 # direct implicit GEMM; bias is part of the context term (context_terms)
@@ -544,7 +545,7 @@ class BasicUpdateBlock(nn.Module):
         if cached is None or cached[0] != key:
             pw = ops.PackedWino(c1.weight, c1.bias) if WINOGRAD and c1.weight.is_cuda else None
             w2, b2 = (0.25 * c2.weight).detach(), (0.25 * c2.bias).detach()
-            self._mask_packed = cached = (key, pw, w2, b2, ops.PackedConv(w2, b2) if c2.weight.is_cuda else None)
+            self._mask_packed = cached = (key, pw, w2, b2, ops.Conv1x1(w2, b2) if c2.weight.is_cuda else None)
         _, pw, w2, b2, p2 = cached
         hh, ww = net.shape[-2:]
         if pw is not None and not torch.is_grad_enabled() and hh % 2 == 0 and ww % 2 == 0:      # (net may be a channel slice: hx[:, :128])
@@ -552,7 +553,7 @@ class BasicUpdateBlock(nn.Module):
         else:
             t = F.relu(c1(net.contiguous()))
         if p2 is not None and ww % 4 == 0 and not torch.is_grad_enabled():
-            return ops.conv_fused(t, p2, ops.CONV_LINEAR, torch.empty(net.shape[0], c2.out_channels, hh, ww, device=net.device))
+            return p2(t, ops.CONV_LINEAR, torch.empty(net.shape[0], c2.out_channels, hh, ww, device=net.device))
         return F.conv2d(t, w2, b2)
 
 

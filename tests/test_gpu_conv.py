@@ -649,3 +649,29 @@ def test_instnorm_apply_with_a_raw_residual(rpe):
     assert torch.equal(got, two_pass)
     with pytest.raises(rpe.RpeError):
         ops.instnorm_apply(raw.clone(), stats, residual_norm=res_mi)              # a norm without a residual
+
+
+@pytest.mark.parametrize('cin,cout,h,w,b,mode', [(324, 256, 64, 80, 32, 'relu'), (324, 256, 64, 80, 1, 'relu'), (128, 256, 44, 48, 2, 'tanh'),
+                                                 (256, 576, 44, 48, 2, 'linear'), (20, 70, 6, 10, 3, 'linear'), (17, 130, 2, 2, 1, 'relu')])
+def test_conv1x1_gemm_matches_f64(rpe, cin, cout, h, w, b, mode):
+    """rpe_conv1x1 (LDS-DMA GEMM for 1x1 convolutions: convc1 behind the lookup, the 1x1 output layers, the mask head) against the f64
+    convolution: channel counts that end inside a 16-channel step / a 128-channel tile, pixel counts that end inside a 128-pixel tile,
+    input and outputs as channel slices of wider buffers, a second destination."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + h)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, 1, 1, s=0.05), _rand(rng, cout, s=0.3)
+    ref = _ref_conv(x, wt, bias, None)
+    ref = {'relu': ref.clamp_min(0), 'tanh': torch.tanh(ref), 'linear': ref}[mode]
+    m = {'relu': ops.CONV_RELU, 'tanh': ops.CONV_TANH, 'linear': ops.CONV_LINEAR}[mode]
+    xbuf = torch.full((b, cin + 8, h, w), float('nan'), device='cuda'); xbuf[:, 4:4 + cin] = x.cuda()
+    obuf = torch.full((b, cout + 5, h, w), -7.0, device='cuda'); o2 = torch.full((b, cout + 1, h, w), -7.0, device='cuda')
+    pc = ops.PackedConv1x1(wt.cuda(), bias.cuda())
+    ops.conv1x1(xbuf[:, 4:4 + cin], pc, m, obuf[:, 2:2 + cout], out2=o2[:, 1:])
+    got = obuf[:, 2:2 + cout].cpu().double()
+    assert float((got - ref).abs().max()) < _tol(x, wt) + (1e-6 if mode == 'tanh' else 0.0)
+    assert torch.equal(obuf[:, 2:2 + cout], o2[:, 1:])
+    assert bool((obuf[:, :2] == -7.0).all()) and bool((obuf[:, 2 + cout:] == -7.0).all()) and bool((o2[:, 0] == -7.0).all())
+    again = ops.conv1x1(xbuf[:, 4:4 + cin], pc, m, torch.empty(b, cout, h, w, device='cuda'), prepare=True)()
+    assert torch.equal(again, obuf[:, 2:2 + cout])
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
+        ops.conv_fused(xbuf[:, 4:4 + cin], pc, ops.CONV_GATE_H, obuf[:, 2:2 + cout], hidden=obuf[:, 2:2 + cout], zgate=obuf[:, 2:2 + cout], entry='rpe_conv1x1')
