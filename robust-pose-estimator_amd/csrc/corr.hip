@@ -35,6 +35,7 @@
 //                     reference's bit for bit.
 #include "rpe_common.h"
 #include "sampling.h"
+#include <type_traits>
 
 #define MAX_LEVELS 4
 #define RADIUS 4
@@ -220,25 +221,56 @@ __device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* smem,
 #define SMEM_FLOATS (64 * TP + 64 * 33 + 64 * 9 + 64 * 3)
 
 // A: (b, K, mp) fmap1 in group order;  B: (b, K, np) fmap2 in patch order.  grid = (nbands, mp/128, b).
+// K loop (round 3): both operand tiles are k-major rows of 128 consecutive floats in global memory, i.e. already the matrix
+// instruction's operand order, so they arrive by LDS-DMA (global_load_lds_dwordx4, four 1 KB chunks per wave and step) into 3-deep
+// rings issued two steps ahead and counted by hand (s_waitcnt vmcnt(4); see wino_common.h / conv1x1.hip), instead of passing
+// through registers with a __syncthreads per step: the loop holds the 32 matrix instructions of a step, their 32 fragment reads,
+// one wait, one barrier and four DMA instructions.
+#define CB_TILE (BK * 128)
+#define CB_BIAS 4096u
+#define SMEM_MAIN (6 * CB_TILE)
+__device__ __forceinline__ void cb_dma2(const float* base, unsigned v0, unsigned v1, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned long long vb = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)vb), hi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+    const float* sb = (const float*)(((unsigned long long)hi << 32) | lo);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sb), "s"(lds_addr) : "memory");
+}
+
 __global__ __launch_bounds__(256, 3) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
                                                     int K, float scale, PyrGeom G) {
-    // main loop: As[2][BK][BM] | Bs[2][BK][BN] (32 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    float (*As)[BK][BM] = (float (*)[BK][BM])smem;
-    float (*Bs)[BK][BN] = (float (*)[BK][BN])(smem + 2 * BK * BM);
+    // main loop: As[3][BK][BM] | Bs[3][BK][BN] (48 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_FLOATS ? SMEM_MAIN : SMEM_FLOATS];
     const int bz = blockIdx.z, band = blockIdx.x;
     const int m0 = blockIdx.y * BM;
     const int M = G.mp, N = G.np;
     const float* Ab = A + (size_t)bz * K * M;
     const float* Bb = B + (size_t)bz * K * N;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
-    const int lk = tid >> 5, lc = (tid & 31) * 4;                 // loader: (k = tid>>5 [+8], 4 consecutive columns)
-    static_assert(BK == 16, "two loader rows per thread");
+    static_assert(BK == 16 && BM == 128 && BN == 128, "DMA roles: a wave moves four 512-byte rows of each tile per step");
     const int nk = K / BK;
+    // DMA roles: wave wv moves rows k = 4 wv .. 4 wv + 3 of both tiles (two 1 KB chunks = two rows each)
+    const int bl = lane & 31, bh = lane >> 5;
+    unsigned aoff[2], boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 4 * wv + 2 * j + bh;
+        aoff[j] = (unsigned)((size_t)k * M + m0 + 4 * bl) * 4u + CB_BIAS - 1024u * j;      // (16 rows of a step: < 4 GB for any map that fits the pyramid)
+        boff[j] = (unsigned)((size_t)k * N + 4 * bl) * 4u + CB_BIAS - 1024u * j;
+    }
+    const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem + (unsigned)(4 * wv) * 512u;
+    const unsigned b_lds = a_lds + 3u * CB_TILE * 4u;
+    const float* asrc = Ab - CB_BIAS / 4;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* a_l = smem + wm * 64 + l31 + lh * 128;
+    const float* b_l = smem + 3 * CB_TILE + wn * 64 + l31 + lh * 128;
 
     for (int px = 0; px < G.npx; ++px) {
         const int n0 = (band * G.npx + px) * BN;
+        const float* bsrc = Bb + n0 - CB_BIAS / 4;
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -246,39 +278,41 @@ __global__ __launch_bounds__(256, 3) void k_corr_build(const float* __restrict__
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        float4 ra0, ra1, rb0, rb1;                                // (scalars: as arrays they are demoted to LDS)
-        ra0 = *(const float4*)(Ab + (size_t)lk * M + m0 + lc);        ra1 = *(const float4*)(Ab + (size_t)(lk + 8) * M + m0 + lc);
-        rb0 = *(const float4*)(Bb + (size_t)lk * N + n0 + lc);        rb1 = *(const float4*)(Bb + (size_t)(lk + 8) * N + n0 + lc);
+        auto issue = [&](int s, int buf) {
+            const int sc = s < nk ? s : nk - 1;                               // past the end: a harmless repeat keeps the DMA count per step constant
+            cb_dma2(asrc + (size_t)sc * BK * M, aoff[0], aoff[1], a_lds + (unsigned)buf * (CB_TILE * 4u));
+            cb_dma2(bsrc + (size_t)sc * BK * N, boff[0], boff[1], b_lds + (unsigned)buf * (CB_TILE * 4u));
+        };
         __syncthreads();                                          // the previous patch's epilogue is done with smem
-        *(float4*)&As[0][lk][lc] = ra0; *(float4*)&As[0][lk + 8][lc] = ra1;
-        *(float4*)&Bs[0][lk][lc] = rb0; *(float4*)&Bs[0][lk + 8][lc] = rb1;
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                const int k1 = (kt + 1) * BK + lk;
-                ra0 = *(const float4*)(Ab + (size_t)k1 * M + m0 + lc);    ra1 = *(const float4*)(Ab + (size_t)(k1 + 8) * M + m0 + lc);
-                rb0 = *(const float4*)(Bb + (size_t)k1 * N + n0 + lc);    rb1 = *(const float4*)(Bb + (size_t)(k1 + 8) * N + n0 + lc);
-            }
+        issue(0, 0);
+        issue(1, 1);
+        auto step = [&](auto bufc, int s) {
+            constexpr int BUF = decltype(bufc)::value, NB = (BUF + 2) % 3;
+            __builtin_amdgcn_s_waitcnt(0x0F74);                               // vmcnt(4): own DMAs of step s have landed
+            __builtin_amdgcn_s_barrier();                                     // ... everybody's have, and buffer (s + 2) % 3 is free
+            issue(s + 2, NB);
+            const float* a = a_l + BUF * CB_TILE;
+            const float* b = b_l + BUF * CB_TILE;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
-                const int kr = kk + (lane >> 5);
-                float a0 = As[cur][kr][wm * 64 + (lane & 31)];
-                float a1 = As[cur][kr][wm * 64 + 32 + (lane & 31)];
-                float b0 = Bs[cur][kr][wn * 64 + (lane & 31)];
-                float b1 = Bs[cur][kr][wn * 64 + 32 + (lane & 31)];
+                const float a0 = a[kk * 128], a1 = a[kk * 128 + 32], b0 = b[kk * 128], b1 = b[kk * 128 + 32];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
-            if (kt + 1 < nk) {
-                const int nxt = cur ^ 1;
-                *(float4*)&As[nxt][lk][lc] = ra0; *(float4*)&As[nxt][lk + 8][lc] = ra1;
-                *(float4*)&Bs[nxt][lk][lc] = rb0; *(float4*)&Bs[nxt][lk + 8][lc] = rb1;
+        };
+        {
+            typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+            int s = 0;
+            while (true) {
+                step(I0{}, s); if (++s == nk) break;
+                step(I1{}, s); if (++s == nk) break;
+                step(I2{}, s); if (++s == nk) break;
             }
-            __syncthreads();
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                   // the repeats issued past the end have landed ...
+        __syncthreads();                                                      // ... and every wave is done with the operand tiles the epilogue aliases
         build_epilogue(acc, smem, pyr, G, scale, bz, m0, band, px, tid);
     }
 }
