@@ -15,8 +15,12 @@ Pinning status (see DESIGN.md "Oracle"):
     PINNED against the reference files imported unchanged.
   * lietorch SE3 exp/log/act/mul/inv: lietorch is an unpinned pip-from-git dependency that is not
     installed here (reference README.md:37).  Restated from its published algorithm
-    (quaternion exp/log with Taylor guards, left Jacobian); pinned only through the reference's own
-    tests (tests/unit_test_pinhole_transforms.py:24-53, tests/unit_test_pose_head.py:38-50).
+    (quaternion exp/log with Taylor guards, left Jacobian); pinned through the reference's own
+    tests (tests/unit_test_pinhole_transforms.py:24-53, tests/unit_test_pose_head.py:38-50) and against scipy's
+    matrix exponential / logarithm / Rotation as an independent statement of the same conventions (1e-12).
+  * TinyUNet, PoseNet.infer / flow2depth / get_weight_maps / proj, PoseEstimator (f2f): PINNED (round 3) by
+    ``gen_golden.py::gen_modules`` running the reference's own core/unet/unet.py, core/pose/pose_net.py and
+    core/pose/pose_estimator.py (with oracle.raft.RAFT standing in for the empty submodule).
   * RAFT (core/RAFT submodule is empty in the reference checkout): restated from the published
     princeton-vl/RAFT architecture; PARITY UNPINNED (no reference test touches RAFT).
 """

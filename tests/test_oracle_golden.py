@@ -174,3 +174,42 @@ def test_layer_backward_zero_when_not_converged():
     with pytest.warns(UserWarning, match='Non-zero objective'):
         out, fY, _ = pose_grad.layer_backward(*args, ident, g['v'], eps=1e-9)
     assert all(float(v.abs().max()) == 0.0 for v in out.values())
+
+
+def test_se3_matches_an_independent_matrix_exponential():
+    """lietorch is absent, so oracle/se3.py restates its SE(3) conventions (twist = (tau, phi) translation first, exp through the left
+    Jacobian, unit quaternion (x, y, z, w)).  Independent check of that mathematics against scipy -- the 4x4 matrix exponential /
+    logarithm of the twist's hat matrix, scipy's Rotation for the quaternion convention, plain matrix products and inverses -- to
+    1e-12, incl. rotations close to pi and tiny ones (the Taylor branches)."""
+    import numpy as np
+    import scipy.linalg
+    from scipy.spatial.transform import Rotation
+
+    def hat(x):
+        t, p = x[:3], x[3:]
+        M = np.zeros((4, 4))
+        M[:3, :3] = [[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0]]
+        M[:3, 3] = t
+        return M
+    rng = np.random.default_rng(3)
+    xis = [rng.normal(0, s, 6) for s in (0.7, 0.7, 0.05, 1e-6, 1e-9)]
+    near_pi = rng.normal(size=3)
+    xis.append(np.concatenate((rng.normal(0, 1, 3), near_pi / np.linalg.norm(near_pi) * (np.pi - 1e-3))))
+    xi = torch.from_numpy(np.stack(xis))
+    T = se3.se3_exp(xi)
+    M = se3.se3_matrix(T).numpy()
+    for i in range(len(xis)):
+        E = scipy.linalg.expm(hat(xis[i]))
+        assert np.abs(E - M[i]).max() < 1e-12, i
+        q = Rotation.from_matrix(E[:3, :3]).as_quat()                      # scalar-last, like lietorch's data layout
+        assert min(np.abs(q - T[i, 3:].numpy()).max(), np.abs(q + T[i, 3:].numpy()).max()) < 1e-12
+        assert np.abs(T[i, :3].numpy() - E[:3, 3]).max() < 1e-12
+        L = scipy.linalg.logm(E).real
+        back = se3.se3_log(T[i:i + 1])[0].numpy()
+        assert np.abs(back - np.concatenate((L[:3, 3], [L[2, 1], L[0, 2], L[1, 0]]))).max() < 1e-9 * max(1.0, np.abs(xis[i]).max()), i
+    P = se3.se3_matrix(se3.se3_mul(T[:3], T[3:6])).numpy()
+    assert np.abs(P - M[:3] @ M[3:6]).max() < 1e-12
+    assert np.abs(se3.se3_matrix(se3.se3_inv(T)).numpy() - np.linalg.inv(M)).max() < 1e-10
+    pts = torch.from_numpy(rng.normal(size=(len(xis), 7, 3)))
+    act = se3.se3_act(T[:, None], pts).numpy()
+    assert np.abs(act - (np.einsum('nij,npj->npi', M[:, :3, :3], pts.numpy()) + M[:, None, :3, 3])).max() < 1e-12
