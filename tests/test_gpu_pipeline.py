@@ -321,3 +321,29 @@ def test_infer_parity_sweep(models):
             assert d < 5e-5, (seed, d, scale)
     print(f'parity sweep: worst pose difference {worst:.2e} over 12 pairs, {flips} differing mask pixels, {diverged} diverged solves')
     assert flips <= 50
+
+
+def test_whole_infer_is_graph_capturable(models):
+    """PoseNet.infer enqueues ~200 kernels (incl. the side stream of small passes) and never synchronises with the host: the whole
+    call can be captured into one HIP graph; its replay gives the eager result bit for bit."""
+    model, om, synth = models
+    a = {k: v.cuda() for k, v in synth.infer_args(synth.stereo_frames(7, 1, H, W)).items()}
+    m0 = a['mask2'].clone()
+
+    def step():
+        a['mask2'].copy_(m0)
+        return model.infer(**a)
+    eager = step().data.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.data, eager)
