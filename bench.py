@@ -87,6 +87,8 @@ def parse_args(argv=None):
     ap.add_argument('--solver-iters', type=int, default=8)
     ap.add_argument('--cpu-frames', type=int, default=8, help='frames timed on the CPU oracle (0 = skip)')
     ap.add_argument('--seq-frames', type=int, default=24, help='--mode sequence: frames per GPU (weak scaling)')
+    ap.add_argument('--fp16-features', action='store_true',
+                    help="BASELINE config 5: fp16 feature maps into the correlation (upstream RAFT's mixed_precision), f32 pyramid, f64 solve")
     ap.add_argument('--no-extras', action='store_true', help='skip the batch-1 latency / tracker / Gauss-Newton lines')
     return ap.parse_args(argv)
 
@@ -236,7 +238,7 @@ def run_batch(args, rank, world, dev, dist):
     from rpe_amd import pose_head, pose_net, synth  # noqa: F401
 
     H, W, B = args.height, args.width, args.batch
-    cfg = synth.model_config(H, W, iters=args.raft_iters, lbgfs_iters=args.solver_iters, solver=args.solver)
+    cfg = synth.model_config(H, W, iters=args.raft_iters, lbgfs_iters=args.solver_iters, solver=args.solver, mixed_precision=args.fp16_features)
     model = pose_net.PoseNet(cfg)
     synth.init_synthetic_weights(model, seed=1234)
     model.eval().to(dev)
@@ -390,10 +392,12 @@ def run_batch(args, rank, world, dev, dist):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / max(1, args.steps),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference',
+        'dtype': ('f32 (RAFT / geometry; fp16 feature maps into the correlation) + f64 (SE(3) solve)' if args.fp16_features
+                  else 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference'),
         'data': 'synthetic (seeded rendered stereo pairs, seeded random-init weights)',
         'config': {'workload': f'PoseNet.infer, {W}x{H} stereo frame pairs, {B} per GPU per step (RAFT batch {2 * B}), '
-                               f'{args.raft_iters} GRU iters, {args.solver} x{args.solver_iters} SE(3) solve, weight heads on',
+                               f'{args.raft_iters} GRU iters, {args.solver} x{args.solver_iters} SE(3) solve, weight heads on'
+                               + (', fp16 features' if args.fp16_features else ''),
                    'frames_per_gpu': B, 'height': H, 'width': W, 'raft_iters': args.raft_iters,
                    'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
         'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
