@@ -161,11 +161,56 @@ __device__ __forceinline__ void scatter_level(const float* __restrict__ src, int
     }
 }
 
+// Level 0 with a CARRY (k_corr_build, f32 features): a workgroup walks the patches of its band left to right, and slot x' of a row
+// holds x = x' - 7 + k for query k, so the first seven slots of a patch are completed by the LAST seven columns of the previous
+// patch.  Those columns wait in LDS (carry[q][yy][7], zero in front of the first patch = the map's zero padding) and a patch writes
+// slots [x0, x0 + 16) only -- whole 32-byte slots, each exactly once, as 16-byte pieces -- instead of leaving half-written sectors
+// for the next patch to finish ~27 us later (after L2 had evicted most of them: 6.3 GB written for a 4.9 GB pyramid).  The last
+// patch of the band also writes its trailing slots [x0 + 16, x0 + 23): every column they reference lies beyond the map (zeros).
+#define CARRY_HALF (64 * 8 * 7)
+template <bool LAST>
+__device__ __forceinline__ void scatter_level0_carry(const float* __restrict__ T, const float* __restrict__ carry, float* __restrict__ lvl,
+                                                     const PyrGeom& G, int bz, int g0, int band, int px, int tid) {
+    constexpr int NS = LAST ? 23 : 16, NITEM = 2 * 64 * NS;
+    const int hl = G.h[0], wp = G.wp[0];
+    const int x0 = px * 16, y0 = band * 8;
+    char* lv = (char*)lvl + (size_t)bz * G.ngroups * hl * ((unsigned)wp * 32);
+#pragma unroll 1
+    for (int u = tid; u < NITEM; u += 256) {
+        const int half = u & 1, t = u >> 1;
+        const int row = t / NS, sl = t - row * NS;                // (compile-time divisor)
+        const int g = row >> 3, yy = row & 7;
+        const int y = y0 + yy, xs = x0 + sl, Gi = g0 + g;
+        if ((Gi >= G.ngroups) | (y >= hl) | (xs >= wp)) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * half + e, q = g * 8 + k;
+            const int xx = sl - 7 + k;                            // column of this patch; < 0: the previous patch's column 16 + xx
+            v[e] = xx >= 16 ? 0.0f : (xx >= 0 ? T[q * TP + yy * 16 + xx] : carry[(q * 8 + yy) * 7 + xx + 7]);
+        }
+        *(f32x4*)(lv + (size_t)(((unsigned)(Gi * hl + y) * (unsigned)wp + (unsigned)xs) * 32u + (unsigned)half * 16u)) = v;
+    }
+    if (LAST) {                                                   // row padding right of the last patch's slots: zeros
+        const int xe = x0 + 23, ne = wp - xe;
+        if (ne > 0) {
+            for (int idx = tid; idx < 64 * ne * 8; idx += 256) {
+                const int t = idx >> 3, k = idx & 7;
+                const int se = t % ne, t2 = t / ne;
+                const int yy = t2 & 7, g = t2 >> 3;
+                const int y = y0 + yy, Gi = g0 + g;
+                if (Gi >= G.ngroups || y >= hl) continue;
+                *(float*)(lv + (size_t)(((unsigned)(Gi * hl + y) * (unsigned)wp + (unsigned)(xe + se)) * 32u + (unsigned)k * 4u)) = 0.0f;
+            }
+        }
+    }
+}
+
 // Epilogue of one 128 x 128 tile: one half (64 queries = the rows of the waves with wm == hh) at a time through LDS
 // (aliasing the operand tiles, which nobody reads after the K loop's last barrier), pooled to levels 1-3 and scattered.
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 __device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* smem, float* __restrict__ pyr, const PyrGeom& G, float scale,
-                                               int bz, int m0, int band, int px, int tid) {
+                                               int bz, int m0, int band, int px, int tid, float* carry = nullptr) {
     float* T = smem;
     float* T1 = smem + 64 * TP;
     float* T2 = T1 + 64 * 33;
@@ -208,13 +253,24 @@ __device__ __forceinline__ void build_epilogue(f32x16 (&acc)[2][2], float* smem,
         __syncthreads();
         const int g0 = (m0 + hh * 64) >> 3;
 #ifndef CB_NO_SCATTER0
-        scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
+        if (carry) {
+            if (px == G.npx - 1) scatter_level0_carry<true>(T, carry + hh * CARRY_HALF, pyr + G.base[0], G, bz, g0, band, px, tid);
+            else scatter_level0_carry<false>(T, carry + hh * CARRY_HALF, pyr + G.base[0], G, bz, g0, band, px, tid);
+        } else scatter_level<0>(T, TP, pyr + G.base[0], G, bz, g0, band, px, tid);
 #endif
 #ifndef CB_NO_SCATTER123
         if (G.levels > 1) scatter_level<1>(T1, 33, pyr + G.base[1], G, bz, g0, band, px, tid);
         if (G.levels > 2) scatter_level<2>(T2, 9, pyr + G.base[2], G, bz, g0, band, px, tid);
         if (G.levels > 3) scatter_level<3>(T3, 3, pyr + G.base[3], G, bz, g0, band, px, tid);
 #endif
+        if (carry) {                                              // this patch's last seven columns wait for the next patch
+            __syncthreads();                                      // (every read of the old carry is done)
+            float* ch = carry + hh * CARRY_HALF;
+            for (int idx = tid; idx < CARRY_HALF; idx += 256) {
+                const int j = idx % 7, qy = idx / 7;              // qy = q * 8 + yy
+                ch[idx] = T[(qy >> 3) * TP + (qy & 7) * 16 + 9 + j];
+            }
+        }
     }
 }
 
@@ -239,10 +295,16 @@ __device__ __forceinline__ void cb_dma2(const float* base, unsigned v0, unsigned
                  : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sb), "s"(lds_addr) : "memory");
 }
 
-__global__ __launch_bounds__(256, 3) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
+#ifndef CB_CARRY
+#define CB_CARRY 1
+#endif
+__global__ __launch_bounds__(256, CB_CARRY ? 2 : 3) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
                                                     int K, float scale, PyrGeom G) {
     // main loop: As[3][BK][BM] | Bs[3][BK][BN] (48 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
     __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_FLOATS ? SMEM_MAIN : SMEM_FLOATS];
+    __shared__ float carry_s[CB_CARRY ? 2 * CARRY_HALF : 1];                 // level 0: the previous patch's last seven columns (28 KB)
+    float* carry = CB_CARRY ? carry_s : nullptr;
+    if (CB_CARRY) for (int i = threadIdx.x; i < 2 * CARRY_HALF; i += 256) carry_s[i] = 0.0f;   // (published by the loop's first barrier)
     const int bz = blockIdx.z, band = blockIdx.x;
     const int m0 = blockIdx.y * BM;
     const int M = G.mp, N = G.np;
@@ -313,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void k_corr_build(const float* __restrict__
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                                   // the repeats issued past the end have landed ...
         __syncthreads();                                                      // ... and every wave is done with the operand tiles the epilogue aliases
-        build_epilogue(acc, smem, pyr, G, scale, bz, m0, band, px, tid);
+        build_epilogue(acc, smem, pyr, G, scale, bz, m0, band, px, tid, carry);
     }
 }
 
