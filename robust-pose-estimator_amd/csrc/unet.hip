@@ -25,38 +25,83 @@ struct UConvHead {
 struct UConvP { UConvHead hd[2]; int b, ho, wo, relu_first, relu_last; };
 
 // valid 3x3 convolution, thread = output pixel x CT output channels:  v = acc + bias; [ReLU]; v = v * scale + shift; [ReLU]
-// (CT = 4 when 16 channels per thread would leave most of the chip idle: one frame pair of sequential tracking)
+// (CT = 4 when 16 channels per thread would leave most of the chip idle: one frame pair of sequential tracking).
+// The weights of UCK input channels at a time ([ci][9][CT], this workgroup's CT output channels) are staged in LDS by the whole
+// workgroup (coalesced, double-buffered) and read back as 16-byte broadcasts: as wave-uniform scalar loads -- 9 x CT per input
+// channel, more than the scalar register file holds -- they were a chain of load latencies (the first layer, 264 -> 16 channels
+// on 62 x 78 pixels: 214 us at batch 1).
+#define UCK 8
 template <int CT>
 __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
+    __shared__ __attribute__((aligned(16))) float wsm[2][UCK * 9 * CT];
     const int head = blockIdx.z / P.b, bz = blockIdx.z % P.b;
     const UConvHead& H = P.hd[head];
     const int co0 = blockIdx.y * CT;
-    if (co0 >= H.cout) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co0 >= H.cout) return;                                   // (workgroup-uniform)
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x * blockDim.x + tid;
     const int npix = P.ho * P.wo;
     const bool ok = p < npix;
     const int y = ok ? p / P.wo : 0, x = ok ? p - (p / P.wo) * P.wo : 0;
     float acc[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) acc[j] = 0.0f;
-    const float* wp = H.w + co0;
+    const int cout = H.cout;
+    // chunk q of the flattened input-channel axis (all sources back to back) -> its weights: rows (ci * 9 + t) of cout floats, of
+    // which this workgroup takes columns [co0, co0 + CT)
+    int cin_total = 0;
+    for (int s = 0; s < H.nsrc; ++s) cin_total += H.src[s].c;
+    const int nchunk = (cin_total + UCK - 1) / UCK;
+    constexpr int WN = UCK * 9 * CT, NLD = (WN + 255) / 256;
+    float wreg[NLD];
+    auto wload = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;                          // e = (ci_local * 9 + t) * CT + j
+            const int row = e / CT, j = e - row * CT;
+            const int ci = q * UCK + row / 9;
+            wreg[i] = (e < WN && ci < cin_total) ? H.w[(size_t)(q * UCK * 9 + row) * cout + co0 + j] : 0.0f;
+        }
+    };
+    auto wstash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < WN) wsm[buf][e] = wreg[i];
+        }
+    };
+    wload(0); wstash(0);
+    __syncthreads();
+    int q = 0, cbase = 0;                                        // cbase: first flattened channel of the current source
     for (int s = 0; s < H.nsrc; ++s) {
         const USrc S = H.src[s];
         const float* base = S.p + (size_t)bz * S.bs + (size_t)(y + S.oy) * S.w + (x + S.ox);
         const size_t plane = (size_t)S.h * S.w;
         for (int ci = 0; ci < S.c; ++ci) {
+            const int cf = cbase + ci;                            // flattened channel
+            if (cf % UCK == 0 && cf > 0) {                        // next chunk (workgroup-uniform: every thread walks the same channels)
+                ++q;
+                __syncthreads();
+            }
+            if (cf % UCK == 0) {                                  // prefetch the chunk after this one while this one is consumed
+                if (q + 1 < nchunk) { wload(q + 1); wstash((q + 1) & 1); }
+            }
             const float* ip = base + (size_t)ci * plane;
             float v[9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = ip[dy * S.w + dx];
+            const float* wl = &wsm[q & 1][(cf % UCK) * 9 * CT];
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int j = 0; j < CT; ++j) acc[j] += v[t] * wp[(size_t)t * H.cout + j];
-            wp += (size_t)9 * H.cout;
+                for (int j = 0; j < CT; j += 4) {
+                    const float4 w4 = *(const float4*)(wl + t * CT + j);
+                    acc[j] += v[t] * w4.x; acc[j + 1] += v[t] * w4.y; acc[j + 2] += v[t] * w4.z; acc[j + 3] += v[t] * w4.w;
+                }
         }
+        cbase += S.c;
     }
     if (!ok) return;
     float* o = H.out + ((size_t)bz * H.cout + co0) * npix + p;
