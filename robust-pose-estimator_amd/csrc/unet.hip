@@ -73,33 +73,64 @@ __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
     wload(0); wstash(0);
     __syncthreads();
     int q = 0, cbase = 0;                                        // cbase: first flattened channel of the current source
+    bool aligned = true;                                         // every source a multiple of UCK channels (the architecture's widths are)
+    for (int s = 0; s < H.nsrc; ++s) aligned = aligned && (H.src[s].c % UCK == 0);
     for (int s = 0; s < H.nsrc; ++s) {
         const USrc S = H.src[s];
         const float* base = S.p + (size_t)bz * S.bs + (size_t)(y + S.oy) * S.w + (x + S.ox);
         const size_t plane = (size_t)S.h * S.w;
-        for (int ci = 0; ci < S.c; ++ci) {
-            const int cf = cbase + ci;                            // flattened channel
-            if (cf % UCK == 0 && cf > 0) {                        // next chunk (workgroup-uniform: every thread walks the same channels)
-                ++q;
-                __syncthreads();
-            }
-            if (cf % UCK == 0) {                                  // prefetch the chunk after this one while this one is consumed
-                if (q + 1 < nchunk) { wload(q + 1); wstash((q + 1) & 1); }
-            }
-            const float* ip = base + (size_t)ci * plane;
-            float v[9];
+        if (aligned) {
+            // a chunk at a time: its 8 x 9 input values are requested together (72 loads in flight per thread instead of 9: the layer
+            // is a latency chain at batch 1), the next chunk's weights travel meanwhile
+            for (int ci0 = 0; ci0 < S.c; ci0 += UCK) {
+                if (cbase + ci0 > 0) { ++q; __syncthreads(); }
+                if (q + 1 < nchunk) wload(q + 1);
+                float v[UCK][9];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+                for (int c = 0; c < UCK; ++c) {
+                    const float* ip = base + (size_t)(ci0 + c) * plane;
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = ip[dy * S.w + dx];
-            const float* wl = &wsm[q & 1][(cf % UCK) * 9 * CT];
+                    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < CT; j += 4) {
-                    const float4 w4 = *(const float4*)(wl + t * CT + j);
-                    acc[j] += v[t] * w4.x; acc[j + 1] += v[t] * w4.y; acc[j + 2] += v[t] * w4.z; acc[j + 3] += v[t] * w4.w;
+                        for (int dx = 0; dx < 3; ++dx) v[c][dy * 3 + dx] = ip[dy * S.w + dx];
                 }
+                if (q + 1 < nchunk) wstash((q + 1) & 1);
+                const float* wl = &wsm[q & 1][0];
+#pragma unroll
+                for (int c = 0; c < UCK; ++c)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int j = 0; j < CT; j += 4) {
+                            const float4 w4 = *(const float4*)(wl + (c * 9 + t) * CT + j);
+                            acc[j] += v[c][t] * w4.x; acc[j + 1] += v[c][t] * w4.y; acc[j + 2] += v[c][t] * w4.z; acc[j + 3] += v[c][t] * w4.w;
+                        }
+            }
+        } else {
+            for (int ci = 0; ci < S.c; ++ci) {
+                const int cf = cbase + ci;                        // flattened channel
+                if (cf % UCK == 0 && cf > 0) {                    // next chunk (workgroup-uniform: every thread walks the same channels)
+                    ++q;
+                    __syncthreads();
+                }
+                if (cf % UCK == 0) {                              // prefetch the chunk after this one while this one is consumed
+                    if (q + 1 < nchunk) { wload(q + 1); wstash((q + 1) & 1); }
+                }
+                const float* ip = base + (size_t)ci * plane;
+                float v[9];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = ip[dy * S.w + dx];
+                const float* wl = &wsm[q & 1][(cf % UCK) * 9 * CT];
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < CT; j += 4) {
+                        const float4 w4 = *(const float4*)(wl + t * CT + j);
+                        acc[j] += v[t] * w4.x; acc[j + 1] += v[t] * w4.y; acc[j + 2] += v[t] * w4.z; acc[j + 3] += v[t] * w4.w;
+                    }
+            }
         }
         cbase += S.c;
     }
