@@ -191,43 +191,68 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ x,
 // launches.  p[i] = first of the two planes of destination i in batch item 0 (NULL = unused), bs[i] = its batch stride in floats.
 struct FlowDst { float* p[3]; long long bs[3]; };
 
-__global__ __launch_bounds__(256) void k_conv3x3_to2(const float* __restrict__ x, const float* __restrict__ wgt,
+#define TO1_WAVES 8                            // channel slices per workgroup (small launches are chains of load latencies: the
+                                              // more slices, the shorter each chain)
+__global__ __launch_bounds__(64 * TO1_WAVES) void k_conv3x3_to2(const float* __restrict__ x, const float* __restrict__ wgt,
                                                      const float* __restrict__ bias, int C, int h, int w,
                                                      const float* __restrict__ add, float* __restrict__ out, FlowDst F) {
-    __shared__ float part[4][2][64];
+    __shared__ float part[TO1_WAVES][2][64];
     const int bz = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: weights by scalar loads
     const size_t hw = (size_t)h * w;
     const size_t p = (size_t)blockIdx.x * 64 + lane;
     const bool inside = p < hw;
     const int py = inside ? (int)(p / w) : 0, px = inside ? (int)(p - (size_t)py * w) : 0;
     const float* xb = x + (size_t)bz * C * hw;
-    // neighbour offsets / validity are the same for every channel
-    int off[9]; bool ok[9];
+    // neighbour offsets (clamped into the map) and 0 / 1 validity factors are the same for every channel: no conditional loads
+    int off[9]; float msk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int yy = py + k / 3 - 1, xx = px + k % 3 - 1;
-        ok[k] = inside && yy >= 0 && yy < h && xx >= 0 && xx < w;
-        off[k] = ok[k] ? yy * w + xx : 0;
+        const bool ok = inside && yy >= 0 && yy < h && xx >= 0 && xx < w;
+        off[k] = ok ? yy * w + xx : py * w + px;
+        msk[k] = ok ? 1.0f : 0.0f;
     }
-    const int cq = (C + 3) / 4, c_lo = wv * cq, c_hi = min(C, c_lo + cq);
+    const int cq = (C + TO1_WAVES - 1) / TO1_WAVES, c_lo = wv * cq, c_hi = min(C, c_lo + cq);
     float a0 = 0.0f, a1 = 0.0f;
-    for (int c = c_lo; c < c_hi; ++c) {
+    constexpr int UN = 4;                                            // channels whose 9 loads each are issued before any is used
+    int c = c_lo;
+    for (; c + UN <= c_hi; c += UN) {
+        float v[UN][9];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[u][k] = xb[(size_t)(c + u) * hw + off[k]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float* w0 = wgt + (size_t)(c + u) * 9;             // (2, C, 3, 3)
+            const float* w1 = wgt + (size_t)(C + c + u) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float t = v[u][k] * msk[k];
+                a0 += t * w0[k];
+                a1 += t * w1[k];
+            }
+        }
+    }
+    for (; c < c_hi; ++c) {
         const float* xc = xb + (size_t)c * hw;
-        const float* w0 = wgt + (size_t)c * 9;                       // (2, C, 3, 3)
+        const float* w0 = wgt + (size_t)c * 9;
         const float* w1 = wgt + (size_t)(C + c) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const float v = ok[k] ? xc[off[k]] : 0.0f;
-            a0 += v * w0[k];
-            a1 += v * w1[k];
+            const float t = xc[off[k]] * msk[k];
+            a0 += t * w0[k];
+            a1 += t * w1[k];
         }
     }
     part[wv][0][lane] = a0; part[wv][1][lane] = a1;
     __syncthreads();
     if (wv == 0 && inside) {
-        a0 = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
-        a1 = ((part[0][1][lane] + part[1][1][lane]) + part[2][1][lane]) + part[3][1][lane];
+        a0 = part[0][0][lane]; a1 = part[0][1][lane];
+#pragma unroll
+        for (int k = 1; k < TO1_WAVES; ++k) { a0 += part[k][0][lane]; a1 += part[k][1][lane]; }
         const size_t o = (size_t)bz * 2 * hw + p;
         a0 += bias ? bias[0] : 0.0f; a1 += bias ? bias[1] : 0.0f;
         if (add) { a0 += add[o]; a1 += add[o + hw]; }
@@ -407,7 +432,7 @@ static int launch_to2(const float* x, const float* weight, const float* bias, in
         hipLaunchKernelGGL(k_conv3x3_to2_x4, dim3(ceil_div((size_t)h * w / 4, 64), b), dim3(64 * TO2_WAVES), 0, (hipStream_t)stream, x, weight, bias,
                            c, h, w, add, out, F);
     else
-        hipLaunchKernelGGL(k_conv3x3_to2, dim3(ceil_div((size_t)h * w, 64), b), dim3(256), 0, (hipStream_t)stream, x, weight, bias,
+        hipLaunchKernelGGL(k_conv3x3_to2, dim3(ceil_div((size_t)h * w, 64), b), dim3(64 * TO1_WAVES), 0, (hipStream_t)stream, x, weight, bias,
                            c, h, w, add, out, F);
     return rpe_check_launch();
 }
