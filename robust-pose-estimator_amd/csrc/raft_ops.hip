@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* 
     }
 }
 
-// One thread per 1/8-resolution cell; loops over the 64 sub-pixels.  Mask channel = k*64 + i*8 + j.
+// One thread per 1/8-resolution cell and sub-pixel row; loops over the row's 8 sub-pixels.  Mask channel = k*64 + i*8 + j.
 __global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict__ flow, const float* __restrict__ mask, int h8,
                                                          int w8, float* __restrict__ out) {
     const int bz = blockIdx.y;
@@ -381,7 +381,10 @@ __global__ __launch_bounds__(256) void k_upsample_convex(const float* __restrict
     const int W = 8 * w8;
     float* ox = out + ((size_t)bz * 2 + 0) * 64 * nq;
     float* oy = out + ((size_t)bz * 2 + 1) * 64 * nq;
-    for (int i = 0; i < 8; ++i) {
+    // blockIdx.z = sub-pixel row i of the 8 x 8 block: eight times the threads of a thread-per-cell loop (a batch-2 launch was 40
+    // workgroups walking 64 sub-pixels each: 96 us of load latency), the same arithmetic per sub-pixel
+    {
+        const int i = blockIdx.z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float m[9], mx = -INFINITY;
@@ -497,6 +500,6 @@ extern "C" int rpe_gru_gates_h(const float* z, const float* q_pre, const float* 
 
 extern "C" int rpe_upsample_convex(const float* flow, const float* mask, int b, int h8, int w8, float* out, void* stream) {
     if (!flow || !mask || !out || b <= 0 || h8 <= 0 || w8 <= 0) return RPE_E_BADARG;
-    hipLaunchKernelGGL(k_upsample_convex, dim3(ceil_div((size_t)h8 * w8, 256), b), dim3(256), 0, (hipStream_t)stream, flow, mask, h8, w8, out);
+    hipLaunchKernelGGL(k_upsample_convex, dim3(ceil_div((size_t)h8 * w8, 256), b, 8), dim3(256), 0, (hipStream_t)stream, flow, mask, h8, w8, out);
     return rpe_check_launch();
 }
