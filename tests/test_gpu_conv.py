@@ -675,3 +675,20 @@ def test_conv1x1_gemm_matches_f64(rpe, cin, cout, h, w, b, mode):
     assert torch.equal(again, obuf[:, 2:2 + cout])
     with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
         ops.conv_fused(xbuf[:, 4:4 + cin], pc, ops.CONV_GATE_H, obuf[:, 2:2 + cout], hidden=obuf[:, 2:2 + cout], zgate=obuf[:, 2:2 + cout], entry='rpe_conv1x1')
+
+
+@pytest.mark.parametrize('cin,cout', [(256, 192), (128, 64), (256, 126), (128, 256)])
+def test_winograd_small_and_large_launches_agree_bitwise(rpe, cin, cout):
+    """rpe_conv_wino runs launches below 512 workgroups on 32-channel tiles (two workgroups per CU hide each other's DMA latency at
+    batch 1-2) and larger ones on 64-channel tiles (+ a 32-channel tail).  Every output element accumulates the same products in the
+    same order either way: a batch of 16 maps (large) must equal the same maps convolved two at a time (small) bit for bit."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout)
+    b, h, w = 16, 64, 80
+    x, wt, bias = _rand(rng, b, cin, h, w, s=0.5).cuda(), _rand(rng, cout, cin, 3, 3, s=0.05).cuda(), _rand(rng, cout, s=0.1).cuda()
+    pw = ops.PackedWino(wt, bias)
+    big = ops.conv_wino(x, pw, ops.CONV_RELU, torch.empty(b, cout, h, w, device='cuda'))
+    assert 40 * -(-cout // 64) * b >= 512 > 40 * -(-cout // 64) * 2                      # the two launch classes
+    for i in range(0, b, 6):
+        small = ops.conv_wino(x[i:i + 2].contiguous(), pw, ops.CONV_RELU, torch.empty(2, cout, h, w, device='cuda'))
+        assert torch.equal(big[i:i + 2], small)
