@@ -818,9 +818,12 @@ extern "C" int rpe_corr_build_ex(const float* fmap1, const float* fmap2, int b, 
                            1.0f / sqrtf((float)c), G);
         return rpe_check_launch();
     }
-    hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.mp, 256), b * c), dim3(256), 0, s, fmap1, Ap, h8, w8, 0, G.gx, G.npx, G.mp);
+    // group order is the map's own row-major order when a row is whole groups (w8 % 8 == 0), and no padding is needed when h8 * w8 is a
+    // multiple of the 128-query tile: fmap1 is then the GEMM's A operand as it stands (16-byte aligned rows for the LDS-DMA)
+    const bool a_in_place = (w8 % 8 == 0) && G.mp == h8 * w8 && (((uintptr_t)fmap1) & 15) == 0;
+    if (!a_in_place) hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.mp, 256), b * c), dim3(256), 0, s, fmap1, Ap, h8, w8, 0, G.gx, G.npx, G.mp);
     hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.np, 256), b * c), dim3(256), 0, s, fmap2, Bp, h8, w8, 1, G.gx, G.npx, G.np);
-    hipLaunchKernelGGL(k_corr_build, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, (const float*)Ap, (const float*)Bp, pyr, c,
+    hipLaunchKernelGGL(k_corr_build, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, a_in_place ? fmap1 : (const float*)Ap, (const float*)Bp, pyr, c,
                        1.0f / sqrtf((float)c), G);
     return rpe_check_launch();
 }

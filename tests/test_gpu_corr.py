@@ -47,6 +47,23 @@ def test_pyramid_and_lookup_match_oracle(rpe, b, h8, w8):
         assert float((out - expect).abs().max()) <= 4e-5 * scale, spread
 
 
+def test_build_reads_fmap1_in_place_when_it_is_already_in_group_order(rpe):
+    """64x80: a row is whole 8-pixel groups and the map is whole query tiles, so the build's A operand is fmap1 itself; a
+    4-byte-offset copy of the same values cannot be (the LDS-DMA needs 16-byte rows) and goes through the permute pass.
+    Same arithmetic either way -> identical pyramid bytes."""
+    from rpe_amd import ops
+    b, h8, w8 = 1, 64, 80
+    f1, f2 = fmaps(5, b, h8, w8)
+    g1, g2 = f1.cuda(), f2.cuda()
+    shifted = torch.empty(g1.numel() + 1, device='cuda')[1:].view_as(g1)
+    shifted.copy_(g1)
+    assert g1.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    p0 = ops.CorrPyramid(b, h8, w8, device='cuda').build(g1, g2)
+    p1 = ops.CorrPyramid(b, h8, w8, device='cuda').build(shifted, g2)
+    for l in range(4):
+        assert torch.equal(p0.export_level(l), p1.export_level(l)), l
+
+
 def test_lookup_taps_bit_exact(rpe):
     """Floor indices of every window tap == floor of torch's grid_sample position, computed explicitly."""
     from rpe_amd import ops
