@@ -15,6 +15,7 @@
 //                   caller's workspace, so the whole N-iteration solve is 2N launches and zero host syncs.
 #include "rpe_common.h"
 #include <cstddef>
+#include <cstdlib>
 #include "se3_device.h"
 
 #define NPART 32          // doubles per partial row: loss2d, loss3d, g[6], H[21], pad
@@ -45,12 +46,14 @@ struct RowUniform {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static int pose_nblk(int n, int h, int w) {
+static int pose_nblk(int n, int h, int w, bool hess = false) {
     int64_t hw = (int64_t)h * w;
     int64_t quads = (hw + 3) / 4;
-    // >= 2 quads per thread, and aim for >= ~1024 blocks chip-wide so all 256 CUs get several waves
+    // >= 2 quads per thread, and ONE resident round of workgroups chip-wide: 256 CUs x 3 workgroups (2 with the Hessian's 29
+    // accumulators: __launch_bounds__ below).  Measured at n = 16, 640x512 (8-iteration solve): 1024 blocks 420 / 664 us (L-BFGS / GN),
+    // 768 413 / 659, 512 419 / 620, 2048 451 / 769 -- a second, partly filled round costs more than the shorter threads gain.
     int64_t per_row = (quads + RED_THREADS * 2 - 1) / (RED_THREADS * 2);
-    int64_t want = (1024 + n - 1) / n;
+    int64_t want = ((hess ? 512 : 768) + n - 1) / n;
     int64_t nblk = per_row < want ? per_row : want;
     if (nblk < 1) nblk = 1;
     int64_t maxblk = (quads + RED_THREADS - 1) / RED_THREADS;
@@ -62,7 +65,7 @@ static int pose_nblk(int n, int h, int w) {
 extern "C" size_t rpe_pose_workspace_bytes(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     size_t st = align_up(sizeof(RowState) * (size_t)n, 256) + align_up(sizeof(RowUniform) * (size_t)n, 256);
-    size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(n, h, w) * n, 256);
+    size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(n, h, w) * n, 256);   // (the Hessian launch never has more blocks)
     return st + pa + 256;
 }
 
@@ -91,7 +94,11 @@ __device__ __forceinline__ void pixel_terms(double* acc, double px, double py, d
     double iz = K[6] * X + K[7] * Y + K[8] * Z;
     double dep = iz < 1e-12 ? 1e-12 : iz;                 // NaN stays NaN, like torch.clamp
     double passz = iz >= 1e-12 ? 1.0 : 0.0;
-    double u = ix / dep, v = iy / dep;
+    // Gauss-Newton (HESS; not on the reference's L-BFGS path, which keeps torch's five IEEE divisions bit for bit): ONE reciprocal --
+    // the hardware's estimate + one Newton step, < 1 ulp -- serves the projection, its gradient and the Jacobian rows below
+    double invd = 0.0;
+    if (HESS) { const double r0 = __builtin_amdgcn_rcp(dep); invd = r0 == 0.0 ? r0 : fma(fma(-dep, r0, 1.0), r0, r0); }   // (1 / inf = 0, as the division gives)
+    double u = HESS ? ix * invd : ix / dep, v = HESS ? iy * invd : iy / dep;
     double fx = px + fl_x, fy = py + fl_y;                // pose_head.py:19
     double ex = fx - u, ey = fy - v;
     double r2 = (ex * ex + ey * ey) * w1;                 // :21-22
@@ -107,12 +114,24 @@ __device__ __forceinline__ void pixel_terms(double* acc, double px, double py, d
     // gradient, multiplied out the way autograd does (0 * nan = nan reaches the pose, as in the reference)
     double a2 = -2.0 * w1 * gate2 * c2;
     double gu = a2 * ex, gv = a2 * ey;
-    double g_ix = gu / dep, g_iy = gv / dep;
-    double g_iz = -(gu * ix + gv * iy) / (dep * dep) * passz;
     double a3 = 2.0 * w2 * gate3 * c3;
-    double gX = K[0] * g_ix + K[3] * g_iy + K[6] * g_iz + a3 * ex3;
-    double gY = K[1] * g_ix + K[4] * g_iy + K[7] * g_iz + a3 * ey3;
-    double gZ = K[2] * g_ix + K[5] * g_iy + K[8] * g_iz + a3 * ez3;
+    double gX, gY, gZ;
+    double Ju[6], Jv[6];                                  // HESS: rows of d(u, v)/d(xi) = d(u, v)/dX [I | -[X]x]
+    if (HESS) {
+        // the same chain rule with the projection's Jacobian rows written out (they are needed for J^T J anyway)
+        const double up = u * passz, vp = v * passz;
+        Ju[0] = (K[0] - up * K[6]) * invd; Ju[1] = (K[1] - up * K[7]) * invd; Ju[2] = (K[2] - up * K[8]) * invd;
+        Jv[0] = (K[3] - vp * K[6]) * invd; Jv[1] = (K[4] - vp * K[7]) * invd; Jv[2] = (K[5] - vp * K[8]) * invd;
+        gX = gu * Ju[0] + gv * Jv[0] + a3 * ex3;
+        gY = gu * Ju[1] + gv * Jv[1] + a3 * ey3;
+        gZ = gu * Ju[2] + gv * Jv[2] + a3 * ez3;
+    } else {
+        double g_ix = gu / dep, g_iy = gv / dep;
+        double g_iz = -(gu * ix + gv * iy) / (dep * dep) * passz;
+        gX = K[0] * g_ix + K[3] * g_iy + K[6] * g_iz + a3 * ex3;
+        gY = K[1] * g_ix + K[4] * g_iy + K[7] * g_iz + a3 * ey3;
+        gZ = K[2] * g_ix + K[5] * g_iy + K[8] * g_iz + a3 * ez3;
+    }
     acc[2] += gX; acc[3] += gY; acc[4] += gZ;            // [I | -[X]x]^T gX
     acc[5] += Y * gZ - Z * gY;
     acc[6] += Z * gX - X * gZ;
@@ -121,15 +140,10 @@ __device__ __forceinline__ void pixel_terms(double* acc, double px, double py, d
         double* Hh = acc + 8;
         double s2 = bad ? 0.0 : 2.0 * w1 * c2;
         double s3 = ok3 ? 2.0 * w2 * c3 : 0.0;
-        double up = u * passz, vp = v * passz;
-        double Ju[6], Jv[6];
-        // (Gauss-Newton only -- not on the reference's L-BFGS path: one reciprocal instead of six f64 divisions; H changes by an ulp.
-        // Measured and NOT adopted: the 21 products as packed f32 FMAs with per-thread f32 partial sums -- 707 -> 642 us per
-        // 8-iteration solve of 16 frames, but the iterates leave the 1e-9 band around the f64 oracle; on CDNA4 an f64 FMA costs what
-        // an f32 one does, so what is left is the five f64 divisions and ~250 instructions of the gradient path itself.)
-        const double invd = 1.0 / dep;
-        Ju[0] = (K[0] - up * K[6]) * invd; Ju[1] = (K[1] - up * K[7]) * invd; Ju[2] = (K[2] - up * K[8]) * invd;
-        Jv[0] = (K[3] - vp * K[6]) * invd; Jv[1] = (K[4] - vp * K[7]) * invd; Jv[2] = (K[5] - vp * K[8]) * invd;
+        // (Measured and NOT adopted: the 21 products as packed f32 FMAs with per-thread f32 partial sums -- 9 % faster, but the
+        // iterates leave the 1e-9 band around the f64 oracle; a two-pixel vector width with three workgroups per CU (161 VGPRs) and
+        // scheduling barriers every other pixel or none -- no change: PMC puts the kernel's vector pipe at 60 % busy with ~280 f64
+        // instructions per pixel, full rate on CDNA4, i.e. the floor of this formulation is ~38 us per evaluation of 16 frames.)
         Ju[3] = Y * Ju[2] - Z * Ju[1]; Ju[4] = Z * Ju[0] - X * Ju[2]; Ju[5] = X * Ju[1] - Y * Ju[0];
         Jv[3] = Y * Jv[2] - Z * Jv[1]; Jv[4] = Z * Jv[0] - X * Jv[2]; Jv[5] = X * Jv[1] - Y * Jv[0];
         if (s2 != 0.0) {
@@ -535,7 +549,7 @@ extern "C" int rpe_pose_reduce(const float* flow, const float* pcl1, const float
     if (!carve(workspace, n, h, w, &st, &uni, &partials)) return RPE_E_BADARG;
     PoseArgs A{flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w};
     hipStream_t s = (hipStream_t)stream;
-    int nblk = pose_nblk(n, h, w);
+    int nblk = pose_nblk(n, h, w, need_hessian != 0);
     hipLaunchKernelGGL(k_pose_prep, dim3(ceil_div(n, 64)), dim3(64), 0, s, uni, T, K, loss_weight, n, h, w);
     launch_reduce(A, uni, nullptr, partials, nblk, need_hessian != 0, s);
     hipLaunchKernelGGL(k_pose_pack, dim3(n), dim3(UPD_THREADS), 0, s, (const double*)partials, nblk, loss_weight, h, w, out);
@@ -571,7 +585,7 @@ extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const f
     if (!carve(workspace, n, h, w, &st, &uni, &partials)) return RPE_E_BADARG;
     PoseArgs A{flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w};
     hipStream_t s = (hipStream_t)stream;
-    int nblk = pose_nblk(n, h, w);
+    int nblk = pose_nblk(n, h, w, mode == RPE_SOLVER_GN);
     hipLaunchKernelGGL(k_pose_init, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, uni, K, loss_weight, n, h, w);
     // LBFGS with max_iter = N costs N evaluations (the last iteration moves without re-evaluating);
     // torch evaluates the closure once even for max_iter = 0.
