@@ -19,6 +19,7 @@
 // group cover all 64 banks.
 #include "wino_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 #define W1_CO 64
 #define W1_NT 64
@@ -39,9 +40,12 @@ struct W1P {
 
 __device__ __forceinline__ int row_swap(int r) { return ((r >> 2) ^ (r >> 3)) & 1; }
 
-template <bool VERT>
+// CB = 16-channel blocks per wave: 2 -> 64 output channels per workgroup; 1 -> 32 (wave = 16 channels x 32 tiles): twice the
+// workgroups for launches that do not fill the chip (sequential tracking).  Same products and summation order: bit-identical outputs.
+template <bool VERT, int CB>
 __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
-    __shared__ __attribute__((aligned(16))) float Us[3][W1_USTEP];            // [ci][co][8 positions], as packed in global memory
+    constexpr int TCO = 32 * CB, UT_STEP = W1_K * TCO * W1_ROW;
+    __shared__ __attribute__((aligned(16))) float Us[3][UT_STEP];             // [ci][co][8 positions], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][W1_USTEP];            // [ci][tile][8 positions]
     __shared__ __attribute__((aligned(16))) float Rs[3][W1_RAWF];             // raw input patch [ci][row][column]
     // every kernel argument in ONE batch of scalar loads (left to the compiler: three dependent fetch - wait rounds, 6-9 k cycles
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     const int pid = blockIdx.x;
 #endif
     const int x0 = (pid % ptx) * 16, y0 = (pid / ptx) * 16;
-    const int co0 = blockIdx.y * W1_CO, bz = blockIdx.z;
+    const int co0 = blockIdx.y * TCO, bz = blockIdx.z;
     const int H = P.H, W = P.W, hw = H * W;
     const float* xb = P.x + (size_t)bz * P.xbs;
     const int nsteps = P.cin / W1_K;
@@ -90,12 +94,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                 if ((oob >> j) & 1) *(f32x4*)&Rs[buf][4 * (LANES * (2 * wv + j) + lane)] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
     };
-    const float* wslice = P.wp + (size_t)(co0 / W1_CO) * W1_USTEP + (size_t)(wv * 2) * 256;
+    // packed weights: [step][64-channel tile][ci][co % 64][8].  CB = 2: the wave's two 1 KB chunks are consecutive; CB = 1: wave = input
+    // channel, its 32 rows (1 KB) start at row co0 % 64 of that channel's 64
+    const float* wslice = CB == 2 ? P.wp + (size_t)(co0 / W1_CO) * W1_USTEP + (size_t)(wv * 2) * 256
+                                  : P.wp + (size_t)(co0 / W1_CO) * W1_USTEP + (size_t)wv * (W1_CO * W1_ROW) + (size_t)(co0 % W1_CO) * W1_ROW;
     const unsigned uoff = lane * 16u;
     const size_t wstep = (size_t)(P.coP / W1_CO) * W1_USTEP, rstep = (size_t)W1_K * hw;
-    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * 2048u, rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(2 * wv) * RSTRIDE;
+    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 2048u : 1024u), rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(2 * wv) * RSTRIDE;
     const unsigned long long lane_mask = (1ull << LANES) - 1ull;
-    auto dma_u = [&](const float* src, int buf) { dma16x2(src, uoff, us_base + (unsigned)buf * (W1_USTEP * 4u)); };
+    auto dma_u = [&](const float* src, int buf) {
+        if (CB == 2) dma16x2(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
+        else dma16x1(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
+    };
     auto dma_raw = [&](const float* src, int buf) { dma16x2_masked<RSTRIDE>(src, roff[0], roff[1], rs_base + (unsigned)buf * (W1_RAWF * 4u), lane_mask); };
     auto clamped = [&](int step) { return step < nsteps ? step : nsteps - 1; };    // (past the end: a harmless repeat keeps the DMA count per step constant)
     const float* xsrc = xb - W1_BIAS / 4;
@@ -132,20 +142,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
         *(f32x4*)&Vs[vbuf][t_dst + 4 * (t_swap ^ 1)] = vhi;
     };
 
-    f32x4 acc[8][2][2];                                        // [position][channel block][tile block]
+    f32x4 acc[8][CB][2];                                       // [position][channel block][tile block]
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < CB; ++c)
 #pragma unroll
             for (int t = 0; t < 2; ++t) acc[p][c][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int cw = wv >> 1, tw = wv & 1, li = lane & 15, lk = lane >> 4;
-    float bi_[2][4];                                            // per-channel bias, requested before the first DMA (conv_wino.hip explains)
+    float bi_[CB][4];                                           // per-channel bias, requested before the first DMA (conv_wino.hip explains)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+            const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
             bi_[cb][r] = P.bias ? P.bias[co < P.cout ? co : P.cout - 1] : 0.0f;
         }
 
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
     dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
     dma_u(wslice + (size_t)clamped(2) * wstep, 2);
-    __builtin_amdgcn_s_waitcnt(0x0F76);                       // vmcnt(2 + 2 + 2)
+    if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F76); else __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(2 + 2 + 2 | 1 + 2 + 1)
     patch_raw(0); patch_raw(1);
     __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
@@ -171,13 +181,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     //   g2 (hi, c0) | read A(hi, c1) | V(s+1) stored | wait: own DMAs older than the newest group landed | border: patch raw(s+2) | BARRIER
     //   g3 (hi, c1) | read A(lo, c0), B(lo, t0), B(lo, t1) of step s+1 | DMA U(s+3) -> U(s)'s buffer, raw(s+4) -> raw(s+1)'s
     const int sl = 4 * row_swap(li);                          // float offset of the logical low half within this lane's rows
-    const int aoff = (lk * W1_CO + cw * 32 + li) * W1_ROW, boff = (lk * W1_NT + tw * 32 + li) * W1_ROW;
+    const int aoff = (lk * TCO + cw * 16 * CB + li) * W1_ROW, boff = (lk * W1_NT + tw * 32 + li) * W1_ROW;
     f32x4 fa = *(const f32x4*)&Us[0][aoff + sl], fb0 = *(const f32x4*)&Vs[0][boff + sl], fb1 = *(const f32x4*)&Vs[0][boff + 16 * W1_ROW + sl];
-    auto mfma_group = [&](int half, int cb, const f32x4& a, const f32x4& b0, const f32x4& b1) {
+    // (CB = 1: the four groups are positions (0-1 | 2-3 | 4-5 | 6-7) of the wave's one channel block, four matrix instructions each)
+    auto mfma_range = [&](int p0, int np, int cb, const f32x4& a, const f32x4& b0, const f32x4& b1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[4 * half + e][cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc[4 * half + e][cb][0], 0, 0, 0);
-            acc[4 * half + e][cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc[4 * half + e][cb][1], 0, 0, 0);
+        for (int e = 0; e < np; ++e) {
+            const int p = p0 + e;
+            acc[p][cb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p & 3], b0[p & 3], acc[p][cb][0], 0, 0, 0);
+            acc[p][cb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p & 3], b1[p & 3], acc[p][cb][1], 0, 0, 0);
         }
     };
     auto step = [&](auto ubc, auto curc, const int s) {
@@ -185,28 +197,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
         const float* ua = &Us[UB][aoff];
         const float* vb = &Vs[CUR][boff];
         // g0
-        const f32x4 a_lo1 = *(const f32x4*)(ua + 16 * W1_ROW + sl);
+        f32x4 a_lo1 = fa;
+        if (CB == 2) a_lo1 = *(const f32x4*)(ua + 16 * W1_ROW + sl);
         tr_read(UB1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 0, fa, fb0, fb1);
+        if (CB == 2) mfma_range(0, 4, 0, fa, fb0, fb1); else mfma_range(0, 2, 0, fa, fb0, fb1);
         __builtin_amdgcn_sched_barrier(0);
         // g1
         const f32x4 a_hi0 = *(const f32x4*)(ua + (sl ^ 4)), b_hi0 = *(const f32x4*)(vb + (sl ^ 4)), b_hi1 = *(const f32x4*)(vb + 16 * W1_ROW + (sl ^ 4));
         __builtin_amdgcn_sched_barrier(0);
         tr_math();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, 1, a_lo1, fb0, fb1);
+        if (CB == 2) mfma_range(0, 4, CB - 1, a_lo1, fb0, fb1); else mfma_range(2, 2, 0, fa, fb0, fb1);
         __builtin_amdgcn_sched_barrier(0);
         // g2
-        const f32x4 a_hi1 = *(const f32x4*)(ua + 16 * W1_ROW + (sl ^ 4));
+        f32x4 a_hi1 = a_hi0;
+        if (CB == 2) a_hi1 = *(const f32x4*)(ua + 16 * W1_ROW + (sl ^ 4));
         __builtin_amdgcn_sched_barrier(0);
         tr_store(CUR ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1, 0, a_hi0, b_hi0, b_hi1);
+        if (CB == 2) mfma_range(4, 4, 0, a_hi0, b_hi0, b_hi1); else mfma_range(4, 2, 0, a_hi0, b_hi0, b_hi1);
         __builtin_amdgcn_sched_barrier(0);
-        // own DMAs except the newest group (2 weight + 2 patch instructions) have landed; the V stores and every fragment read
+        // own DMAs except the newest group (CB weight + 2 patch instructions) have landed; the V stores and every fragment read
         // of this step are complete: after the barrier U(s), V(s) and raw(s+1) may be overwritten
-        __builtin_amdgcn_s_waitcnt(0x0F74);                                      // vmcnt(4)
+        if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F73);     // vmcnt(4 | 3)
         patch_raw(UB2);
         __builtin_amdgcn_s_waitcnt(0xC07F);                                      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
@@ -215,9 +229,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
         fa = *(const f32x4*)&Us[UB1][aoff + sl]; fb0 = *(const f32x4*)&Vs[CUR ^ 1][boff + sl]; fb1 = *(const f32x4*)&Vs[CUR ^ 1][boff + 16 * W1_ROW + sl];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[4 + e][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi1[e], b_hi0[e], acc[4 + e][1][0], 0, 0, 0);
-            acc[4 + e][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi1[e], b_hi1[e], acc[4 + e][1][1], 0, 0, 0);
+        for (int e = 0; e < 2 * CB; ++e) {
+            const int p = CB == 2 ? 4 + e : 6 + e;
+            acc[p][CB - 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi1[p & 3], b_hi0[p & 3], acc[p][CB - 1][0], 0, 0, 0);
+            acc[p][CB - 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi1[p & 3], b_hi1[p & 3], acc[p][CB - 1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (e == 0) { dma_u(unext, UB); if (s + 4 < nsteps) unext += wstep; }
             if (e == 1) { dma_raw(rnext, UB1); if (s + 5 < nsteps) rnext += rstep; }
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     // costs four times the memory instructions of the 1x5 case (PMC: matrix pipe 58 % busy against 68 %), so each 16-lane
     // group first transposes its 16 columns x 4 rows through LDS -- the wave's own slice of the idle weight ring -- and a lane
     // ends up with four consecutive columns of one row: every access below is 16 bytes in both orientations.
-    float* tsc = &Us[0][wv * 512] + lk * 64;
+    float* tsc = &Us[0][wv * (CB == 2 ? 512 : 256)] + lk * 64;
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
         const int tile = tw * 32 + tb * 16 + li;
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
             if (pok) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
         };
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < CB; ++cb) {
             // the four channel rows of a block: every operand of their gate arithmetic is requested first (loaded where it is used,
             // each row waited a memory round trip behind the previous row's store -- the in-place h update keeps the compiler from
             // moving loads across stores), then the arithmetic and the stores
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
             const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+                const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
                 const bool ok = pok && co < P.cout;
                 const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
                 av_[r] = (addb && ok) ? *(const f32x4*)(addb + e0) : zero4;
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + cw * 32 + cb * 16 + 4 * lk + r;
+                const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
                 if (co >= P.cout) continue;
                 float m[8];
 #pragma unroll
@@ -387,8 +402,20 @@ extern "C" int rpe_conv_wino1d(const rpe_conv_desc* d, void* stream) {
     P.H = d->h; P.W = d->w; P.bias = d->bias; P.add = d->add; P.abs_ = d->add_batch_stride;
     P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride;
     P.hid = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels; P.mode = d->mode;
-    const dim3 grid(ceil_div(d->w, 16) * ceil_div(d->h, 16), P.coP / W1_CO, d->b);
-    if (vert) hipLaunchKernelGGL((k_conv_wino1d<true>), grid, dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL((k_conv_wino1d<false>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    // Small launches (sequential tracking: 80-320 workgroups of 64 channels) leave most CUs with one workgroup whose K loop is a chain
+    // of DMA latencies: 32-channel tiles double the workgroups.  Measured (whole pass, 640x512): batch 1 8.43 -> 7.87 ms, 4 frame pairs
+    // 21.9 -> 21.1 ms, 8 pairs equal, 16 pairs (q convolutions: 1 280 workgroups = 2.5 rounds of the 512 slots) 70.96 -> 71.62 ms --
+    // at full occupancy one weight fragment per four matrix instructions beats whole rounds, so only below 1.5 rounds.
+    static const long long small_wg = [] { const char* e = getenv("RPE_WINO1D_SMALL_WG"); return e ? atoll(e) : 768LL; }();
+    const unsigned gx = ceil_div(d->w, 16) * ceil_div(d->h, 16);
+    if ((long long)gx * (P.coP / W1_CO) * d->b < small_wg) {
+        const dim3 grid(gx, ceil_div(d->cout, 32), d->b);
+        if (vert) hipLaunchKernelGGL((k_conv_wino1d<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL((k_conv_wino1d<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, P);
+        return rpe_check_launch();
+    }
+    const dim3 grid(gx, P.coP / W1_CO, d->b);
+    if (vert) hipLaunchKernelGGL((k_conv_wino1d<true, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((k_conv_wino1d<false, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
     return rpe_check_launch();
 }

@@ -32,6 +32,14 @@ __device__ __forceinline__ void dma16x2(const float* base, unsigned voff, unsign
                  "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
+// one 1 KB chunk
+__device__ __forceinline__ void dma16x1(const float* base, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    base = wave_uniform(base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
 // two 1 KB chunks of which only the first `lanes` lanes take part (exec-masked): LDS lds_addr + stride j + lane * 16, the
 // caller folds -stride j into v_j (and a bias that keeps them non-negative into the base)
 template <unsigned STRIDE>

@@ -692,3 +692,31 @@ def test_winograd_small_and_large_launches_agree_bitwise(rpe, cin, cout):
     for i in range(0, b, 6):
         small = ops.conv_wino(x[i:i + 2].contiguous(), pw, ops.CONV_RELU, torch.empty(2, cout, h, w, device='cuda'))
         assert torch.equal(big[i:i + 2], small)
+
+
+@pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
+def test_winograd_1d_tile_classes_agree_bitwise(rpe, kh, kw):
+    """rpe_conv_wino1d runs launches below 768 workgroups (1.5 rounds of the chip's 512 slots) on 32-channel tiles and larger
+    ones on 64-channel tiles; an output element accumulates the same products in the same order either way.  One GRU half on 24
+    maps (z|r: 1 920 workgroups -> 64-channel tiles) must equal the same maps run two at a time (32-channel tiles) bit for bit --
+    gate epilogues, in-place hidden update and all."""
+    from rpe_amd import ops
+    c, b, h, w = 128, 24, 64, 80
+    rng = np.random.default_rng(kh * 7 + kw)
+    hx = _rand(rng, b, 2 * c, h, w, s=0.5).cuda()
+    wzr, bzr, azr = _rand(rng, 2 * c, 2 * c, kh, kw, s=0.03).cuda(), _rand(rng, 2 * c, s=0.1).cuda(), _rand(rng, b, 2 * c, h, w, s=0.3).cuda()
+    wl, bl = _rand(rng, 4 * c, 2 * c, kh, kw, s=0.03).cuda(), _rand(rng, 4 * c, s=0.1).cuda()
+    pzr, pl = ops.PackedWino1d(wzr, bzr), ops.PackedWino1d(wl, bl)
+    assert 20 * 4 * b >= 768 > 20 * 8 * 2                 # (the 512-channel layer of two maps: 320 workgroups of 64 channels)
+
+    def half(hx_in, add):
+        n = hx_in.shape[0]
+        g_hx, g_rhx, g_z = hx_in.clone(), hx_in.clone(), torch.empty(n, c, h, w, device='cuda')
+        ops.conv_wino1d(g_hx, pzr, ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=add, hidden=g_hx[:, :c], gate_channels=c)
+        lin = ops.conv_wino1d(g_rhx, pl, ops.CONV_RELU, torch.empty(n, 4 * c, h, w, device='cuda'))     # 512 channels: eight 64-tiles
+        return g_z, g_rhx, lin
+    big = half(hx, azr)
+    for i in (0, 10, 22):
+        small = half(hx[i:i + 2].contiguous(), azr[i:i + 2].contiguous())
+        for a, s_ in zip(big, small):
+            assert torch.equal(a[i:i + 2], s_)
