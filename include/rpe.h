@@ -284,6 +284,8 @@ typedef struct rpe_conv_desc {
     int b, cin, cout, h, w, kh, kw, mode, gate_channels;  /* h, w: INPUT map                                       */
     int stride;                                          /* 0 or 1: stride 1; 2: the encoders' down-sampling convolutions (3x3 pad 1 or 1x1 pad 0,
                                                           * even h and w, LINEAR / RELU only); the output map is (h/2, w/2)                        */
+    int stats_tiles;                                     /* records per (b, cout) plane of `stats`: 0 = rpe_conv_stats_tiles(cout,h,w,stride), or
+                                                          * the count rpe_conv_stats_tiles_batch returned (small stride-2 launches: 64-pixel tiles) */
 } rpe_conv_desc;
 /* number of floats of the packed form of a (cout, cin, kh, kw) weight tensor (0 on bad arguments) */
 size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
@@ -321,6 +323,10 @@ int rpe_conv1x1(const rpe_conv_desc *desc, void *stream);
 /* number of pixel tiles (= moment records per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input);
  * the launcher and this function share one tile-width rule */
 int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
+/* the same for a batch of b maps: stride-2 launches that would not fill the chip with 128 x 128 tiles (sequential tracking's 2-3 image
+ * batches) run on 64 x 64 tiles and leave one record per 64 pixels; pass the returned count in desc->stats_tiles (and as `tiles` to
+ * rpe_instnorm_apply / rpe_instnorm_finalize) */
+int rpe_conv_stats_tiles_batch(int cout, int h, int w, int stride, int b);
 /* Instance norm (torch.nn.InstanceNorm2d, affine=False; fnet of core/RAFT/core/extractor.py) of x (b,c,hw) given the
  * per-tile (count, mean, M2) records rpe_conv_fused / rpe_stem_conv left in `partials` (b,c,tiles,3) -- or rpe_conv_wino in
  * (b,|tiles|,c,3) when tiles < 0 --, merged in f64 with the parallel-variance formula:

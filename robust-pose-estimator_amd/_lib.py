@@ -28,7 +28,7 @@ class ConvDesc(_c.Structure):
                 ('hidden', _f), ('hidden_batch_stride', _ll), ('zgate', _f), ('zgate_batch_stride', _ll),
                 ('scale', _f), ('residual', _f), ('residual_batch_stride', _ll), ('stats', _f), ('pre_norm', _f),
                 ('b', _i), ('cin', _i), ('cout', _i), ('h', _i), ('w', _i), ('kh', _i), ('kw', _i), ('mode', _i),
-                ('gate_channels', _i), ('stride', _i)]
+                ('gate_channels', _i), ('stride', _i), ('stats_tiles', _i)]
 
 
 # name -> (restype, argtypes); mirrors include/rpe.h one to one
@@ -80,6 +80,7 @@ SIGNATURES = {
     'rpe_conv_wino1d_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino1d': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),
+    'rpe_conv_stats_tiles_batch': (_i, [_i, _i, _i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),
     'rpe_instnorm_apply_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp, _vp]),
     'rpe_instnorm_finalize': (_i, [_vp, _i, _i, _i, _i, _c.c_float, _vp, _vp]),

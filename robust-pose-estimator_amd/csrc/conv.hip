@@ -576,6 +576,8 @@ static inline int conv_cop(int cout) { return (cout + 127) / 128 * 128; }
 // Stride-1 launches use 64(co) x 256(px) tiles when cout is 64 / 96 / 192-like (cout % 128 in 1..96), else 128 x 128.
 // ONE definition: the launcher, rpe_conv_stats_tiles and the statistics consumers must agree on the pixel-tile width.
 static inline bool conv_wide(int cout) { return (cout % 128) != 0 && (cout % 128) <= 96; }
+// stride 2: fewer than two rounds of 128 x 128 workgroups on 256 CUs -> 64 x 64 tiles
+static inline bool conv_s2_small(int cout, int hw_out, int b) { return (long long)ceil_div(hw_out, 128) * ceil_div(cout, 128) * b < 512; }
 
 extern "C" size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw) {
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
@@ -592,7 +594,7 @@ extern "C" int rpe_conv_pack(const float* weight, int cout, int cin, int kh, int
     return rpe_check_launch();
 }
 
-static_assert(sizeof(rpe_conv_desc) == 192, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
+static_assert(sizeof(rpe_conv_desc) == 200, "rpe_conv_desc layout is part of the ABI (ctypes mirror in _lib.py)");
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
@@ -619,8 +621,24 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     P.h = d->hidden; P.hbs = d->hidden_batch_stride; P.z = d->zgate; P.zbs = d->zgate_batch_stride; P.cgate = d->gate_channels;
     P.scale = d->scale; P.res = d->residual; P.rbs = d->residual_batch_stride; P.stats = d->stats; P.pre = d->pre_norm;
     hipStream_t s = (hipStream_t)stream;
-    if (stride == 2) {                               // 128x128 tiles only (the E/O staging doubles the input tile)
-        dim3 g2(ceil_div(P.hw, 128), ceil_div(d->cout, 128), d->b);
+    if (stride == 2) {
+        // 128 x 128 tiles, or 64 x 64 for launches that would leave most CUs with at most one workgroup (sequential tracking's 2-3 image
+        // batches: layer3 of a 640x512 frame is 40 tiles of 128 pixels).  With statistics the caller's buffer decides: its records are
+        // per pixel tile (desc->stats_tiles of them; 0 = rpe_conv_stats_tiles, the 128-pixel tiling).
+        const int t128 = ceil_div(P.hw, 128), t64 = ceil_div(P.hw, 64);
+        bool small = conv_s2_small(d->cout, P.hw, d->b);
+        if (d->stats && t128 != t64) {
+            const int given = d->stats_tiles ? d->stats_tiles : t128;
+            if (given != t128 && given != t64) return RPE_E_BADARG;
+            small = given == t64;
+        }
+        if (small) {
+            dim3 g2(t64, ceil_div(d->cout, 64), d->b);
+            if (d->kw == 3) hipLaunchKernelGGL((k_conv_igemm<3, 2, true, 1, false, true>), g2, dim3(256), 0, s, P);
+            else hipLaunchKernelGGL((k_conv_igemm<1, 2, true, 1, false, true>), g2, dim3(256), 0, s, P);
+            return rpe_check_launch();
+        }
+        dim3 g2(t128, ceil_div(d->cout, 128), d->b);
         if (d->kw == 3) hipLaunchKernelGGL((k_conv_igemm<3, 2, true, 2, false, true>), g2, dim3(256), 0, s, P);
         else hipLaunchKernelGGL((k_conv_igemm<1, 2, true, 2, false, true>), g2, dim3(256), 0, s, P);
         return rpe_check_launch();
@@ -653,6 +671,12 @@ extern "C" int rpe_conv_stats_tiles(int cout, int h, int w, int stride) {
     if (cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2)) return 0;
     if (stride == 2) return ceil_div((int64_t)(h / 2) * (w / 2), 128);
     return ceil_div((int64_t)h * w, conv_wide(cout) ? 256 : 128);     // (a statistics launch is never a "small" 64x64 one)
+}
+
+extern "C" int rpe_conv_stats_tiles_batch(int cout, int h, int w, int stride, int b) {
+    if (cout <= 0 || h <= 0 || w <= 0 || b <= 0 || (stride != 1 && stride != 2)) return 0;
+    if (stride == 2 && conv_s2_small(cout, (h / 2) * (w / 2), b)) return ceil_div((int64_t)(h / 2) * (w / 2), 64);
+    return rpe_conv_stats_tiles(cout, h, w, stride);
 }
 
 extern "C" int rpe_instnorm_apply_ex(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,

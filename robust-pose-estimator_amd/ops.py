@@ -508,9 +508,11 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     if mode in (CONV_LINEAR, CONV_RELU, CONV_TANH) and out2 is not None and out2.shape[1] < pc.cout:
         raise _lib.RpeError('conv_fused: out2 slice has too few channels')
     if stats is not None:
-        tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride)
-        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 3)):
-            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},3) GPU tensor')
+        tiles = (lib().rpe_conv_stats_tiles_batch(pc.cout, hh, ww, stride, b), lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride))
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and stats.shape[2] in tiles
+                and tuple(stats.shape) == (b, pc.cout, stats.shape[2], 3)):
+            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles[0]},3) GPU tensor (conv_stats_buffer)')
+        d.stats_tiles = stats.shape[2]
     d.stats = ptr(stats)
     if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
                                      and tuple(pre_norm.shape) == (b, cin, 2)):
@@ -662,7 +664,7 @@ def _stats_layout(stats, b, c, who):
 
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
     """Per-tile (count, mean, M2) records rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 3); hh, ww = input map."""
-    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 3, dtype=torch.float32, device=device)
+    return torch.empty(b, cout, lib().rpe_conv_stats_tiles_batch(cout, hh, ww, stride, b), 3, dtype=torch.float32, device=device)
 
 
 def instnorm_finalize(stats, hw, eps=1e-5, channels=None):

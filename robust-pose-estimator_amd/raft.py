@@ -157,11 +157,10 @@ def _fusable(conv, x):
     s2 = conv.stride == (2, 2) and hh % 2 == 0 and ww % 2 == 0 and \
         ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
     stride = 2 if s2 else 1
-    # launches of fewer than ~one workgroup per CU (sequential tracking: layer3 of a 2-3 image batch) stay on the library:
-    # the encoder instantiations have no small-tile variant
+    # stride-1 launches of fewer than ~one workgroup per CU that the Winograd kernel cannot take stay on the library (odd maps)
     wide = conv.out_channels % 128 != 0 and conv.out_channels % 128 <= 96
     tiles = -(-(hh // stride) * (ww // stride) // (128 if (s2 or not wide) else 256)) * -(-conv.out_channels // (128 if (s2 or not wide) else 64))
-    big = tiles * x.shape[0] >= 256                            # (measured: below that the library's stride-2 kernels win, 104.9 vs 104.0 frames/s)
+    big = s2 or tiles * x.shape[0] >= 256                      # (stride 2: rpe_conv_fused has its own 64 x 64 tiles for small launches)
     if s1 and WINOGRAD and hh % 2 == 0 and ww % 2 == 0 and conv.in_channels <= 128:
         # the Winograd kernel's workgroups are 16 x 8 pixels x 64 channels: it still wins over the library at a quarter of the chip
         big = big or -(-hh // 8) * -(-ww // 16) * -(-conv.out_channels // 64) * x.shape[0] >= int(os.environ.get('RPE_WINO_MIN_WG', '64'))

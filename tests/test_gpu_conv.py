@@ -252,10 +252,11 @@ def test_vertical_patch_tiles_match_library(rpe, h, w):
 
 
 @pytest.mark.parametrize('cin,cout,k,h,w,b', [(64, 96, 3, 64, 80, 3), (96, 128, 3, 44, 48, 2), (64, 96, 1, 64, 80, 2), (96, 128, 1, 36, 40, 3),
-                                              (16, 32, 3, 12, 16, 1)])
+                                              (16, 32, 3, 12, 16, 1), (64, 96, 3, 128, 160, 14), (64, 96, 1, 128, 160, 14)])
 def test_stride2_convolutions_match_f64(rpe, cin, cout, k, h, w, b):
     """The encoders' down-sampling convolutions: 3x3 stride 2 pad 1 and 1x1 stride 2, with both encoder epilogues
-    (folded batch norm + ReLU; instance-norm partial sums + rpe_instnorm_apply)."""
+    (folded batch norm + ReLU; instance-norm partial sums + rpe_instnorm_apply).  The first five cases are launches of fewer than
+    512 workgroups of 128 x 128 (64 x 64 tiles, one moment record per 64 pixels), the last two run on the 128 x 128 tiles."""
     from rpe_amd import ops
     rng = np.random.default_rng(cin + cout + k + h)
     x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, k, k, s=0.05), _rand(rng, cout, s=0.5)
@@ -275,6 +276,35 @@ def test_stride2_convolutions_match_f64(rpe, cin, cout, k, h, w, b):
     got2 = ops.instnorm_apply(raw, stats, eps=1e-5, relu=False)
     inv = float((1 / torch.sqrt(var + 1e-5)).max())
     assert (got2.cpu().double() - (pre - mean) / torch.sqrt(var + 1e-5)).abs().max() < (_tol(x, wt) + 2e-6) * inv * 2
+
+
+def test_stride2_tile_classes_agree_and_legacy_stats_buffers_work(rpe):
+    """A stride-2 launch below 512 workgroups runs on 64 x 64 tiles: same products, same order, so a batch of 14 (128 x 128 tiles)
+    equals the same maps run two at a time bit for bit.  A statistics buffer sized by rpe_conv_stats_tiles (the 128-pixel tiling,
+    what a caller of the C ABI that does not know the batch rule allocates) keeps the small launch on 128-pixel tiles."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(99)
+    b, cin, cout, h, w = 14, 64, 96, 128, 160
+    x, wt, bias = _rand(rng, b, cin, h, w).cuda(), _rand(rng, cout, cin, 3, 3, s=0.05).cuda(), _rand(rng, cout, s=0.5).cuda()
+    pc = ops.PackedConv(wt, bias)
+    L = rpe.lib()
+    assert L.rpe_conv_stats_tiles_batch(cout, h, w, 2, b) == L.rpe_conv_stats_tiles(cout, h, w, 2) == 40
+    assert L.rpe_conv_stats_tiles_batch(cout, h, w, 2, 2) == 80
+    big = ops.conv_fused(x, pc, ops.CONV_RELU, torch.empty(b, cout, h // 2, w // 2, device='cuda'), stride=2)
+    st_new, st_old = ops.conv_stats_buffer(2, cout, h, w, 'cuda', stride=2), torch.empty(2, cout, 40, 3, device='cuda')
+    assert st_new.shape[2] == 80
+    for i in (0, 6, 12):
+        xs = x[i:i + 2].contiguous()
+        small = ops.conv_fused(xs, pc, ops.CONV_RELU, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stride=2)
+        assert torch.equal(big[i:i + 2], small)
+        raw_new = ops.conv_fused(xs, pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stats=st_new, stride=2)
+        raw_old = ops.conv_fused(xs, pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stats=st_old, stride=2)
+        assert torch.equal(raw_new, raw_old)
+        n_new, n_old = ops.instnorm_apply(raw_new, st_new, eps=1e-5, relu=True), ops.instnorm_apply(raw_old, st_old, eps=1e-5, relu=True)
+        assert (n_new - n_old).abs().max() < 2e-6            # the same moments merged from 80 or 40 records per plane (f64 merge)
+    with pytest.raises(rpe.RpeError):                        # neither tiling
+        ops.conv_fused(x[:2].contiguous(), pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'),
+                       stats=torch.empty(2, cout, 41, 3, device='cuda'), stride=2)
 
 
 def test_stride2_refusals(rpe):

@@ -72,7 +72,7 @@ def test_bad_arguments_return_status_without_a_gpu(rpe):
     assert L.rpe_bias_act(one, null, 1, 4, 16, 1, one, 3, 0, null, 0, 0, null) == -1                   # slice overflow
     # fused convolutions: descriptor validation and the layout of the ctypes mirror
     from rpe_amd import _lib
-    assert ctypes.sizeof(_lib.ConvDesc) == 192
+    assert ctypes.sizeof(_lib.ConvDesc) == 200
     assert L.rpe_conv_packed_floats(256, 256, 1, 5) == (16 * 5 + 1) * 16 * 256 and L.rpe_conv_packed_floats(126, 324, 1, 1) == (21 + 1) * 16 * 128
     assert L.rpe_conv_packed_floats(0, 4, 3, 3) == 0
     assert L.rpe_conv_fused(None, null) == -1 and L.rpe_conv_pack(null, 8, 8, 3, 3, one, null) == -1
