@@ -365,7 +365,7 @@ class BasicMotionEncoder(nn.Module):
         """convf1 -> convf2 (fused route): depends on the flow only, not on the correlation lookup, so RAFT.forward may run it on a
         side stream beside lookup -> convc1 -> convc2."""
         _, cor, flo_buf, c1, c2, f2, cv_ = self._calls(corr, cat_buf, hx, rhx, packed)
-        if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '64')):    # (the library wins only on tiny maps)
+        if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '48')):    # (one 640x512 pair = 48 workgroups; the library wins only on tiny maps)
             ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
         else:
             ops.bias_act(F.conv2d(flow, self.convf1.weight, None, self.convf1.stride, self.convf1.padding), self.convf1.bias, out=flo_buf)
