@@ -28,6 +28,7 @@ extern "C" {
 #define RPE_F32 0
 #define RPE_F64 1
 #define RPE_F16 2      /* rpe_corr_build_ex only: feature maps rounded to fp16 */
+#define RPE_F32X3 3    /* rpe_corr_build_ex only: f32 feature maps, every f32 product evaluated as six bf16 products (3-way exact split) */
 
 /* solver modes of rpe_pose_solve */
 #define RPE_SOLVER_LBFGS 0 /* reference-faithful: torch.optim.LBFGS(lr=1, line_search_fn=None) iterates */

@@ -72,7 +72,8 @@ static bool make_geom(int b, int h8, int w8, int levels, PyrGeom& G) {
     return true;
 }
 
-static size_t scratch_floats(const PyrGeom& G, int c) { return (size_t)G.b * c * ((size_t)G.mp + G.np); }
+// (6 bytes per element: the RPE_F32X3 build keeps both maps as three bf16 planes; the f32 / fp16 builds use 4 / 2 of them)
+static size_t scratch_floats(const PyrGeom& G, int c) { return (size_t)G.b * c * ((size_t)G.mp + G.np) * 3 / 2; }
 
 extern "C" size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels) {
     PyrGeom G;
@@ -451,6 +452,133 @@ __global__ __launch_bounds__(256, 2) void k_corr_build_h(const half4* __restrict
     }
 }
 
+// ---- RPE_F32X3: the f32 correlation with every f32 product evaluated as SIX bf16 products on the 16-bit matrix cores.
+// x = hi + mid + lo EXACTLY (three bf16 pieces of 8 significand bits each: truncation split of the 24-bit significand), and
+//   x y ~= hi hi' + (hi mid' + mid hi') + (hi lo' + lo hi' + mid mid'),   f32 accumulation;
+// the dropped terms (mid lo', lo mid', lo lo') are below 2^-24 |x y|, i.e. below the rounding of the f32 product itself (measured,
+// experiments/bf16x3_probe.hip: RMS error against f64 3.6e-7 vs 4.0e-7 for v_mfma_f32_32x32x2_f32 on the same data).  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per 16 k: 3/8 of the matrix time.
+// Operands: both maps pre-split by the permute pass into the tile-major layout  [b][tile of 128][step of 16 k][plane 3][k half 2]
+// [128 pixels][8 bf16]  -- a step's operand tile is ONE contiguous 12 KB block (its LDS image: plain LDS-DMA copies, three 1 KB
+// chunks per wave and operand) and a lane's eight consecutive k of one plane are one 16-byte LDS read.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+#define X3_TILE 6144                                          // u16 per operand tile of a step (12 KB)
+
+__global__ void k_permute_fmap_x3(const float* __restrict__ f, unsigned short* __restrict__ out, int C, int h8, int w8, int mode, int gx, int npx, int npad) {
+    const int np = blockIdx.x * blockDim.x + threadIdx.x;         // grid.y = b * C/8
+    if (np >= npad) return;
+    int y, x;
+    if (mode == 0) { const int g = np >> 3; y = g / gx; x = (g % gx) * 8 + (np & 7); }
+    else { const int t = np >> 7, r = np & 127; y = (t / npx) * 8 + (r >> 4); x = (t % npx) * 16 + (r & 15); }
+    const int c8 = C / 8, bz = blockIdx.y / c8, cg = blockIdx.y % c8;
+    u16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, mid = hi, lo = hi;
+    if (y < h8 && x < w8) {
+        const float* src = f + ((size_t)bz * C + 8 * cg) * h8 * w8 + (size_t)y * w8 + x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = src[(size_t)e * h8 * w8];
+            const unsigned u = __builtin_bit_cast(unsigned, v) & 0xFFFF0000u;                 // truncation: the pieces do not overlap
+            const float r1 = v - __builtin_bit_cast(float, u);                                // exact
+            const unsigned u1 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, u1);                              // exact; at most 8 significant bits left
+            hi[e] = (unsigned short)(u >> 16); mid[e] = (unsigned short)(u1 >> 16); lo[e] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+        }
+    }
+    const int tile = np >> 7, r = np & 127, ks = cg >> 1, kg = cg & 1, nk = C / 16, ntiles = npad >> 7;
+    unsigned short* dst = out + (((size_t)bz * ntiles + tile) * nk + ks) * X3_TILE + ((size_t)kg * 128 + r) * 8;
+    *(u16x8*)(dst) = hi;
+    *(u16x8*)(dst + 2 * 128 * 8) = mid;
+    *(u16x8*)(dst + 4 * 128 * 8) = lo;
+}
+
+// three 1 KB chunks: global base + voff + 1024 j  ->  LDS lds_addr + 1024 j + lane * 16
+__device__ __forceinline__ void x3_dma3(const void* base, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    const unsigned long long vb = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)vb), hi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+    const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds_addr) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void k_corr_build_x3(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B, float* __restrict__ pyr,
+                                                          int K, float scale, PyrGeom G) {
+    // main loop: 3 x (A tile | B tile) = 72 KB; the epilogue's staging (46 KB) aliases it
+    __shared__ __attribute__((aligned(16))) unsigned short smem3[3 * 2 * X3_TILE];
+    static_assert(3 * 2 * X3_TILE * 2 >= SMEM_FLOATS * 4, "epilogue staging fits the operand rings");
+    const int bz = blockIdx.z, band = blockIdx.x, mt = blockIdx.y, m0 = mt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, lh = lane >> 5;
+    const int nk = K / 16, mtiles = G.mp / BM, ntiles = G.np / BN;
+    const unsigned short* Ab = A + ((size_t)bz * mtiles + mt) * nk * X3_TILE;
+    const unsigned voff = (unsigned)lane * 16u + (unsigned)wv * 3072u;            // this wave's three chunks of a 12 KB tile
+    const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem3 + (unsigned)wv * 3072u;
+    const unsigned b_lds = a_lds + X3_TILE * 2u;
+    // fragment of (plane p, row block i): u16 index ((2 p + lh) * 128 + 64 w + 32 i + l31) * 8
+    const unsigned short* a_l = smem3 + (lh * 128 + wm * 64 + l31) * 8;
+    const unsigned short* b_l = smem3 + X3_TILE + (lh * 128 + wn * 64 + l31) * 8;
+    for (int px = 0; px < G.npx; ++px) {
+        const unsigned short* Bb = B + ((size_t)bz * ntiles + band * G.npx + px) * nk * X3_TILE;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        auto issue = [&](int s, int buf) {
+            const int sc = s < nk ? s : nk - 1;                               // past the end: a harmless repeat keeps the DMA count per step constant
+            x3_dma3(Ab + (size_t)sc * X3_TILE, voff, a_lds + (unsigned)buf * (4u * X3_TILE));
+            x3_dma3(Bb + (size_t)sc * X3_TILE, voff, b_lds + (unsigned)buf * (4u * X3_TILE));
+        };
+        __syncthreads();                                          // the previous patch's epilogue is done with smem
+        issue(0, 0);
+        issue(1, 1);
+        auto step = [&](auto bufc, int s) {
+            constexpr int BUF = decltype(bufc)::value, NB = (BUF + 2) % 3;
+            __builtin_amdgcn_s_waitcnt(0x0F76);                               // vmcnt(6): own DMAs of step s have landed
+            __builtin_amdgcn_s_barrier();                                     // ... everybody's have, and buffer (s + 2) % 3 is free
+            issue(s + 2, NB);
+            const unsigned short* a = a_l + BUF * (2 * X3_TILE);
+            const unsigned short* b = b_l + BUF * (2 * X3_TILE);
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i][p] = *(const bf16x8*)(a + (p * 256 + i * 32) * 8);
+                    fb[i][p] = *(const bf16x8*)(b + (p * 256 + i * 32) * 8);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                                 // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        };
+        {
+            typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+            int s = 0;
+            while (true) {
+                step(I0{}, s); if (++s == nk) break;
+                step(I1{}, s); if (++s == nk) break;
+                step(I2{}, s); if (++s == nk) break;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                   // the repeats issued past the end have landed ...
+        __syncthreads();                                                      // ... and every wave is done with the operand tiles the epilogue aliases
+        build_epilogue(acc, (float*)smem3, pyr, G, scale, bz, m0, band, px, tid);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ lookup
 // The 9 tap positions of one axis at one level.  Tap i reads pixels lo+i+dev_i and lo+i+dev_i+1 with weights
 // (w0, w1); written as three weights over the pixels lo+i, lo+i+1, lo+i+2 so the inner loop has no selects:
@@ -802,7 +930,7 @@ __global__ void k_corr_export(const float* __restrict__ pyr, float* __restrict__
 extern "C" int rpe_corr_build_ex(const float* fmap1, const float* fmap2, int b, int c, int h8, int w8, int levels, int feature_dtype,
                                  void* pyramid, void* stream) {
     PyrGeom G;
-    if (feature_dtype != RPE_F32 && feature_dtype != RPE_F16) return RPE_E_BADARG;
+    if (feature_dtype != RPE_F32 && feature_dtype != RPE_F16 && feature_dtype != RPE_F32X3) return RPE_E_BADARG;
     if (!fmap1 || !fmap2 || !pyramid || c <= 0 || c > 256 || c % BK != 0 || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
     if (((uintptr_t)pyramid) & 15) return RPE_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
@@ -815,6 +943,15 @@ extern "C" int rpe_corr_build_ex(const float* fmap1, const float* fmap2, int b, 
         hipLaunchKernelGGL(k_permute_fmap_h, dim3(ceil_div(G.mp, 256), b * (c / 4)), dim3(256), 0, s, fmap1, Ah, c, h8, w8, 0, G.gx, G.npx, G.mp);
         hipLaunchKernelGGL(k_permute_fmap_h, dim3(ceil_div(G.np, 256), b * (c / 4)), dim3(256), 0, s, fmap2, Bh, c, h8, w8, 1, G.gx, G.npx, G.np);
         hipLaunchKernelGGL(k_corr_build_h, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, (const half4*)Ah, (const half4*)Bh, pyr, c,
+                           1.0f / sqrtf((float)c), G);
+        return rpe_check_launch();
+    }
+    if (feature_dtype == RPE_F32X3) {                         // f32 features, f32 products as six bf16 products (k_corr_build_x3)
+        unsigned short* A3 = (unsigned short*)Ap;
+        unsigned short* B3 = A3 + (size_t)b * c * G.mp * 3;
+        hipLaunchKernelGGL(k_permute_fmap_x3, dim3(ceil_div(G.mp, 256), b * (c / 8)), dim3(256), 0, s, fmap1, A3, c, h8, w8, 0, G.gx, G.npx, G.mp);
+        hipLaunchKernelGGL(k_permute_fmap_x3, dim3(ceil_div(G.np, 256), b * (c / 8)), dim3(256), 0, s, fmap2, B3, c, h8, w8, 1, G.gx, G.npx, G.np);
+        hipLaunchKernelGGL(k_corr_build_x3, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, (const unsigned short*)A3, (const unsigned short*)B3, pyr, c,
                            1.0f / sqrtf((float)c), G);
         return rpe_check_launch();
     }

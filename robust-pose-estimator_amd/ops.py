@@ -218,14 +218,15 @@ class CorrPyramid:
             raise _lib.RpeError('rpe_corr_pyramid_bytes: unsupported geometry')
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
 
-    def build(self, fmap1, fmap2, fp16_features=False):
+    def build(self, fmap1, fmap2, fp16_features=False, bf16x3=False):
         """``fp16_features``: BASELINE config 5 -- both maps are rounded to fp16 and correlated on the 16-bit matrix cores
-        with f32 accumulation; the pyramid stays f32."""
+        with f32 accumulation; the pyramid stays f32.  ``bf16x3``: f32 features, every f32 product evaluated as six bf16 products of
+        an exact three-way split (RPE_F32X3: f32-equivalent results at 3/8 of the matrix time)."""
         f1, f2 = _dev(fmap1, torch.float32, 'fmap1'), _dev(fmap2, torch.float32, 'fmap2')
         b, c, h8, w8 = f1.shape
         if (b, h8, w8) != (self.b, self.h8, self.w8) or f2.shape != f1.shape:
             raise _lib.RpeError('corr build: shape mismatch')
-        check(lib().rpe_corr_build_ex(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, 2 if fp16_features else 0, ptr(self.buf),
+        check(lib().rpe_corr_build_ex(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, 2 if fp16_features else 3 if bf16x3 else 0, ptr(self.buf),
                                       stream_ptr()), 'rpe_corr_build_ex')
         return self
 

@@ -38,6 +38,7 @@ WINOGRAD = os.environ.get('RPE_WINOGRAD', '1') != '0'      # 3x3 layers of the u
 # The motion encoder's flow branch (convf1 -> convf2) on a side stream beside lookup -> convc1 -> convc2.  Measured (MI355X, 640x512):
 # batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
 # launch fills the chip on its own), so it is used for small passes only.  RPE_SIDE_STREAM=0 switches it off.
+CORR_BF16X3 = os.environ.get('RPE_CORR_BF16X3', '0') != '0'   # correlation products as six bf16 products of an exact 3-way split (EXPERIMENT switch)
 SIDE_STREAM = os.environ.get('RPE_SIDE_STREAM', '1') != '0'
 SIDE_STREAM_MAX = 8 * 5120                                     # queries per pass (batch * h/8 * w/8) up to which the side stream is used
 
@@ -649,7 +650,7 @@ class RAFT(nn.Module):
             fmap1, fmap2 = f[:N], f[N:]
         else:
             fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
-        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision)
+        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision, bf16x3=CORR_BF16X3)
         if cnet is None:
             cnet = self.encode_context(image1)                # (tanh(net) | relu(inp))
         c = self.hidden_dim

@@ -331,3 +331,34 @@ def test_fp16_feature_pyramid_matches_oracle(rpe, b, h8, w8):
     # and it really is a different (rounded) result than the f32 build
     f32 = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda()).export_level(0).cpu()
     assert float((f32 - pyr.export_level(0).cpu()).abs().max()) > 1e-4 * scale
+
+
+def test_bf16x3_build_is_f32_equivalent(rpe):
+    """EXPERIMENT switch (RPE_F32X3 / RPE_CORR_BF16X3=1; off by default, never in bench.py's headline): every f32 product of the
+    correlation as six bf16 products of an exact three-way split, f32 accumulation.  Its error against an f64 evaluation must stay
+    within 1.25x the f32 matrix pipe's on the same data (measured 0.85x on Gaussian maps, 1.08x on post-ReLU maps with heavy-tailed
+    channel scales), and the pooled levels / the lookup run on it unchanged."""
+    from rpe_amd import ops
+    b, h8, w8 = 2, 32, 40
+    rng = np.random.default_rng(17)
+    for heavy in (False, True):
+        f1 = torch.from_numpy(rng.normal(size=(b, 256, h8, w8)).astype(np.float32))
+        f2 = torch.from_numpy(rng.normal(size=(b, 256, h8, w8)).astype(np.float32))
+        if heavy:
+            f1 = torch.relu(f1 + 1) * torch.from_numpy(np.exp(0.8 * rng.normal(size=(b, 256, 1, 1))).astype(np.float32))
+            f2 = torch.relu(f2 + 1) * torch.from_numpy(np.exp(0.8 * rng.normal(size=(b, 256, 1, 1))).astype(np.float32))
+        ref = torch.einsum('bcq,bcp->bqp', f1.double().reshape(b, 256, -1), f2.double().reshape(b, 256, -1)) / 16.0
+        errs = {}
+        for name, kw in (('f32', {}), ('x3', dict(bf16x3=True))):
+            pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda(), **kw)
+            got = pyr.export_level(0).cpu().double().reshape(b, h8 * w8, h8 * w8)
+            errs[name] = float((got - ref).pow(2).mean().sqrt())
+            if name == 'x3':
+                oref = oraft.CorrBlock(f1, f2, num_levels=4, radius=4)
+                scale = float(oref.corr_pyramid[0].abs().max())
+                for l in range(1, 4):
+                    assert float((pyr.export_level(l).cpu() - oref.corr_pyramid[l][:, 0]).abs().max()) <= 2e-5 * scale, l
+                coords = coords_for(7, b, h8, w8, 2.0)
+                assert float((pyr.lookup(coords.cuda()).cpu() - oref(coords)).abs().max()) <= 4e-5 * scale
+        print('rms error vs f64:', errs)
+        assert errs['x3'] <= 1.25 * errs['f32'], errs
