@@ -170,7 +170,9 @@ int rpe_corr_build(const float *fmap1, const float *fmap2, int b, int c, int h8,
 /* Same with the precision of the feature maps selectable: feature_dtype = RPE_F32 (as rpe_corr_build) or RPE_F16 =
  * "fp16 features" (BASELINE config 5; RAFT's mixed_precision encoders hand fp16 feature maps to corr.py, which calls
  * .float() on them): both maps are rounded to fp16 (round to nearest even), the products run on the 16-bit matrix cores
- * with f32 accumulation (exact products, f32 sums) and the pyramid stays f32.  c % 16 == 0. */
+ * with f32 accumulation (exact products, f32 sums) and the pyramid stays f32.  c % 16 == 0.
+ * RPE_F32X3 (experiment switch): f32 maps, each f32 product evaluated as six bf16 products of an exact three-way split of both factors,
+ * f32 accumulation -- f32-equivalent results (csrc/corr.hip, k_corr_build_x3). */
 int rpe_corr_build_ex(const float *fmap1, const float *fmap2, int b, int c, int h8, int w8, int levels, int feature_dtype,
                       void *pyramid, void *stream);
 /* coords (b,2,h8,w8) f32 (channel 0 = x, 1 = y) -> out (b, levels*(2r+1)^2, h8, w8) f32, channel order
