@@ -89,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument('--seq-frames', type=int, default=24, help='--mode sequence: frames per GPU (weak scaling)')
     ap.add_argument('--fp16-features', action='store_true',
                     help="BASELINE config 5: fp16 feature maps into the correlation (upstream RAFT's mixed_precision), f32 pyramid, f64 solve")
+    ap.add_argument('--corr-bf16x3', action='store_true',
+                    help='EXPERIMENT (reported under its own dtype, never the headline): the correlation build with every f32 product as six bf16 products of an exact 3-way split (RPE_F32X3)')
     ap.add_argument('--no-extras', action='store_true', help='skip the batch-1 latency / tracker / Gauss-Newton lines')
     return ap.parse_args(argv)
 
@@ -139,6 +141,8 @@ def main():
         dist.all_reduce(ones)                              # a real collective: every rank must have joined
         rccl_ranks = int(ones.item())
 
+    if args.corr_bf16x3:
+        os.environ['RPE_CORR_BF16X3'] = '1'             # read when rpe_amd.raft is imported
     import rpe_amd  # noqa: F401  (raises if librpe_hip.so is missing: no fallback)
     if args.mode == 'sequence':
         res = run_sequence(args, rank, world, dev, dist)
@@ -393,11 +397,12 @@ def run_batch(args, rank, world, dev, dist):
         'ms_per_step': 1e3 * elapsed / max(1, args.steps),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': ('f32 (RAFT / geometry; fp16 feature maps into the correlation) + f64 (SE(3) solve)' if args.fp16_features
+                  else 'f32 (RAFT / geometry; EXPERIMENT: correlation products as six bf16 products of an exact 3-way split) + f64 (SE(3) solve)' if args.corr_bf16x3
                   else 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference'),
         'data': 'synthetic (seeded rendered stereo pairs, seeded random-init weights)',
         'config': {'workload': f'PoseNet.infer, {W}x{H} stereo frame pairs, {B} per GPU per step (RAFT batch {2 * B}), '
                                f'{args.raft_iters} GRU iters, {args.solver} x{args.solver_iters} SE(3) solve, weight heads on'
-                               + (', fp16 features' if args.fp16_features else ''),
+                               + (', fp16 features' if args.fp16_features else '') + (', correlation bf16x3 (experiment)' if args.corr_bf16x3 else ''),
                    'frames_per_gpu': B, 'height': H, 'width': W, 'raft_iters': args.raft_iters,
                    'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
         'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
