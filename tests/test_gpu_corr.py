@@ -65,7 +65,10 @@ def test_build_reads_fmap1_in_place_when_it_is_already_in_group_order(rpe):
 
 
 def test_lookup_taps_bit_exact(rpe):
-    """Floor indices of every window tap == floor of torch's grid_sample position, computed explicitly."""
+    """Floor indices of every window tap (read back through the side entry rpe_corr_lookup_taps) == floor of the position
+    torch's grid_sample computes for upstream's normalised coordinates, RESTATED here in numpy f32 -- not torch.grid_sample itself,
+    which returns no indices; the sampled VALUES are compared with torch's own grid_sample (oracle CorrBlock) in
+    test_pyramid_and_lookup_match_oracle, incl. windows that leave the map and exact-integer / quarter positions."""
     from rpe_amd import ops
     b, h8, w8 = 2, 32, 40
     pyr = ops.CorrPyramid(b, h8, w8, device='cuda')
