@@ -31,7 +31,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md); ~6.3 TB/s achievable
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # what streaming kernels reach on this part (same guide; tools/hbm_roof_probe.py measured 5.3-5.8 TB/s for copy / add)
 
 
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X dense f32 matrix peak (256 CUs x 256 FLOP/clk x 2.4 GHz); the packed-f32 vector pipe shares it
@@ -86,7 +87,8 @@ def parse_args(argv=None):
     ap.add_argument('--solver', default='lbfgs', choices=['lbfgs', 'gn'])
     ap.add_argument('--solver-iters', type=int, default=8)
     ap.add_argument('--cpu-frames', type=int, default=8, help='frames timed on the CPU oracle (0 = skip)')
-    ap.add_argument('--seq-frames', type=int, default=24, help='--mode sequence: frames per GPU (weak scaling)')
+    ap.add_argument('--seq-frames', type=int, default=33, help='--mode sequence: frames per GPU (weak scaling); 33 = 32 pairs = two chunks of 16 at N = 1')
+    ap.add_argument('--seq-chunk', type=int, default=16, help='--mode sequence: frames per RAFT pass (SequenceTracker(chunk=...)); 1 = one frame at a time')
     ap.add_argument('--fp16-features', action='store_true',
                     help="BASELINE config 5: fp16 feature maps into the correlation (upstream RAFT's mixed_precision), f32 pyramid, f64 solve")
     ap.add_argument('--corr-bf16x3', action='store_true',
@@ -141,9 +143,10 @@ def main():
         dist.all_reduce(ones)                              # a real collective: every rank must have joined
         rccl_ranks = int(ones.item())
 
-    if args.corr_bf16x3:
-        os.environ['RPE_CORR_BF16X3'] = '1'             # read when rpe_amd.raft is imported
     import rpe_amd  # noqa: F401  (raises if librpe_hip.so is missing: no fallback)
+    if args.corr_bf16x3:
+        from rpe_amd import raft as _raft
+        _raft.CORR_BF16X3 = True                        # the labelled experiment (its own dtype string below)
     if args.mode == 'sequence':
         res = run_sequence(args, rank, world, dev, dist)
     else:
@@ -163,6 +166,9 @@ def main():
         print(json.dumps(res), flush=True)
 
 
+RANK_MS = {}          # per-rank ms/step (min / max over ranks) of the last timed_region
+
+
 def timed_region(step, steps, warmup, dev, dist):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
     def barrier():
@@ -178,20 +184,31 @@ def timed_region(step, steps, warmup, dev, dist):
     for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
+    busy = time.perf_counter() - t0                  # this rank's own work, without waiting for the others
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own = busy / max(1, steps)
+    RANK_MS.clear()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # each rank's own time per step BEFORE the closing barrier (the MAX-reduced value hides which rank is slow)
+        mine = torch.tensor([own], device=dev, dtype=torch.float64)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        RANK_MS.update(min=1e3 * float(lo), max=1e3 * float(hi))
+    else:
+        RANK_MS.update(min=1e3 * own, max=1e3 * own)
     return elapsed, out
 
 
 def run_sequence(args, rank, world, dev, dist):
     """BASELINE config 4: a stereo sequence sharded over the ranks in contiguous blocks with a one-frame halo
     (rpe_amd.sharding, scripts/infer_trajectory.py:57,71-97 + core/pose/pose_estimator.py:81-91 of the reference),
-    every rank walking its block one frame at a time, ONE all-gather of the relative poses, then gate + prefix product.
+    every rank walking its block in chunks of --seq-chunk frames, ONE all-gather of the relative poses, then gate + prefix product.
     A step = tracking the whole sequence once; value = frames/s over the whole job."""
     from rpe_amd import pose_estimator, pose_net, sharding, synth
     H, W, Fg = args.height, args.width, args.seq_frames
@@ -208,7 +225,7 @@ def run_sequence(args, rank, world, dev, dist):
     K = synth.intrinsics(H, W)
     make = lambda: pose_estimator.PoseEstimator(slam, K, 7.2 * 250.0, model, (W, H)).to(dev)
     get = lambda t: (cache[t][0], cache[t][1], cache[t][2].clone())
-    tracker = sharding.SequenceTracker(make, get)
+    tracker = sharding.SequenceTracker(make, get, chunk=args.seq_chunk)
     import warnings
 
     def step():
@@ -221,6 +238,12 @@ def run_sequence(args, rank, world, dev, dist):
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = bool(float(lo) == float(hi))
+    if not same:                                            # a sharded run whose ranks disagree about the trajectory is a failed run
+        print(f'bench.py --mode sequence: rank {rank}: trajectory checksums differ across ranks ({float(lo)!r} .. {float(hi)!r})', file=sys.stderr)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(3)
     if rank != 0:
         return None
     return {
@@ -230,10 +253,12 @@ def run_sequence(args, rank, world, dev, dist):
         'dtype': 'f32 (RAFT / geometry) + f64 (SE(3) solve), as the reference',
         'data': 'synthetic (independent seeded stereo frames used as a sequence, seeded random-init weights)',
         'config': {'workload': f'SequenceTracker.track, {F} frames of {W}x{H} ({Fg} per GPU, contiguous blocks + 1-frame halo), '
-                               f'batch 1 per frame, {args.raft_iters} GRU iters, {args.solver} x20 solve, one all-gather of (frames,8) f32',
-                   'frames': F, 'frames_per_gpu': Fg, 'parallelism': f'sequence blocks x{world}'},
+                               f'chunks of {args.seq_chunk} frames (one RAFT pass per chunk; bit-identical to one frame at a time), '
+                               f'{args.raft_iters} GRU iters, {args.solver} x20 solve, one all-gather of (frames,8) f32',
+                   'frames': F, 'frames_per_gpu': Fg, 'chunk': args.seq_chunk, 'parallelism': f'sequence blocks x{world}'},
+        'rank_ms_per_step': dict(RANK_MS),
         'poses_finite': bool(torch.isfinite(poses).all()), 'pairs_accepted': int(ok.sum()), 'poses_shape': list(poses.shape),
-        'poses_equal_on_all_ranks': bool(float(lo) == float(hi)), 'poses_checksum': float(chk),
+        'poses_equal_on_all_ranks': same, 'poses_checksum': float(chk),
     }
 
 
@@ -395,6 +420,7 @@ def run_batch(args, rank, world, dev, dist):
         'unit': 'pose solves/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / max(1, args.steps),
+        'rank_ms_per_step': dict(RANK_MS),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': ('f32 (RAFT / geometry; fp16 feature maps into the correlation) + f64 (SE(3) solve)' if args.fp16_features
                   else 'f32 (RAFT / geometry; EXPERIMENT: correlation products as six bf16 products of an exact 3-way split) + f64 (SE(3) solve)' if args.corr_bf16x3
@@ -406,7 +432,8 @@ def run_batch(args, rank, world, dev, dist):
                    'frames_per_gpu': B, 'height': H, 'width': W, 'raft_iters': args.raft_iters,
                    'solver': args.solver, 'solver_iters': args.solver_iters, 'parallelism': f'frames sharded x{world}'},
         'roofline': {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
+                     'frac': achieved / HBM_PEAK_GBS, 'peak_achievable': HBM_ACHIEVABLE_GBS, 'frac_of_achievable': achieved / HBM_ACHIEVABLE_GBS,
+                     'traffic': traffic, 'algorithmic_bytes_per_launch': alg,
                      'avg_launch_us': lk_avg_s * 1e6, 'launches_timed': len(lk_ms), 'traffic_source': traffic_src,
                      'coordinates': 'the final GRU iteration of this run (random-init RAFT: near-uniform drift)', **rounds_own},
         'roofline_pose_solve': pose_roofline(solve_events, B, H, W, args.solver_iters),

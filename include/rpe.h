@@ -46,6 +46,11 @@ extern "C" {
 
 /* Library / build identification, e.g. "rpe-hip 0.1 gfx950". */
 const char *rpe_version(void);
+/* Layout version of this header's structs (rpe_conv_desc, rpe_solve_opts) and signatures: a binding compares it with the
+ * RPE_ABI_VERSION it was written against before the first call (the ctypes binding does, robust-pose-estimator_amd/_lib.py).
+ * 4: rpe_conv_desc is 200 bytes (stats_tiles), stride-2 statistics are one record per 32 output pixels, rpe_pose_solve_ex. */
+#define RPE_ABI_VERSION 4
+int rpe_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * SE(3) group ops -- replace the lietorch C++/CUDA kernels the reference calls through
@@ -102,6 +107,26 @@ int rpe_pose_solve_opts(const float *flow, const float *pcl1, const float *pcl2,
                         int n, int h, int w, int mode, int iters, double tolerance_grad, double tolerance_change,
                         int history_size, double *T_out, float *vec7, float *log6, int32_t *info, void *workspace,
                         void *stream);
+
+/* The same with the options in a sized struct (new fields can follow without breaking callers: struct_size must be
+ * sizeof(rpe_solve_opts) of the header the caller was built against).
+ *   partition_rows: the pixel reduction sums per-block partials in a fixed order, and the number of blocks per row is chosen so that
+ *   ONE round of workgroups covers the batch -- so a row's float64 sums are grouped differently in a 16-row launch than alone.
+ *   0 = that default; p > 0 = the partition a p-row batch would get.  With p = 1 every row's iterates are bit-identical to solving
+ *   it alone, whatever the batch (what the chunked sequence tracker asks for: core/pose/pose_estimator.py:98-125 solves one frame at
+ *   a time).  rpe_pose_workspace_bytes covers every choice. */
+typedef struct rpe_solve_opts {
+    int struct_size;             /* sizeof(rpe_solve_opts) */
+    int history_size;            /* 1..100 (torch.optim.LBFGS default 100) */
+    double tolerance_grad;       /* 1e-7 */
+    double tolerance_change;     /* 1e-9 */
+    int partition_rows;          /* 0 = n */
+    int reserved;                /* 0 */
+} rpe_solve_opts;
+int rpe_pose_solve_ex(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
+                      const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
+                      int n, int h, int w, int mode, int iters, const rpe_solve_opts *opts, double *T_out, float *vec7,
+                      float *log6, int32_t *info, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Backward of the declarative pose layer (training): replaces DeclarativeNodeLie.gradient /
@@ -287,8 +312,8 @@ typedef struct rpe_conv_desc {
     int b, cin, cout, h, w, kh, kw, mode, gate_channels;  /* h, w: INPUT map                                       */
     int stride;                                          /* 0 or 1: stride 1; 2: the encoders' down-sampling convolutions (3x3 pad 1 or 1x1 pad 0,
                                                           * even h and w, LINEAR / RELU only); the output map is (h/2, w/2)                        */
-    int stats_tiles;                                     /* records per (b, cout) plane of `stats`: 0 = rpe_conv_stats_tiles(cout,h,w,stride), or
-                                                          * the count rpe_conv_stats_tiles_batch returned (small stride-2 launches: 64-pixel tiles) */
+    int stats_tiles;                                     /* records per (b, cout) plane of `stats`: 0 or rpe_conv_stats_tiles(cout,h,w,stride)
+                                                          * (checked when non-zero; it selects nothing) */
 } rpe_conv_desc;
 /* number of floats of the packed form of a (cout, cin, kh, kw) weight tensor (0 on bad arguments) */
 size_t rpe_conv_packed_floats(int cout, int cin, int kh, int kw);
@@ -323,12 +348,12 @@ int rpe_conv_wino1d(const rpe_conv_desc *desc, void *stream);
 size_t rpe_conv1x1_packed_floats(int cout, int cin);
 int rpe_conv1x1_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv1x1(const rpe_conv_desc *desc, void *stream);
-/* number of pixel tiles (= moment records per (b, channel) plane) rpe_conv_fused uses for this shape (h, w: input);
- * the launcher and this function share one tile-width rule */
+/* number of moment records per (b, channel) plane rpe_conv_fused leaves for this shape (h, w: input): stride 1 one per pixel
+ * tile (the launcher and this function share one tile-width rule); stride 2 one per 32 output pixels -- in both of its tile
+ * classes (128 x 128, or 64 x 64 for launches too small to fill the chip), bit-identical between them, so an image's statistics
+ * do not depend on how many images share the launch */
 int rpe_conv_stats_tiles(int cout, int h, int w, int stride);
-/* the same for a batch of b maps: stride-2 launches that would not fill the chip with 128 x 128 tiles (sequential tracking's 2-3 image
- * batches) run on 64 x 64 tiles and leave one record per 64 pixels; pass the returned count in desc->stats_tiles (and as `tiles` to
- * rpe_instnorm_apply / rpe_instnorm_finalize) */
+/* round-3 name, kept: the count no longer depends on the batch (returns rpe_conv_stats_tiles; 0 for b <= 0) */
 int rpe_conv_stats_tiles_batch(int cout, int h, int w, int stride, int b);
 /* Instance norm (torch.nn.InstanceNorm2d, affine=False; fnet of core/RAFT/core/extractor.py) of x (b,c,hw) given the
  * per-tile (count, mean, M2) records rpe_conv_fused / rpe_stem_conv left in `partials` (b,c,tiles,3) -- or rpe_conv_wino in

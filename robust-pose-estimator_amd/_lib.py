@@ -31,9 +31,18 @@ class ConvDesc(_c.Structure):
                 ('gate_channels', _i), ('stride', _i), ('stats_tiles', _i)]
 
 
+ABI_VERSION = 4            # RPE_ABI_VERSION of include/rpe.h these struct mirrors were written against
+
+
+class SolveOpts(_c.Structure):
+    """struct rpe_solve_opts (include/rpe.h)."""
+    _fields_ = [('struct_size', _i), ('history_size', _i), ('tolerance_grad', _d), ('tolerance_change', _d), ('partition_rows', _i), ('reserved', _i)]
+
+
 # name -> (restype, argtypes); mirrors include/rpe.h one to one
 SIGNATURES = {
     'rpe_version': (_c.c_char_p, []),
+    'rpe_abi_version': (_i, []),
     'rpe_se3_exp': (_i, [_vp, _vp, _i64, _i, _vp]),
     'rpe_se3_log': (_i, [_vp, _vp, _i64, _i, _vp]),
     'rpe_se3_mul': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
@@ -44,6 +53,7 @@ SIGNATURES = {
     'rpe_pose_reduce': (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_pose_solve': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rpe_pose_solve_opts': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rpe_pose_solve_ex': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _c.POINTER(SolveOpts), _vp, _vp, _vp, _vp, _vp, _vp]),
     'rpe_pose_backward_workspace_bytes': (_sz, [_i, _i, _i]),
     'rpe_pose_backward_moments': (_i, [_vp] * 10 + [_i, _i, _i, _vp, _vp, _vp]),
     'rpe_pose_backward_grads': (_i, [_vp] * 11 + [_i, _i, _i] + [_vp] * 6),
@@ -128,6 +138,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.rpe_abi_version() != ABI_VERSION:
+            raise RpeError(f'{LIB_PATH} has ABI version {L.rpe_abi_version()}, this binding expects {ABI_VERSION} (struct layouts of include/rpe.h): rebuild')
         _lib = L
     return _lib
 

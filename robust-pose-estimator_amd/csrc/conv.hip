@@ -398,8 +398,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
             }
         return;
     }
-    float* red = &As[0][0][0];                                   // [WN][BM][3] partial statistics (sum d, sum d^2, pivot) (LDS is free now:
+    float* red = &As[0][0][0];                                   // [WN * NS][BM][3] partial statistics (sum d, sum d^2, pivot) (LDS is free now:
                                                                  // nothing reads the tiles after the last barrier)
+    constexpr int NS = S2 ? T : 1;                               // statistics blocks per wave
+    static_assert(WN * NS * 3 <= 2 * KS, "statistics scratch must fit the weights tiles");
     // Four channel rows x T column blocks per batch: the residual loads of a batch are issued back to back from clamped
     // in-range addresses (per-element validity branches made the compiler emit load - wait - store per element), then
     // the arithmetic, then stores under the lane mask.
@@ -447,28 +449,56 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
                 // Instance-norm statistics are taken about a PIVOT (this wave's first column of the channel row), not about
                 // zero: sum(v - p) and sum((v - p)^2) keep their digits when |mean| >> std (a large conv bias is pure shift;
                 // E[v^2] - mean^2 from f32 sums loses mean^2/var * 1e-7 of the variance).
-                const float piv = P.stats ? __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv[0]), 32)
-                                                                         : __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv[0]), 0)) : 0.0f;
-                float ssum = 0.0f, ssq = 0.0f;
+                // Stride 2 (NS = T): one record per 32-pixel block of the plane, whatever the tile class -- a 64 x 64-tile launch
+                // (small batches) and a 128 x 128-tile one leave the SAME records, so the statistics of an image do not depend on
+                // how many images share the launch (the chunked sequence tracker relies on that).
+                float piv[NS], ssum[NS], ssq[NS];
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) {
+                    const int vb = __builtin_bit_cast(int, vv[S2 ? s2 : 0]);
+                    piv[s2] = P.stats ? __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(vb, 32) : __builtin_amdgcn_readlane(vb, 0)) : 0.0f;
+                    ssum[s2] = 0.0f; ssq[s2] = 0.0f;
+                }
 #pragma unroll
                 for (int j = 0; j < T; ++j) {
                     float v = vv[j];
-                    if (ok[j][r]) { const float dv = v - piv; ssum += dv; ssq += dv * dv; }
+                    if (ok[j][r]) { const float dv = v - piv[S2 ? j : 0]; ssum[S2 ? j : 0] += dv; ssq[S2 ? j : 0] += dv * dv; }
                     if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;
                     if (resb) { v = rv[j][r] + v; v = v < 0.0f ? 0.0f : v; }
                     if (ok[j][r]) { outb[e[j][r]] = v; if (out2b) out2b[e[j][r]] = v; }
                 }
                 if (P.stats) {                                   // sum over the 32 lanes that share this channel row
-                    ssum = half_wave_sum(ssum); ssq = half_wave_sum(ssq);
                     const int row = row0 + r + 8 * (rb >> 2);
-                    if (l31 == 31) { red[(wn * BM + row) * 3] = ssum; red[(wn * BM + row) * 3 + 1] = ssq; red[(wn * BM + row) * 3 + 2] = piv; }
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) {
+                        const float a = half_wave_sum(ssum[s2]), q = half_wave_sum(ssq[s2]);
+                        float* rd = red + ((wn * NS + s2) * BM + row) * 3;
+                        if (l31 == 31) { rd[0] = a; rd[1] = q; rd[2] = piv[s2]; }
+                    }
                 }
             }
         }
     }
     if (P.stats) {                                               // combine the WN waves that cover the same channels
         __syncthreads();
-        if (tid < BM && m0 + tid < P.cout) {
+        if (S2) {
+            const int nrec = (hw + 31) / 32;
+            if (tid < BM && m0 + tid < P.cout) {
+#pragma unroll
+                for (int w2 = 0; w2 < WN; ++w2)
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) {
+                        const int blk = (n0 + w2 * WT + s2 * 32) >> 5;
+                        if (blk >= nrec) continue;
+                        int nw = hw - blk * 32; nw = nw > 32 ? 32 : nw;                    // valid columns of the block (>= 1)
+                        const float* rd = red + ((w2 * NS + s2) * BM + tid) * 3;
+                        StatAcc A;
+                        A.add_pivoted(nw, rd[0], rd[1], rd[2]);
+                        float* st = P.stats + (((size_t)bz * P.cout + m0 + tid) * nrec + blk) * 3;
+                        st[0] = (float)A.n; st[1] = (float)A.mean; st[2] = (float)A.m2;
+                    }
+            }
+        } else if (tid < BM && m0 + tid < P.cout) {
             StatAcc A;
 #pragma unroll
             for (int w2 = 0; w2 < WN; ++w2) {
@@ -626,15 +656,11 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (stride == 2) {
         // 128 x 128 tiles, or 64 x 64 for launches that would leave most CUs with at most one workgroup (sequential tracking's 2-3 image
-        // batches: layer3 of a 640x512 frame is 40 tiles of 128 pixels).  With statistics the caller's buffer decides: its records are
-        // per pixel tile (desc->stats_tiles of them; 0 = rpe_conv_stats_tiles, the 128-pixel tiling).
+        // batches: layer3 of a 640x512 frame is 40 tiles of 128 pixels).  Statistics are one record per 32 output pixels in BOTH classes
+        // (rpe_conv_stats_tiles), bit-identical between them; desc->stats_tiles, when given, must be that count.
         const int t128 = ceil_div(P.hw, 128), t64 = ceil_div(P.hw, 64);
-        bool small = conv_s2_small(d->cout, P.hw, d->b);
-        if (d->stats && t128 != t64) {
-            const int given = d->stats_tiles ? d->stats_tiles : t128;
-            if (given != t128 && given != t64) return RPE_E_BADARG;
-            small = given == t64;
-        }
+        const bool small = conv_s2_small(d->cout, P.hw, d->b);
+        if (d->stats && d->stats_tiles != 0 && d->stats_tiles != ceil_div(P.hw, 32)) return RPE_E_BADARG;
         if (small) {
             dim3 g2(t64, ceil_div(d->cout, 64), d->b);
             if (d->kw == 3) hipLaunchKernelGGL((k_conv_igemm<3, 2, true, 1, false, true>), g2, dim3(256), 0, s, P);
@@ -672,13 +698,13 @@ extern "C" int rpe_conv_fused(const rpe_conv_desc* d, void* stream) {
 
 extern "C" int rpe_conv_stats_tiles(int cout, int h, int w, int stride) {
     if (cout <= 0 || h <= 0 || w <= 0 || (stride != 1 && stride != 2)) return 0;
-    if (stride == 2) return ceil_div((int64_t)(h / 2) * (w / 2), 128);
-    return ceil_div((int64_t)h * w, conv_wide(cout) ? 256 : 128);     // (a statistics launch is never a "small" 64x64 one)
+    if (stride == 2) return ceil_div((int64_t)(h / 2) * (w / 2), 32);  // one record per 32 output pixels, in either tile class
+    return ceil_div((int64_t)h * w, conv_wide(cout) ? 256 : 128);     // (a stride-1 statistics launch is never a "small" 64x64 one)
 }
 
+// Kept for callers of the round-3 ABI: the record count no longer depends on the batch.
 extern "C" int rpe_conv_stats_tiles_batch(int cout, int h, int w, int stride, int b) {
-    if (cout <= 0 || h <= 0 || w <= 0 || b <= 0 || (stride != 1 && stride != 2)) return 0;
-    if (stride == 2 && conv_s2_small(cout, (h / 2) * (w / 2), b)) return ceil_div((int64_t)(h / 2) * (w / 2), 64);
+    if (b <= 0) return 0;
     return rpe_conv_stats_tiles(cout, h, w, stride);
 }
 

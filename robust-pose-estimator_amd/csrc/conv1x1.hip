@@ -51,6 +51,12 @@ __device__ __forceinline__ void store_sv(float* base, unsigned voff, float v) {
     asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(v), "s"(base) : "memory");
 }
 
+// LDS row rho of a step's operand tiles holds input channel rho / 2 + 8 (rho & 1) of the step: matrix instruction j of a step then adds
+// the products of channels j and 8 + j, in that order -- exactly rpe_conv_fused's k_conv_igemm (its lane half lh of k2-step j supplies
+// k = 8 lh + j).  Same products in the same order: the two kernels agree BIT FOR BIT, so which of them ops.Conv1x1 picks for a launch
+// (by its workgroup count) never shows in the result (tests/test_gpu_conv.py::test_conv1x1_routes_agree_bitwise).
+__host__ __device__ __forceinline__ int g1_chan(int rho) { return (rho >> 1) + 8 * (rho & 1); }
+
 template <int MODE, bool OUT2>
 __global__ __launch_bounds__(256, G1_OCC) void k_conv1x1(G1P P) {
     __shared__ __attribute__((aligned(16))) float As[3][G1_TILE];             // [k][co], as packed in global memory
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256, G1_OCC) void k_conv1x1(G1P P) {
     unsigned boff[2], boff_last[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int k = 4 * wv + 2 * j + bh;
+        const int k = g1_chan(4 * wv + 2 * j + bh);                           // LDS row -> input channel of the step
         boff[j] = (unsigned)((size_t)k * hw + pxl) * 4u + G1_BIAS - 1024u * j;
         int kl = (nsteps - 1) * G1_K + k; kl = kl < cin ? kl : cin - 1;       // last step: clamp the channel
         boff_last[j] = (unsigned)((size_t)(kl - (nsteps - 1) * G1_K) * hw + pxl) * 4u + G1_BIAS - 1024u * j;
@@ -188,14 +194,14 @@ __global__ __launch_bounds__(256, G1_OCC) void k_conv1x1(G1P P) {
     }
 }
 
-// weight (cout, cin, 1, 1) -> [co tile = co / 128][step = ci / 16][k = ci % 16][co % 128], zero beyond cin / cout
+// weight (cout, cin, 1, 1) -> [co tile = co / 128][step = ci / 16][row rho: ci % 16 = g1_chan(rho)][co % 128], zero beyond cin / cout
 __global__ void k_conv1x1_pack(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int nsteps, long long total) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     const int col = (int)(e & 127), k = (int)((e >> 7) & 15);
     const long long rest = e >> 11;
     const int step = (int)(rest % nsteps), tile = (int)(rest / nsteps);
-    const int co = tile * 128 + col, ci = step * G1_K + k;
+    const int co = tile * 128 + col, ci = step * G1_K + g1_chan(k);
     wp[e] = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
 }
 

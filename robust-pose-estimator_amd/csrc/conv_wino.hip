@@ -21,8 +21,13 @@
 // channel | tile) row are contiguous, so a lane's fragments for four positions are one 16-B LDS read.
 #include "wino_common.h"
 #include <type_traits>
-#include <cstdlib>
 
+#ifndef WINO_RQ_ASM
+#define WINO_RQ_ASM 1
+#endif
+#ifndef WINO_RQ_SHIFT
+#define WINO_RQ_SHIFT 1
+#endif
 #define WB_CO 64
 #define WB_TX 8
 #define WB_TY 4
@@ -77,13 +82,20 @@ extern "C" int rpe_debug_wino_timing(unsigned long long* out8) { return hipMemcp
 // EPI = the epilogue's compile-time shape: 0 bias / ReLU / out2 (update block); 1 + scale and residual (cnet: folded batch norm);
 // 2 + moments (fnet); 3 all of them at run time.  (With every feature behind a run-time branch the encoder epilogue took 14-22 k
 // cycles per workgroup against 9 k for the plain one.)
-template <int EPI, bool PRE, int CB>
+// RQ: the raw patch arrives as 16-byte quads -- rows [x0 - 4, x0 + 20) of the map, 24 floats apart in LDS, ONE global_load_lds_dwordx4 per
+// wave and step instead of three dword gathers (a DMA instruction costs the issuing wave 40-60 cycles among matrix instructions), and
+// the 24-float row pitch puts the transform's four tile rows on disjoint banks (with 18-float rows the 8-byte patch reads of tile rows
+// 0 / 2 and 1 / 3 overlapped on 8 banks: half of the kernel's LDS bank-conflict cycles).  Needs W % 4 == 0 and 16-byte aligned planes
+// (quads are then wholly inside or wholly outside the map); other shapes keep the dword gather (RQ = false).
+template <int EPI, bool PRE, int CB, bool RQ>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     constexpr bool HAS_AFFINE = EPI == 1 || EPI == 3, HAS_STATS = EPI == 2 || EPI == 3;
     constexpr int TCO = 32 * CB, UT_STEP = WK * TCO * 16;
+    constexpr int RROW = RQ ? 24 : RAW_W, RCH = RROW * RAW_H, RBUF = RQ ? 1024 : RAW_BUF, RCOL0 = RQ ? 3 : 0;   // (patch column 0 = map column x0 - 1)
+    constexpr int NRAW = RQ ? 1 : 3;                                         // raw-patch DMA instructions per wave and step
     __shared__ __attribute__((aligned(16))) float Us[3][UT_STEP];            // [ci][co][position], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
-    __shared__ __attribute__((aligned(16))) float Rs[3][RAW_BUF];            // raw input patches [ci][row][col]
+    __shared__ __attribute__((aligned(16))) float Rs[3][RBUF];               // raw input patches [ci][row][col]
     __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // PRE: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
     // every kernel argument the set-up needs is fetched in ONE batch of scalar loads: left to the compiler they were three
     // dependent fetch - wait rounds (6-9 k cycles before the first DMA could be issued, of a 16-step workgroup's 57 k)
@@ -117,24 +129,44 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     // value once they have landed (patch_raw), so the transform itself carries no masks.  U: chunk c = 4*wave + j, plain copy.
     unsigned roff[3];                                         // byte offsets from (step's first channel - 512 B), chunk offset folded in
     unsigned oob = 0;                                         // bit j: this lane's element of chunk j is outside the map
+    if (RQ) {
+        // quad q = 64 * wave + lane -> (ci, row, quad column) of the 4 x 10 x 6 quads; lanes past 240 repeat the last quad into the
+        // buffer's slack.  Out-of-map quads read a clamped in-map quad and are overwritten once landed (patch_raw)
+        const int q0 = wv * 64 + lane, q = q0 < 240 ? q0 : 239;
+        const int ci = q / 60, rem = q - ci * 60, r = rem / 6, qc = rem - r * 6;
+        int yy = y0 - 1 + r, xx = x0 - 4 + 4 * qc;
+        if (q0 < 240 && (yy < 0 || yy >= H || xx < 0 || xx >= W)) oob = 1u;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 4 : xx);
+        roff[0] = (unsigned)(ci * hw + yy * W + xx) * 4u; roff[1] = roff[2] = 0u;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int e0 = (wv * 3 + j) * 64 + lane;
-        const int e = e0 < RAW_N ? e0 : RAW_N - 1;
-        const int ci = e / RAW_CH, rem = e - ci * RAW_CH, r = rem / RAW_W, c = rem - r * RAW_W;
-        int yy = y0 - 1 + r, xx = x0 - 1 + c;
-        if (e0 < RAW_N && (yy < 0 || yy >= H || xx < 0 || xx >= W)) oob |= 1u << j;
-        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-        roff[j] = (unsigned)(ci * hw + yy * W + xx) * 4u + 512u - 256u * j;
+        for (int j = 0; j < 3; ++j) {
+            const int e0 = (wv * 3 + j) * 64 + lane;
+            const int e = e0 < RAW_N ? e0 : RAW_N - 1;
+            const int ci = e / RAW_CH, rem = e - ci * RAW_CH, r = rem / RAW_W, c = rem - r * RAW_W;
+            int yy = y0 - 1 + r, xx = x0 - 1 + c;
+            if (e0 < RAW_N && (yy < 0 || yy >= H || xx < 0 || xx >= W)) oob |= 1u << j;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            roff[j] = (unsigned)(ci * hw + yy * W + xx) * 4u + 512u - 256u * j;
+        }
     }
+    // (RQ: the patch's right halo column x0 + 16 sits in a quad of its own, so a patch ending exactly at the map's edge is a border one)
     const bool border = (y0 < 1) | (y0 + 2 * WB_TY >= H) | (x0 < 1) | (x0 + 2 * WB_TX >= W);       // workgroup-uniform
     // padding: zero; with the loader-side normalisation -inf, which relu((x - mean) / std) turns into the zero torch pads with (1/std > 0)
     const float padv = PRE ? -__builtin_inff() : 0.0f;
     auto patch_raw = [&](int buf) {
         if (border) {
+            if (RQ) {
+                if (oob) {
+                    float* q4 = &Rs[buf][4 * (wv * 64 + lane) + (WINO_RQ_SHIFT ? 1 : 0)];
+                    if (WINO_RQ_SHIFT) { q4[0] = padv; q4[1] = padv; q4[2] = padv; q4[3] = padv; }
+                    else *(f32x4*)q4 = (f32x4){padv, padv, padv, padv};
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if ((oob >> j) & 1) Rs[buf][(wv * 3 + j) * 64 + lane] = padv;
+                for (int j = 0; j < 3; ++j)
+                    if ((oob >> j) & 1) Rs[buf][(wv * 3 + j) * 64 + lane] = padv;
+            }
         }
     };
     // packed weights: [step][64-channel tile][ci][co % 64][16].  CB = 2: the wave's four 1 KB chunks are consecutive; CB = 1: wave =
@@ -143,14 +175,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
                                   : P.wp + (size_t)(co0 / WB_CO) * U_STEP + (size_t)wv * (WB_CO * 16) + (size_t)(co0 % WB_CO) * 16;
     const unsigned uoff = lane * 16u;
     const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP, rstep = (size_t)WK * hw;
-    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 4096u : 2048u), rs_base = lds_addr_of(&Rs[0][0]) + (unsigned)(wv * 3) * 256u;
+    const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 4096u : 2048u);
+    const unsigned rs_base = lds_addr_of(&Rs[0][0]) + (RQ ? (unsigned)wv * 1024u + (WINO_RQ_SHIFT ? 4u : 0u) : (unsigned)(wv * 3) * 256u);
     auto dma_u = [&](const float* src, int buf) {
         if (CB == 2) dma16x4(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
         else dma16x2(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
     };
-    auto dma_raw = [&](const float* src, int buf) { dma4x3(src, roff[0], roff[1], roff[2], rs_base + (unsigned)buf * (RAW_BUF * 4u)); };
+    auto dma_raw = [&](const float* src, int buf) {
+        if (RQ && WINO_RQ_SHIFT) dma16x1_masked(src, roff[0], rs_base + (unsigned)buf * (RBUF * 4u), wv == 3 ? 0x0000FFFFFFFFFFFFull : ~0ull);
+        else if (RQ) dma16x1(src, roff[0], rs_base + (unsigned)buf * (RBUF * 4u));
+        else dma4x3(src, roff[0], roff[1], roff[2], rs_base + (unsigned)buf * (RBUF * 4u));
+    };
     auto clamped = [&](int step) { return step < nsteps ? step : nsteps - 1; };    // (past the end: a harmless repeat keeps the DMA count per step constant)
-    const float* xsrc = xb - 128;                                                   // (the 512-B bias of roff)
+    const float* xsrc = RQ ? xb : xb - 128;                                         // (the 512-B bias of roff)
 
     // ---- transform role: thread -> (half, input channel of the step, tile).  V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0;
     // 0 -1 1 0; 0 1 0 -1].  Half 0 produces position rows 0-1: t0 = d0 - d2, t1 = d1 + d2; half 1 rows 2-3: t2 = d2 - d1,
@@ -158,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     // A - B and B + sigma C (sigma = +1 | -1, exact), so the column pass has no selects: vector instructions do NOT issue in the
     // shadow of the f32 matrix instructions (measured: ~4 cycles each on top, experiments/mfma_filler_probe.hip), their count matters.
     const int v_half = tid >> 7, v_ci = (tid >> 5) & 3, v_tile = tid & 31, v_tx = v_tile & 7, v_ty = v_tile >> 3;
-    const int v_base = v_ci * RAW_CH + 2 * v_ty * RAW_W + 2 * v_tx;
-    const int srcA = v_base + (v_half ? 2 : 0) * RAW_W, srcB = v_base + (v_half ? 1 : 2) * RAW_W, srcC = v_base + (v_half ? 3 : 1) * RAW_W;
+    const int v_base = v_ci * RCH + 2 * v_ty * RROW + 2 * v_tx + RCOL0;
+    const int srcA = v_base + (v_half ? 2 : 0) * RROW, srcB = v_base + (v_half ? 1 : 2) * RROW, srcC = v_base + (v_half ? 3 : 1) * RROW;
     const float sigma = v_half ? -1.0f : 1.0f;
     if (PRE) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
         for (int i = tid; i < P.cin; i += 256) {
@@ -170,14 +207,44 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     // The transform of step s+1 is written as three slices (patch reads, column pass, row pass + store) placed by the main loop
     float tdA[4], tdB[4], tdC[4], tta[4], ttb[4];
     float2 pn = make_float2(0.0f, 1.0f);
-    auto tr_read = [&](int step, int rbuf) {
+    // RQ: the six 8-byte patch reads as single ds_read_b64 instructions (2 LDS cycles each, 64 banks: with 24-float rows the four tile
+    // rows of a 32-lane group fall on disjoint banks).  Written as inline asm because the compiler would merge the two reads of a row
+    // into ds_read2_b64 (8 cycles, 32 banks, 16-lane groups -- the form whose bank conflicts PMC showed) or, the pairs starting on odd
+    // floats, split each into ds_read2_b32.  The wave waits for them itself (tr_wait) before the column pass.
+    unsigned long long rqa0 = 0, rqa1 = 0, rqb0 = 0, rqb1 = 0, rqc0 = 0, rqc1 = 0;
+    const unsigned rq_base = lds_addr_of(&Rs[0][0]) + (RQ && WINO_RQ_SHIFT ? 4u : 0u);
+    const unsigned rq_a = rq_base + (unsigned)srcA * 4u, rq_b = rq_base + (unsigned)srcB * 4u, rq_c = rq_base + (unsigned)srcC * 4u;
+    auto tr_read = [&](int step, auto rbufc) {
+        constexpr int rbuf = decltype(rbufc)::value;
+        if (RQ && WINO_RQ_ASM) {
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqa0) : "v"(rq_a), "n"(rbuf * RBUF * 4));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqa1) : "v"(rq_a), "n"(rbuf * RBUF * 4 + 8));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqb0) : "v"(rq_b), "n"(rbuf * RBUF * 4));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqb1) : "v"(rq_b), "n"(rbuf * RBUF * 4 + 8));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqc0) : "v"(rq_c), "n"(rbuf * RBUF * 4));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqc1) : "v"(rq_c), "n"(rbuf * RBUF * 4 + 8));
+            if (PRE) pn = *(const float2*)&Pn[2 * (step * WK + v_ci)];
+            return;
+        }
         const float* rp = &Rs[rbuf][0];
-        const float2 a0 = *(const float2*)(rp + srcA), a1 = *(const float2*)(rp + srcA + 2), b0 = *(const float2*)(rp + srcB), b1 = *(const float2*)(rp + srcB + 2);
-        const float2 c0 = *(const float2*)(rp + srcC), c1 = *(const float2*)(rp + srcC + 2);
+        // (RQ: the pairs start on odd floats -- 8-byte LDS reads at 4-byte alignment)
+        typedef float2 __attribute__((aligned(4))) float2u;
+        const float2 a0 = *(const float2u*)(rp + srcA), a1 = *(const float2u*)(rp + srcA + 2), b0 = *(const float2u*)(rp + srcB), b1 = *(const float2u*)(rp + srcB + 2);
+        const float2 c0 = *(const float2u*)(rp + srcC), c1 = *(const float2u*)(rp + srcC + 2);
         if (PRE) pn = *(const float2*)&Pn[2 * (step * WK + v_ci)];                   // (-mean / std, 1 / std)
         tdA[0] = a0.x; tdA[1] = a0.y; tdA[2] = a1.x; tdA[3] = a1.y;
         tdB[0] = b0.x; tdB[1] = b0.y; tdB[2] = b1.x; tdB[3] = b1.y;
         tdC[0] = c0.x; tdC[1] = c0.y; tdC[2] = c1.x; tdC[3] = c1.y;
+    };
+    auto tr_wait = [&]() {                                    // the asm reads have returned (LDS operations return in order)
+        if (RQ && WINO_RQ_ASM) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rqa0), "+v"(rqa1), "+v"(rqb0), "+v"(rqb1), "+v"(rqc0), "+v"(rqc1));
+            auto lo = [](unsigned long long v) { return __builtin_bit_cast(float, (unsigned)v); };
+            auto hi = [](unsigned long long v) { return __builtin_bit_cast(float, (unsigned)(v >> 32)); };
+            tdA[0] = lo(rqa0); tdA[1] = hi(rqa0); tdA[2] = lo(rqa1); tdA[3] = hi(rqa1);
+            tdB[0] = lo(rqb0); tdB[1] = hi(rqb0); tdB[2] = lo(rqb1); tdB[3] = hi(rqb1);
+            tdC[0] = lo(rqc0); tdC[1] = hi(rqc0); tdC[2] = lo(rqc1); tdC[3] = hi(rqc1);
+        }
     };
     auto tr_cols = [&]() {
 #pragma unroll
@@ -223,14 +290,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
     dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
     dma_u(wslice + (size_t)clamped(2) * wstep, 2);
-    if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F7B); else __builtin_amdgcn_s_waitcnt(0x0F77);     // vmcnt(4 + 3 + 4 | 2 + 3 + 2)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * 2 * CB + NRAW));                                        // vmcnt(U(1) + raw(2) + U(2) still in flight)
 #ifdef WINO_PHASES
     const unsigned long long phb = __builtin_readcyclecounter();
 #endif
     patch_raw(0); patch_raw(1);
     __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
-    tr_read(0, 0); tr_cols(); tr_store(0);
+    tr_read(0, std::integral_constant<int, 0>{}); tr_wait(); tr_cols(); tr_store(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();                             // V(0) visible; raw(0)'s buffer free
     dma_raw(xsrc + (size_t)clamped(3) * rstep, 0);
@@ -275,13 +342,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         STAMP(0);
         // g0
         frag_reads(ua, vb, 1, 4);
-        tr_read(tstep, UB1);
+        tr_read(tstep, std::integral_constant<int, UB1>{});
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(0);
         __builtin_amdgcn_sched_barrier(0);
         fa0 = na0; fa1 = na1; fb = nb;
         STAMP(1);
         // g1
+        tr_wait();
+        __builtin_amdgcn_sched_barrier(0);
         frag_reads(ua, vb, 2, 8);
         __builtin_amdgcn_sched_barrier(0);
         tr_cols();
@@ -301,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         STAMP(3);
         // own DMAs except the newest group (2 * CB weight + 3 patch instructions) have landed; the V stores and every fragment
         // read of this step are complete: after the barrier U(s), V(s) and raw(s+1) may be overwritten
-        if (CB == 2) __builtin_amdgcn_s_waitcnt(0x0F77); else __builtin_amdgcn_s_waitcnt(0x0F75);     // vmcnt(7 | 5)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * CB + NRAW));                                           // vmcnt(2 CB + 3 | 2 CB + 1)
         patch_raw(UB2);
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                             // lgkmcnt(0)
         STAMP(4);
@@ -559,21 +628,34 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     P.co_base = 0;
     // epilogue shape: 0 plain, 1 scale / residual (cnet), 2 moments (fnet), 3 anything else
     const int epi = !enc ? 0 : (d->stats && !d->scale && !d->residual) ? 2 : !d->stats ? 1 : 3;
+#ifndef WINO_RAWQ
+#define WINO_RAWQ 1
+#endif
+    // the raw patch as 16-byte quads: rows of whole quads, planes and batch items 16-byte aligned, at least one whole quad per row
+    const bool quads = WINO_RAWQ && (d->w & 3) == 0 && d->w >= 4 && ((d->h * d->w) & 3) == 0 && (((uintptr_t)d->x) & 15) == 0 && (d->x_batch_stride & 3) == 0;
     auto launch = [&](auto cbc, dim3 grid) {
         constexpr int CBv = decltype(cbc)::value;
-#define WINO_LAUNCH(E, PR) hipLaunchKernelGGL((k_conv_wino<E, PR, CBv>), grid, dim3(256), 0, s, P)
-        if (d->pre_norm) { if (epi == 2) WINO_LAUNCH(2, true); else WINO_LAUNCH(3, true); }
-        else if (epi == 0) WINO_LAUNCH(0, false);
-        else if (epi == 1) WINO_LAUNCH(1, false);
-        else if (epi == 2) WINO_LAUNCH(2, false);
-        else WINO_LAUNCH(3, false);
+#define WINO_LAUNCH(E, PR, Q) hipLaunchKernelGGL((k_conv_wino<E, PR, CBv, Q>), grid, dim3(256), 0, s, P)
+        if (d->pre_norm) { if (epi == 2) WINO_LAUNCH(2, true, false); else WINO_LAUNCH(3, true, false); }
+        else if (quads) {
+            if (epi == 0) WINO_LAUNCH(0, false, true);
+            else if (epi == 1) WINO_LAUNCH(1, false, true);
+            else if (epi == 2) WINO_LAUNCH(2, false, true);
+            else WINO_LAUNCH(3, false, true);
+        }
+        else if (epi == 0) WINO_LAUNCH(0, false, false);
+        else if (epi == 1) WINO_LAUNCH(1, false, false);
+        else if (epi == 2) WINO_LAUNCH(2, false, false);
+        else WINO_LAUNCH(3, false, false);
 #undef WINO_LAUNCH
     };
     // Small launches (sequential tracking: batch 1-2) would leave every CU with at most one workgroup = one wave per SIMD, whose
     // K loop is a chain of DMA latencies: 32-channel tiles double the workgroups (two per CU hide each other's stalls).  At full
     // occupancy the 64-channel tile is 15-17 % faster (one weight fragment feeds two matrix instructions), so only below the threshold.
-    static const long long small_wg = [] { const char* e = getenv("RPE_WINO_SMALL_WG"); return e ? atoll(e) : 512LL; }();
-    if ((long long)gx * ceil_div(d->cout, WB_CO) * d->b < small_wg) {
+#ifndef WINO_SMALL_WG
+#define WINO_SMALL_WG 512LL                       /* (tools/build_variant.sh -DWINO_SMALL_WG=... for A/B runs) */
+#endif
+    if ((long long)gx * ceil_div(d->cout, WB_CO) * d->b < WINO_SMALL_WG) {
         launch(std::integral_constant<int, 1>{}, dim3(gx, ceil_div(d->cout, 32), d->b));
         return rpe_check_launch();
     }

@@ -406,7 +406,10 @@ extern "C" int rpe_conv_wino1d(const rpe_conv_desc* d, void* stream) {
     // of DMA latencies: 32-channel tiles double the workgroups.  Measured (whole pass, 640x512): batch 1 8.43 -> 7.87 ms, 4 frame pairs
     // 21.9 -> 21.1 ms, 8 pairs equal, 16 pairs (q convolutions: 1 280 workgroups = 2.5 rounds of the 512 slots) 70.96 -> 71.62 ms --
     // at full occupancy one weight fragment per four matrix instructions beats whole rounds, so only below 1.5 rounds.
-    static const long long small_wg = [] { const char* e = getenv("RPE_WINO1D_SMALL_WG"); return e ? atoll(e) : 768LL; }();
+#ifndef WINO1D_SMALL_WG
+#define WINO1D_SMALL_WG 768LL                     /* (tools/build_variant.sh -DWINO1D_SMALL_WG=... for A/B runs) */
+#endif
+    const long long small_wg = WINO1D_SMALL_WG;
     const unsigned gx = ceil_div(d->w, 16) * ceil_div(d->h, 16);
     if ((long long)gx * (P.coP / W1_CO) * d->b < small_wg) {
         const dim3 grid(gx, ceil_div(d->cout, 32), d->b);

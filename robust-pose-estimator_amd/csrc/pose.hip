@@ -65,7 +65,8 @@ static int pose_nblk(int n, int h, int w, bool hess = false) {
 extern "C" size_t rpe_pose_workspace_bytes(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     size_t st = align_up(sizeof(RowState) * (size_t)n, 256) + align_up(sizeof(RowUniform) * (size_t)n, 256);
-    size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(n, h, w) * n, 256);   // (the Hessian launch never has more blocks)
+    size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(1, h, w) * n, 256);   // room for any partition_rows (n = 1 has the most blocks per
+                                                                                          // row; the Hessian launch never has more)
     return st + pa + 256;
 }
 
@@ -562,6 +563,11 @@ extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const f
                                    int history_size, double* T_out, float* vec7, float* log6, int32_t* info,
                                    void* workspace, void* stream);
 
+extern "C" int rpe_pose_solve_ex(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
+                                 const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
+                                 int n, int h, int w, int mode, int iters, const rpe_solve_opts* opts, double* T_out, float* vec7, float* log6,
+                                 int32_t* info, void* workspace, void* stream);
+
 extern "C" int rpe_pose_solve(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
                               const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
                               int n, int h, int w, int mode, int iters, double* T_out, float* vec7, float* log6,
@@ -576,7 +582,20 @@ extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const f
                                    int n, int h, int w, int mode, int iters, double tolerance_grad, double tolerance_change,
                                    int history_size, double* T_out, float* vec7, float* log6, int32_t* info,
                                    void* workspace, void* stream) {
-    if (history_size < 1 || history_size > HIST || !(tolerance_grad >= 0.0) || !(tolerance_change >= 0.0)) return RPE_E_BADARG;
+    rpe_solve_opts o;
+    o.struct_size = (int)sizeof(rpe_solve_opts); o.history_size = history_size; o.tolerance_grad = tolerance_grad; o.tolerance_change = tolerance_change;
+    o.partition_rows = 0; o.reserved = 0;
+    return rpe_pose_solve_ex(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w, mode, iters, &o, T_out, vec7, log6, info, workspace, stream);
+}
+
+extern "C" int rpe_pose_solve_ex(const float* flow, const float* pcl1, const float* pcl2, const float* w1, const float* w2,
+                                 const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
+                                 int n, int h, int w, int mode, int iters, const rpe_solve_opts* opts, double* T_out, float* vec7, float* log6,
+                                 int32_t* info, void* workspace, void* stream) {
+    if (!opts || opts->struct_size != (int)sizeof(rpe_solve_opts)) return RPE_E_BADARG;
+    const int history_size = opts->history_size;
+    const double tolerance_grad = opts->tolerance_grad, tolerance_change = opts->tolerance_change;
+    if (history_size < 1 || history_size > HIST || !(tolerance_grad >= 0.0) || !(tolerance_change >= 0.0) || opts->partition_rows < 0) return RPE_E_BADARG;
     const SolveOpts opt{tolerance_grad, tolerance_change, history_size};
     if (!flow || !pcl1 || !pcl2 || !w1 || !w2 || !mask1 || !mask2 || !K || !loss_weight || !T_out || n <= 0 || h <= 0 || w <= 0 || iters < 0)
         return RPE_E_BADARG;
@@ -585,7 +604,10 @@ extern "C" int rpe_pose_solve_opts(const float* flow, const float* pcl1, const f
     if (!carve(workspace, n, h, w, &st, &uni, &partials)) return RPE_E_BADARG;
     PoseArgs A{flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w};
     hipStream_t s = (hipStream_t)stream;
-    int nblk = pose_nblk(n, h, w, mode == RPE_SOLVER_GN);
+    // The reduction's block partition fixes the order of the f64 sums.  By default it follows the batch (one resident round of
+    // workgroups chip-wide); with partition_rows = p it is the one a p-row batch would get, so with p = 1 a row's iterates are
+    // bit-identical to solving it alone (rpe_pose_workspace_bytes covers every partition: n = 1 has the most blocks per row)
+    int nblk = pose_nblk(opts->partition_rows > 0 && opts->partition_rows < n ? opts->partition_rows : n, h, w, mode == RPE_SOLVER_GN);
     hipLaunchKernelGGL(k_pose_init, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, uni, K, loss_weight, n, h, w);
     // LBFGS with max_iter = N costs N evaluations (the last iteration moves without re-evaluating);
     // torch evaluates the closure once even for max_iter = 0.

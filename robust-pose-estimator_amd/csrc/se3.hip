@@ -51,6 +51,7 @@ template <typename S> __global__ void k_chain(const S* rel, const S* init, S* ou
 extern "C" {
 
 const char* rpe_version(void) { return "rpe-hip 0.1 gfx950"; }
+int rpe_abi_version(void) { return RPE_ABI_VERSION; }
 
 int rpe_se3_exp(const void* xi, void* T, int64_t n, int dtype, void* stream) {
     if (!xi || !T || n < 0) return RPE_E_BADARG;

@@ -40,6 +40,15 @@ __device__ __forceinline__ void dma16x1(const float* base, unsigned voff, unsign
                  "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
+// one chunk, exec-masked
+__device__ __forceinline__ void dma16x1_masked(const float* base, unsigned voff, unsigned lds_addr, unsigned long long lane_mask) {
+    unsigned keep; unsigned long long ekeep;
+    base = wave_uniform(base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %5\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ekeep) : "v"(voff), "s"(base), "s"(lds_addr), "s"(lane_mask) : "memory");
+}
 // two 1 KB chunks of which only the first `lanes` lanes take part (exec-masked): LDS lds_addr + stride j + lane * 16, the
 // caller folds -stride j into v_j (and a bias that keeps them non-negative into the base)
 template <unsigned STRIDE>

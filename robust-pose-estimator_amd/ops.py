@@ -128,8 +128,10 @@ def pose_reduce(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, T, need_
 
 
 def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mode=SOLVER_LBFGS,
-               tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100):
-    """Device-resident solve.  Returns (T f64 (n,7), vec7 f32 (n,7), log6 f32 (n,6), info int32 (n,4))."""
+               tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, partition_rows=0):
+    """Device-resident solve.  Returns (T f64 (n,7), vec7 f32 (n,7), log6 f32 (n,6), info int32 (n,4)).
+    ``partition_rows=1``: every row's float64 sums are grouped as if it were solved alone (rpe_solve_opts), i.e. the result of a
+    row does not depend on the batch it is in, bit for bit."""
     args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
     dev = args[0].device
     T = torch.empty(n, 7, dtype=torch.float64, device=dev)
@@ -137,9 +139,10 @@ def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mo
     log6 = torch.empty(n, 6, dtype=torch.float32, device=dev)
     info = torch.empty(n, 4, dtype=torch.int32, device=dev)
     ws = _workspace(n, h, w, dev)
-    check(lib().rpe_pose_solve_opts(*[ptr(a) for a in args], n, h, w, int(mode), int(iters), float(tolerance_grad),
-                                    float(tolerance_change), int(history_size), ptr(T), ptr(vec7), ptr(log6), ptr(info), ptr(ws),
-                                    stream_ptr()), 'rpe_pose_solve_opts')
+    import ctypes
+    o = _lib.SolveOpts(ctypes.sizeof(_lib.SolveOpts), int(history_size), float(tolerance_grad), float(tolerance_change), int(partition_rows), 0)
+    check(lib().rpe_pose_solve_ex(*[ptr(a) for a in args], n, h, w, int(mode), int(iters), ctypes.byref(o), ptr(T), ptr(vec7), ptr(log6),
+                                  ptr(info), ptr(ws), stream_ptr()), 'rpe_pose_solve_ex')
     return T, vec7, log6, info
 
 
@@ -509,11 +512,10 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     if mode in (CONV_LINEAR, CONV_RELU, CONV_TANH) and out2 is not None and out2.shape[1] < pc.cout:
         raise _lib.RpeError('conv_fused: out2 slice has too few channels')
     if stats is not None:
-        tiles = (lib().rpe_conv_stats_tiles_batch(pc.cout, hh, ww, stride, b), lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride))
-        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and stats.dim() == 4 and stats.shape[2] in tiles
-                and tuple(stats.shape) == (b, pc.cout, stats.shape[2], 3)):
-            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles[0]},3) GPU tensor (conv_stats_buffer)')
-        d.stats_tiles = stats.shape[2]
+        tiles = lib().rpe_conv_stats_tiles(pc.cout, hh, ww, stride)
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, pc.cout, tiles, 3)):
+            raise _lib.RpeError(f'conv_fused: stats must be a contiguous float32 ({b},{pc.cout},{tiles},3) GPU tensor (conv_stats_buffer)')
+        d.stats_tiles = tiles
     d.stats = ptr(stats)
     if pre_norm is not None and not (pre_norm.is_cuda and pre_norm.dtype == torch.float32 and pre_norm.is_contiguous()
                                      and tuple(pre_norm.shape) == (b, cin, 2)):
@@ -665,7 +667,7 @@ def _stats_layout(stats, b, c, who):
 
 def conv_stats_buffer(b, cout, hh, ww, device, stride=1):
     """Per-tile (count, mean, M2) records rpe_conv_fused fills when ``stats`` is given: (b, cout, tiles, 3); hh, ww = input map."""
-    return torch.empty(b, cout, lib().rpe_conv_stats_tiles_batch(cout, hh, ww, stride, b), 3, dtype=torch.float32, device=device)
+    return torch.empty(b, cout, lib().rpe_conv_stats_tiles(cout, hh, ww, stride), 3, dtype=torch.float32, device=device)
 
 
 def instnorm_finalize(stats, hw, eps=1e-5, channels=None):

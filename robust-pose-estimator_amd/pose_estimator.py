@@ -112,6 +112,45 @@ class PoseEstimator(torch.nn.Module):
         self.last_pose = self.last_pose * rel_pose.inv()                 # :91 chain transforms
         return self.last_pose, None, flow, weights
 
+    @torch.no_grad()
+    def forward_chunk(self, limgs, rimgs, masks):
+        """``forward`` for c consecutive frames in ONE pass (PoseNet.infer_chunk): limgs, rimgs (c,3,h,w), masks (c,1,h,w), after at
+        least one ``forward`` call (the sequence's first frame only gets its stereo depth).  Bit-identical to c single calls: same
+        relative poses, same gate decisions, same chained poses, same Frame left behind.  Returns the (c,7) absolute poses;
+        ``last_rel_poses`` (c,7) gated relative poses and ``successes`` (c,) bool are left on the estimator, the gate is evaluated on
+        the device with ONE host synchronisation per chunk (for the warnings) instead of two per frame."""
+        if self.frame is None:
+            raise RuntimeError('forward_chunk: call forward() on the first frame of the sequence (it has no predecessor to pair with)')
+        c = limgs.shape[0]
+        prev = self.frame
+        masks = masks.bool().contiguous()
+        self.last_pose = self.last_pose.to(limgs.device)
+        vec7, depth2, weights, flow, stereo_flow, cache = self.model.infer_chunk(
+            prev.img, limgs, rimgs, self.intrinsics, self.baseline * self.scale, depth0=prev.depth * self.scale, mask0=prev.mask,
+            masks=masks, stereo_flow0=prev.flow, cache0=self._enc_cache, depth_roundtrip=self.scale)
+        self._enc_cache = cache if self.reuse_features else None
+        rel = vec7.reshape(c, 7)
+        log = SE3(rel).log()
+        bad = torch.isnan(rel).any(dim=-1) | (torch.abs(log) > 1.0e-1).any(dim=-1)                   # :81, all frames at once
+        ident = SE3.IdentityLike(SE3(rel)).data
+        rel = torch.where(bad[:, None], ident, rel)
+        n_bad = int(bad.sum())                                             # the chunk's one host synchronisation
+        for _ in range(n_bad):
+            warnings.warn('pose estimation not converged, skip.', RuntimeWarning)
+        self.successes = ~bad
+        self.success = not bool(bad[-1]) if n_bad else True
+        self.last_rel_poses = rel
+        self.last_rel_pose = SE3(rel[c - 1:])
+        # :90-91 for every frame: last_pose <- last_pose * (rel scaled back to millimetres)^-1, the same three operations per frame
+        poses = []
+        scaled_inv = SE3(rel).scale(1 / self.scale).inv()
+        for i in range(c):
+            self.last_pose = self.last_pose * scaled_inv[i:i + 1]
+            poses.append(self.last_pose.data.reshape(1, 7))
+        self.last_frame = Frame(limgs[c - 2:c - 1], rimgs[c - 2:c - 1]) if c > 1 else prev      # (only .img of it is ever read again)
+        self.frame = Frame(limgs[c - 1:], rimgs[c - 1:], depth=depth2[c - 1:] / self.scale, mask=masks[c - 1:], flow=stereo_flow[c - 1:])
+        return torch.cat(poses), None, flow, weights
+
     def get_pose_f2f(self):
         flow = None
         if self.last_frame is None:

@@ -35,6 +35,9 @@ class DPoseSE3Head:
         self.solver = solver
         self.losses = []
         self.last_info = None
+        # 1: every row is reduced with the block partition it would get alone (rpe_solve_opts.partition_rows), so a row's pose does not
+        # depend on the batch it is solved in, bit for bit; 0: the partition follows the batch (one resident round of workgroups)
+        self.partition_rows = 0
 
     @property
     def mode(self):
@@ -49,7 +52,7 @@ class DPoseSE3Head:
 
     def solve(self, *xs):
         xs = [x.detach() if isinstance(x, torch.Tensor) else x for x in xs]
-        T, vec7, log6, info = ops.pose_solve(*xs, iters=self.lbgfs_iters, mode=self.mode)
+        T, vec7, log6, info = ops.pose_solve(*xs, iters=self.lbgfs_iters, mode=self.mode, partition_rows=self.partition_rows)
         self.last_info = info
         return SE3(T[:, None]), (vec7, log6)
 

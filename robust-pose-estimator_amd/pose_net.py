@@ -17,8 +17,7 @@ from .raft import RAFT
 from .se3 import SE3
 from .unet import TinyUNet, pack_params
 
-import os
-FUSED_HEADS = os.environ.get('RPE_FUSED_HEADS', '1') != '0'      # A/B switch: the heads on the HIP kernel chain vs PyTorch-ROCm + HIP epilogues
+FUSED_HEADS = True      # the heads on the HIP kernel chain (csrc/unet.hip); tools/ set this to False for A/B runs against the module route
 
 
 class PoseNet(nn.Module):
@@ -151,6 +150,63 @@ class PoseNet(nn.Module):
         if ret_cache:
             return (*out, s['cache2']) if ret_details else (out, s['cache2'])
         return out
+
+    @torch.no_grad()
+    def infer_chunk(self, image0l, imagesl, imagesr, intrinsics, baseline, depth0, mask0, masks, stereo_flow0, cache0=None,
+                    depth_roundtrip=None):
+        """c consecutive calls of ``infer`` as ONE pass: frame t of the chunk is ``infer(image1l = frame t-1, image2l = frame t, ...)``
+        with frame -1 = (image0l, depth0, mask0, stereo_flow0) and, for t > 0, depth1 / mask1 / stereo_flow1 = the depth2 / mask2 /
+        stereo_flow2 that call t-1 produced (core/pose/pose_estimator.py:113-122 feeds them back through its Frame) -- a shift by one
+        row INSIDE the batch, after the 2c RAFT pairs, which are independent.  imagesl, imagesr (c,3,h,w) 0..255; masks (c,1,h,w) bool,
+        ANDed in place with the stereo validity like ``infer``'s mask2 (pose_net.py:77); depth0 / stereo_flow0 / mask0 (1,..) as ``infer``
+        takes them; ``cache0`` = encoder outputs of image0l ({'fmap','cnet'}) when the caller has them.
+        ``depth_roundtrip`` = s: depth1 of row t > 0 is (depth2[t-1] / s) * s, the two roundings PoseEstimator's Frame puts between
+        consecutive calls (it stores depth / scale and hands over depth * scale, pose_estimator.py:107,116,121).
+        Every kernel on the way computes a row independently of its batch (tests), and the solve runs with partition_rows = 1, so the
+        result is BIT-IDENTICAL to the c single calls.  Returns (vec7 (c,7) f32, depth2 (c,1,h,w), (w2d, w3d), time_flow (c,2,h,w),
+        stereo_flow2 (c,2,h,w), cache of the last frame)."""
+        c = imagesl.shape[0]
+        intrinsics = intrinsics.expand(c, 3, 3).contiguous()
+        baseline = baseline.expand(c).contiguous()
+        f = self.flow.encode_features((imagesl, imagesr))                 # (L_0..L_c-1 | R_0..R_c-1)
+        fl = f[:c]
+        cn = self.flow.encode_context(imagesl)
+        if cache0 is None:
+            f0, c0 = self.flow.encode_features(image0l), self.flow.encode_context(image0l)
+        else:
+            f0, c0 = cache0['fmap'], cache0['cnet']
+        # pairs: temporal (L_t-1 -> L_t) for t = 0..c-1, then stereo (L_t -> R_t): the order PoseNet.stages uses per frame
+        fmap1 = torch.cat((f0, fl[:c - 1], fl), dim=0)
+        cnet = torch.cat((c0, cn[:c - 1], cn), dim=0)
+        flows, hidden, context = self.flow(None, None, upsample=True, fmaps=(fmap1, f), cnet=cnet)
+        time_flow = flows[-1][:c].contiguous()
+        stereo_flow2 = flows[-1][c:].contiguous()
+        hidden, context = hidden[:c], context[:c]
+        depth2, valid = ops.flow2depth(stereo_flow2, baseline)            # the same division and tests rpe_depth_backproject_warp repeats
+        masks &= valid
+        d_prev = depth2[:c - 1]
+        if depth_roundtrip is not None:
+            d_prev = (d_prev / depth_roundtrip) * depth_roundtrip
+        depth1 = torch.cat((depth0, d_prev), dim=0)
+        mask1 = torch.cat((mask0.bool(), masks[:c - 1]), dim=0)
+        stereo_flow1 = torch.cat((stereo_flow0, stereo_flow2[:c - 1]), dim=0)
+        image1l = torch.cat((image0l, imagesl[:c - 1]), dim=0)
+        g = ops.depth_backproject_warp(stereo_flow2, time_flow, baseline, intrinsics, depth1, image1l, imagesl, stereo_flow1, masks)
+        if self.use_weights and not (self.weight_head_2d.training or self.weight_head_3d.training):
+            w2d, w3d = ops.unet_heads(g['inp1'], g['inp2'], hidden, context, pack_params(self.weight_head_2d[0]),
+                                      pack_params(self.weight_head_3d[0]), self.config['image_shape'])
+        elif self.use_weights:
+            raise RuntimeError('infer_chunk: the weight heads must be in eval mode')
+        else:
+            w2d, w3d = torch.ones_like(g['depth2']), torch.ones_like(g['depth2'])
+        lw = self.loss_weight.detach()[None, :].repeat(c, 1)
+        problem = self.pose_head.problem
+        keep, problem.partition_rows = problem.partition_rows, 1
+        try:
+            vec7, _ = self.pose_head(time_flow, g['pcl1'], g['pcl2w'], w2d, w3d, mask1, g['mask2w'], intrinsics, lw)
+        finally:
+            problem.partition_rows = keep
+        return vec7[:, 0], g['depth2'], (w2d, w3d), time_flow, stereo_flow2, dict(fmap=fl[c - 1:], cnet=cn[c - 1:])
 
     def init_from_raft(self, raft_ckp):
         state = torch.load(raft_ckp, map_location='cpu')

@@ -26,20 +26,19 @@ Exact re-associations used (results identical up to float rounding of the conv l
 The RAFT architecture itself is restated from princeton-vl/RAFT (the reference's submodule is empty);
 see oracle/raft.py for the CPU restatement these kernels are tested against.
 """
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
 
-WINOGRAD = os.environ.get('RPE_WINOGRAD', '1') != '0'      # 3x3 layers of the update block as F(2x2,3x3) (A/B switch for measurements)
+# Module-level route constants (no environment switches in the product: tools/ and bench.py's labelled experiments set these attributes)
+WINOGRAD = True          # 3x3 layers as F(2x2,3x3), the GRU's 1x5 / 5x1 as F(4,5); False = the direct implicit GEMM (A/B measurements)
+CORR_BF16X3 = False      # EXPERIMENT: correlation products as six bf16 products of an exact 3-way split (bench.py --corr-bf16x3)
 # The motion encoder's flow branch (convf1 -> convf2) on a side stream beside lookup -> convc1 -> convc2.  Measured (MI355X, 640x512):
 # batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
-# launch fills the chip on its own), so it is used for small passes only.  RPE_SIDE_STREAM=0 switches it off.
-CORR_BF16X3 = os.environ.get('RPE_CORR_BF16X3', '0') != '0'   # correlation products as six bf16 products of an exact 3-way split (EXPERIMENT switch)
-SIDE_STREAM = os.environ.get('RPE_SIDE_STREAM', '1') != '0'
+# launch fills the chip on its own), so it is used for small passes only.
+SIDE_STREAM = True
 SIDE_STREAM_MAX = 8 * 5120                                     # queries per pass (batch * h/8 * w/8) up to which the side stream is used
 
 
@@ -92,7 +91,7 @@ class ResidualBlock(nn.Module):
             else:
                 stats1 = ops.conv_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device, stride=st)
                 ops.conv_fused(x, _packed(self.conv1), ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1, stride=st)
-            mi = ops.instnorm_finalize(stats1, (hh // st) * (ww // st), eps=self.norm1.eps)
+            mi = ops.instnorm_finalize(stats1, (hh // st) * (ww // st), eps=self.norm1.eps, channels=self.conv1.out_channels)
             if self.downsample is not None:
                 x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
             ho, wo = raw1.shape[-2:]
@@ -152,20 +151,15 @@ def _wino(conv, x):
 
 
 def _fusable(conv, x):
-    """Can rpe_conv_fused run this encoder convolution on this input?  (3x3 stride 1; 3x3 pad 1 / 1x1 stride 2 on even maps.)"""
+    """Can rpe_conv_fused / rpe_conv_wino run this encoder convolution on this input?  (3x3 stride 1; 3x3 pad 1 / 1x1 stride 2 on even
+    maps; rows of whole 16-byte quads.)  Every launch size takes this route: the kernels pick smaller tiles for small launches
+    themselves, and their results do not depend on that choice (tests/test_gpu_conv.py::*_agree_bitwise)."""
     _, _, hh, ww = x.shape
     s1 = conv.stride == (1, 1) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
     s2 = conv.stride == (2, 2) and hh % 2 == 0 and ww % 2 == 0 and \
         ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
     stride = 2 if s2 else 1
-    # stride-1 launches of fewer than ~one workgroup per CU that the Winograd kernel cannot take stay on the library (odd maps)
-    wide = conv.out_channels % 128 != 0 and conv.out_channels % 128 <= 96
-    tiles = -(-(hh // stride) * (ww // stride) // (128 if (s2 or not wide) else 256)) * -(-conv.out_channels // (128 if (s2 or not wide) else 64))
-    big = s2 or tiles * x.shape[0] >= 256                      # (stride 2: rpe_conv_fused has its own 64 x 64 tiles for small launches)
-    if s1 and WINOGRAD and hh % 2 == 0 and ww % 2 == 0 and conv.in_channels <= 128:
-        # the Winograd kernel's workgroups are 16 x 8 pixels x 64 channels: it still wins over the library at a quarter of the chip
-        big = big or -(-hh // 8) * -(-ww // 16) * -(-conv.out_channels // 64) * x.shape[0] >= int(os.environ.get('RPE_WINO_MIN_WG', '64'))
-    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous() and big
+    return (s1 or s2) and ww % 4 == 0 and ((hh // stride) * (ww // stride)) % 4 == 0 and x.is_contiguous()
 
 
 def conv_norm_act(conv, norm, x, relu, residual=None):
@@ -262,7 +256,7 @@ class BasicEncoder(nn.Module):
         if bn:
             return out, None
         if self.layer1[0].takes_raw_input(out):               # norm1 + ReLU happen inside layer1's first block (its loader and its last pass)
-            return out, ops.instnorm_finalize(stats, (hh // 2) * (ww // 2), eps=self.norm1.eps)
+            return out, ops.instnorm_finalize(stats, (hh // 2) * (ww // 2), eps=self.norm1.eps, channels=64)
         return ops.instnorm_apply(out, stats, eps=self.norm1.eps, relu=True), None
 
     def _final(self, x, split_act):
@@ -366,10 +360,7 @@ class BasicMotionEncoder(nn.Module):
         """convf1 -> convf2 (fused route): depends on the flow only, not on the correlation lookup, so RAFT.forward may run it on a
         side stream beside lookup -> convc1 -> convc2."""
         _, cor, flo_buf, c1, c2, f2, cv_ = self._calls(corr, cat_buf, hx, rhx, packed)
-        if flow.shape[0] * -(-flow.shape[2] // 8) * -(-flow.shape[3] // 32) * 2 >= int(os.environ.get('RPE_STEM_MIN_WG', '48')):    # (one 640x512 pair = 48 workgroups; the library wins only on tiny maps)
-            ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
-        else:
-            ops.bias_act(F.conv2d(flow, self.convf1.weight, None, self.convf1.stride, self.convf1.padding), self.convf1.bias, out=flo_buf)
+        ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf)   # 7x7 on 2 channels
         f2()
 
     def forward(self, flow, corr, cat_buf, hx, rhx, packed=None, flow_in_place=False, flow_branch_done=None):

@@ -78,16 +78,22 @@ def track_sharded(n_frames, run_block, chain_fn, rank=0, world=1, group=None, sc
 
 
 class SequenceTracker:
-    """GPU driver of track_sharded on top of PoseEstimator: every rank walks its block of frames one at a time
-    (the reference's per-frame semantics, batch 1), starting from the halo frame.  The estimator is built ONCE per tracker
-    (model build / weight load / GPU allocation) and reset between blocks."""
+    """GPU driver of track_sharded on top of PoseEstimator: every rank walks its block of frames in chunks of ``chunk`` frames
+    (PoseEstimator.forward_chunk: one RAFT pass over the 2 * chunk pairs of a chunk, one fused geometry pass, one n-row solve),
+    starting from the halo frame.  The chunked walk is bit-identical to the reference's frame-at-a-time walk (``chunk=1``:
+    core/pose/pose_estimator.py:98-125, one ``forward`` per frame); the chunk size only trades memory (a chunk of 16 640x512 frames
+    = the RAFT batch 32 of bench.py) for throughput.  The estimator is built ONCE per tracker (model build / weight load / GPU
+    allocation) and reset between blocks."""
 
-    def __init__(self, make_estimator, get_frame, flow2depth=None, chain=None):
+    def __init__(self, make_estimator, get_frame, flow2depth=None, chain=None, chunk=16):
         """make_estimator() -> a PoseEstimator on this rank's GPU (called once, lazily); get_frame(t) -> (limg, rimg, mask).
         ``flow2depth(flow, baseline) -> (depth, valid)`` and ``chain(rel, scale) -> poses`` default to the HIP entry points
         (rpe_flow2depth, rpe_se3_chain); the CPU tests inject the oracle's so that the same driver runs without a GPU."""
+        if chunk < 1:
+            raise ValueError('SequenceTracker: chunk must be >= 1')
         self.make_estimator, self.get_frame = make_estimator, get_frame
         self._flow2depth, self._chain = flow2depth, chain
+        self.chunk = int(chunk)
         self._est = None
 
     @property
@@ -114,11 +120,20 @@ class SequenceTracker:
             # mask with the stereo validity (pose_net.py:77); reproduce that for the halo frame
             _, valid = flow2depth(est.frame.flow, est.baseline * est.scale)
             est.frame.mask &= valid
-        for t in range(first_pair, last_pair):
-            l, r, m = self.get_frame(t + 1)
-            est(l, r, m)
-            rels.append(est.last_rel_pose.data.reshape(1, 7).float())
-            oks.append(torch.tensor([est.success], device=rels[-1].device))
+        t = first_pair
+        while t < last_pair:
+            k = min(self.chunk, last_pair - t)
+            if k == 1:
+                l, r, m = self.get_frame(t + 1)
+                est(l, r, m)
+                rels.append(est.last_rel_pose.data.reshape(1, 7).float())
+                oks.append(torch.tensor([est.success], device=rels[-1].device))
+            else:
+                fr = [self.get_frame(t + 1 + i) for i in range(k)]
+                est.forward_chunk(torch.cat([f[0] for f in fr]), torch.cat([f[1] for f in fr]), torch.cat([f[2] for f in fr]))
+                rels.append(est.last_rel_poses.reshape(k, 7).float())
+                oks.append(est.successes.reshape(k))
+            t += k
         return torch.cat(rels), torch.cat(oks)
 
     def track(self, n_frames, rank=0, world=1, group=None, scale=None):

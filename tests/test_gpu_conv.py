@@ -278,31 +278,43 @@ def test_stride2_convolutions_match_f64(rpe, cin, cout, k, h, w, b):
     assert (got2.cpu().double() - (pre - mean) / torch.sqrt(var + 1e-5)).abs().max() < (_tol(x, wt) + 2e-6) * inv * 2
 
 
-def test_stride2_tile_classes_agree_and_legacy_stats_buffers_work(rpe):
+def test_stride2_tile_classes_agree_bitwise_including_statistics(rpe):
     """A stride-2 launch below 512 workgroups runs on 64 x 64 tiles: same products, same order, so a batch of 14 (128 x 128 tiles)
-    equals the same maps run two at a time bit for bit.  A statistics buffer sized by rpe_conv_stats_tiles (the 128-pixel tiling,
-    what a caller of the C ABI that does not know the batch rule allocates) keeps the small launch on 128-pixel tiles."""
+    equals the same maps run two at a time bit for bit -- and so do the instance-norm statistics: both classes leave one record per
+    32 output pixels (rpe_conv_stats_tiles), hence an image's normalisation does not depend on the batch it was launched in."""
     from rpe_amd import ops
     rng = np.random.default_rng(99)
     b, cin, cout, h, w = 14, 64, 96, 128, 160
     x, wt, bias = _rand(rng, b, cin, h, w).cuda(), _rand(rng, cout, cin, 3, 3, s=0.05).cuda(), _rand(rng, cout, s=0.5).cuda()
     pc = ops.PackedConv(wt, bias)
     L = rpe.lib()
-    assert L.rpe_conv_stats_tiles_batch(cout, h, w, 2, b) == L.rpe_conv_stats_tiles(cout, h, w, 2) == 40
-    assert L.rpe_conv_stats_tiles_batch(cout, h, w, 2, 2) == 80
+    assert L.rpe_conv_stats_tiles(cout, h, w, 2) == L.rpe_conv_stats_tiles_batch(cout, h, w, 2, b) == L.rpe_conv_stats_tiles_batch(cout, h, w, 2, 2) == 160
     big = ops.conv_fused(x, pc, ops.CONV_RELU, torch.empty(b, cout, h // 2, w // 2, device='cuda'), stride=2)
-    st_new, st_old = ops.conv_stats_buffer(2, cout, h, w, 'cuda', stride=2), torch.empty(2, cout, 40, 3, device='cuda')
-    assert st_new.shape[2] == 80
+    st_big = ops.conv_stats_buffer(b, cout, h, w, 'cuda', stride=2)
+    raw_big = ops.conv_fused(x, pc, ops.CONV_LINEAR, torch.empty(b, cout, h // 2, w // 2, device='cuda'), stats=st_big, stride=2)
+    n_big = ops.instnorm_apply(raw_big, st_big, eps=1e-5, relu=True, out=torch.empty_like(raw_big))
+    mi_big = ops.instnorm_finalize(st_big, (h // 2) * (w // 2), channels=cout)
+    assert float(st_big[..., 0].sum(dim=2).min()) == float(st_big[..., 0].sum(dim=2).max()) == (h // 2) * (w // 2)
     for i in (0, 6, 12):
         xs = x[i:i + 2].contiguous()
         small = ops.conv_fused(xs, pc, ops.CONV_RELU, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stride=2)
         assert torch.equal(big[i:i + 2], small)
-        raw_new = ops.conv_fused(xs, pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stats=st_new, stride=2)
-        raw_old = ops.conv_fused(xs, pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stats=st_old, stride=2)
-        assert torch.equal(raw_new, raw_old)
-        n_new, n_old = ops.instnorm_apply(raw_new, st_new, eps=1e-5, relu=True), ops.instnorm_apply(raw_old, st_old, eps=1e-5, relu=True)
-        assert (n_new - n_old).abs().max() < 2e-6            # the same moments merged from 80 or 40 records per plane (f64 merge)
-    with pytest.raises(rpe.RpeError):                        # neither tiling
+        st = ops.conv_stats_buffer(2, cout, h, w, 'cuda', stride=2)
+        raw = ops.conv_fused(xs, pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'), stats=st, stride=2)
+        assert torch.equal(raw, raw_big[i:i + 2]) and torch.equal(st, st_big[i:i + 2])
+        assert torch.equal(ops.instnorm_apply(raw, st, eps=1e-5, relu=True, out=torch.empty_like(raw)), n_big[i:i + 2])
+        assert torch.equal(ops.instnorm_finalize(st, (h // 2) * (w // 2), channels=cout), mi_big[i:i + 2])
+    # a plane that is not a whole number of 32-pixel blocks / 64-pixel tiles: 18 x 20 outputs = 360 = 11 blocks + 8 pixels
+    x2 = _rand(rng, 3, cin, 36, 40).cuda()
+    st2 = ops.conv_stats_buffer(3, cout, 36, 40, 'cuda', stride=2)
+    assert st2.shape[2] == 12
+    raw2 = ops.conv_fused(x2, pc, ops.CONV_LINEAR, torch.empty(3, cout, 18, 20, device='cuda'), stats=st2, stride=2)
+    assert st2[..., 0].sum(dim=2).unique().tolist() == [360.0]
+    mi2 = ops.instnorm_finalize(st2, 360, channels=cout).cpu().double()
+    ref = raw2.cpu().double().reshape(3, cout, -1)
+    assert float((mi2[..., 0] - ref.mean(-1)).abs().max()) < 1e-5
+    assert float((mi2[..., 1] * torch.sqrt(ref.var(-1, unbiased=False) + 1e-5) - 1).abs().max()) < 1e-5
+    with pytest.raises(rpe.RpeError):                        # a buffer of another record count is refused
         ops.conv_fused(x[:2].contiguous(), pc, ops.CONV_LINEAR, torch.empty(2, cout, h // 2, w // 2, device='cuda'),
                        stats=torch.empty(2, cout, 41, 3, device='cuda'), stride=2)
 
@@ -679,6 +691,25 @@ def test_instnorm_apply_with_a_raw_residual(rpe):
     assert torch.equal(got, two_pass)
     with pytest.raises(rpe.RpeError):
         ops.instnorm_apply(raw.clone(), stats, residual_norm=res_mi)              # a norm without a residual
+
+
+@pytest.mark.parametrize('cin,cout,h,w,mode', [(324, 256, 44, 48, 'relu'), (256, 576, 44, 48, 'linear'), (128, 256, 64, 80, 'tanh'), (20, 70, 6, 12, 'linear')])
+def test_conv1x1_routes_agree_bitwise(rpe, cin, cout, h, w, mode):
+    """ops.Conv1x1 sends a launch to rpe_conv1x1 (128 x 128 tiles on LDS-DMA rings) or to rpe_conv_fused (128- or 64-wide tiles) by its
+    workgroup count -- i.e. by the batch.  All three sum the same products in the same order (k_conv1x1's operand rows are permuted to
+    k_conv_igemm's pairing of channels j and 8 + j), so a map's result is the same bits whichever route its batch took."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin * 7 + cout)
+    b = 14
+    x, wt, bias = _rand(rng, b, cin, h, w).cuda(), _rand(rng, cout, cin, 1, 1, s=0.05).cuda(), _rand(rng, cout, s=0.3).cuda()
+    m = {'relu': ops.CONV_RELU, 'tanh': ops.CONV_TANH, 'linear': ops.CONV_LINEAR}[mode]
+    gemm = ops.conv1x1(x, ops.PackedConv1x1(wt, bias), m, torch.empty(b, cout, h, w, device='cuda'))
+    fused = ops.conv_fused(x, ops.PackedConv(wt, bias), m, torch.empty(b, cout, h, w, device='cuda'))
+    assert torch.equal(gemm, fused)
+    both = ops.Conv1x1(wt, bias)
+    for sl in (slice(0, 1), slice(5, 7)):                      # small launches: rpe_conv_fused's 64 x 64 tiles
+        assert torch.equal(both(x[sl].contiguous(), m, torch.empty(sl.stop - sl.start, cout, h, w, device='cuda')), gemm[sl])
+    assert torch.equal(both(x, m, torch.empty(b, cout, h, w, device='cuda')), gemm)
 
 
 @pytest.mark.parametrize('cin,cout,h,w,b,mode', [(324, 256, 64, 80, 32, 'relu'), (324, 256, 64, 80, 1, 'relu'), (128, 256, 44, 48, 2, 'tanh'),

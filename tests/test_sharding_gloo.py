@@ -165,12 +165,23 @@ class _OracleEstimator:
         self.success = self._t.success[-1]
         self.last_rel_pose = SimpleNamespace(data=self._t.rel_poses[-1])
 
+    def forward_chunk(self, L, R, M):
+        """The chunk interface of the product estimator with the oracle's semantics: the c single calls, one after the other (what
+        PoseEstimator.forward_chunk must reproduce bit for bit on the GPU; tests/test_gpu_chunked_tracker.py)."""
+        rels, oks = [], []
+        for i in range(L.shape[0]):
+            self(L[i:i + 1], R[i:i + 1], M[i:i + 1])
+            rels.append(self.last_rel_pose.data.reshape(1, 7))
+            oks.append(self.success)
+        self.last_rel_poses, self.successes = torch.cat(rels), torch.tensor(oks)
+        self.chunk_calls = getattr(self, 'chunk_calls', 0) + 1
+
     @property
     def frame(self):
         return _FrameProxy(self._t.frame)
 
 
-def _oracle_tracker(n_frames):
+def _oracle_tracker(n_frames, chunk=2):
     import rpe_amd.sharding as sh
     from oracle import pose_net as opn
     from oracle import tracker, warp
@@ -182,13 +193,13 @@ def _oracle_tracker(n_frames):
     fr = synth.stereo_frames(123, n_frames, h, w)
     get = lambda t: (fr['image2l'][t:t + 1], fr['image2r'][t:t + 1], fr['mask2'][t:t + 1].clone())
     make = lambda: _OracleEstimator(model, fr['K'][0], 7.2 * 250.0)
-    return sh.SequenceTracker(make, get, flow2depth=warp.flow2depth, chain=tracker.chain)
+    return sh.SequenceTracker(make, get, flow2depth=warp.flow2depth, chain=tracker.chain, chunk=chunk)
 
 
 def _worker_seq(rank, world, port, n_frames, out):
     import sys
     sys.path.insert(0, ROOT)
-    torch.set_num_threads(2)
+    torch.set_num_threads(1 if world > 4 else 2)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     tr = _oracle_tracker(n_frames)
@@ -213,7 +224,7 @@ def test_sequence_tracker_four_ranks_uneven_blocks(n_frames):
     out = mgr.dict()
     mp.spawn(_worker_seq, args=(world, _free_port(), n_frames, out), nprocs=world, join=True)
     torch.set_num_threads(2)
-    serial, rel_s, ok_s = _oracle_tracker(n_frames).track(n_frames)
+    serial, rel_s, ok_s = _oracle_tracker(n_frames, chunk=1).track(n_frames)       # the frame-at-a-time walk of the reference
     assert serial.shape == (n_frames, 7) and bool(torch.isfinite(serial).all())
     for r in range(world):
         poses, rel, ok, built = out[r]
@@ -221,3 +232,36 @@ def test_sequence_tracker_four_ranks_uneven_blocks(n_frames):
         assert torch.equal(ok, ok_s) and float((rel - rel_s).abs().max()) <= 1e-6
         assert float((poses - serial).abs().max()) <= 1e-3 * max(1.0, float(serial.abs().max()))
         assert torch.equal(poses, out[0][0])                  # bitwise the same trajectory on every rank
+
+
+def test_chunked_walk_is_the_frame_at_a_time_walk_on_the_oracle():
+    """The driver's chunking itself (chunk boundaries, a trailing single frame, the halo frame in front) with the oracle as the
+    estimator: chunk = 3 over 8 frames = 7 pairs walks (halo) 3 + 3 + 1 and must hand back exactly what chunk = 1 does."""
+    torch.set_num_threads(4)
+    one = _oracle_tracker(8, chunk=1)
+    three = _oracle_tracker(8, chunk=3)
+    r1, ok1 = one.run_block(0, 7)
+    r3, ok3 = three.run_block(0, 7)
+    assert torch.equal(r1, r3) and torch.equal(ok1, ok3) and three.estimator.chunk_calls == 2
+    a, oka = three.run_block(2, 6)                            # a block in the middle: halo frame 2, chunks of 3 + 1
+    assert float((a - r1[2:6]).abs().max()) <= 1e-6 and torch.equal(oka, ok1[2:6])
+    with pytest.raises(ValueError):
+        _oracle_tracker(3, chunk=0)
+
+
+def test_sequence_tracker_eight_ranks_chunked():
+    """World size 8 (one node), 14 frames = 13 pairs -> blocks of 2,2,2,2,2,1,1,1: the five two-pair blocks run through
+    forward_chunk, the three single-pair ones through forward; all ranks end with the serial trajectory bit for bit."""
+    import rpe_amd.sharding as sh
+    world, n_frames = 8, 14
+    assert [e - s for s, e in sh.block_partition(n_frames - 1, world)] == [2, 2, 2, 2, 2, 1, 1, 1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_seq, args=(world, _free_port(), n_frames, out), nprocs=world, join=True)
+    torch.set_num_threads(4)
+    serial, rel_s, ok_s = _oracle_tracker(n_frames, chunk=1).track(n_frames)
+    for r in range(world):
+        poses, rel, ok, built = out[r]
+        assert built == 1 and torch.equal(ok, ok_s) and float((rel - rel_s).abs().max()) <= 1e-6
+        assert float((poses - serial).abs().max()) <= 1e-3 * max(1.0, float(serial.abs().max()))
+        assert torch.equal(poses, out[0][0])
