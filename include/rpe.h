@@ -348,6 +348,15 @@ int rpe_conv_wino1d(const rpe_conv_desc *desc, void *stream);
 size_t rpe_conv1x1_packed_floats(int cout, int cin);
 int rpe_conv1x1_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv1x1(const rpe_conv_desc *desc, void *stream);
+/* Generic convolution for every shape the tuned kernels above refuse (odd maps, rows that are not whole 16-byte quads): replaces
+ * torch.nn.functional.conv2d(x, weight, bias, stride, padding) as the host code's fallback route, so that every convolution of the
+ * reference's RAFT (core/RAFT/core/extractor.py, update.py) runs in this library for any img_size (configuration/infer_f2f.yaml:13).
+ * x (b, cin, h, w) and out (b, cout, ho, wo) are channel slices given by their batch strides (floats); weight (cout, cin, kh, kw)
+ * contiguous, bias (cout) or NULL; kh, kw <= 7; stride 1 or 2; zero padding (pad_h, pad_w); ho = (h + 2 pad_h - kh) / stride + 1;
+ * relu != 0: out = max(., 0).  f32 matrix cores with element-wise operand gathers: robust, 2-3x slower than the tuned kernels. */
+int rpe_conv_direct(const float *x, long long x_batch_stride, const float *weight, const float *bias, int b, int cin, int cout,
+                    int h, int w, int kh, int kw, int stride, int pad_h, int pad_w, int relu, float *out,
+                    long long out_batch_stride, void *stream);
 /* number of moment records per (b, channel) plane rpe_conv_fused leaves for this shape (h, w: input): stride 1 one per pixel
  * tile (the launcher and this function share one tile-width rule); stride 2 one per 32 output pixels -- in both of its tile
  * classes (128 x 128, or 64 x 64 for launches too small to fill the chip), bit-identical between them, so an image's statistics

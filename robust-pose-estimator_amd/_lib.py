@@ -81,6 +81,7 @@ SIGNATURES = {
     'rpe_conv1x1_packed_floats': (_sz, [_i, _i]),
     'rpe_conv1x1_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_fused': (_i, [_c.POINTER(ConvDesc), _vp]),
+    'rpe_conv_direct': (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _ll, _vp]),
     'rpe_conv_wino_packed_floats': (_sz, [_i, _i]),
     'rpe_conv_wino_stats_tiles': (_i, [_i, _i]),
     'rpe_conv_wino_pack': (_i, [_vp, _i, _i, _vp, _vp]),

@@ -22,12 +22,6 @@
 #include "wino_common.h"
 #include <type_traits>
 
-#ifndef WINO_RQ_ASM
-#define WINO_RQ_ASM 1
-#endif
-#ifndef WINO_RQ_SHIFT
-#define WINO_RQ_SHIFT 1
-#endif
 #define WB_CO 64
 #define WB_TX 8
 #define WB_TY 4
@@ -83,10 +77,13 @@ extern "C" int rpe_debug_wino_timing(unsigned long long* out8) { return hipMemcp
 // 2 + moments (fnet); 3 all of them at run time.  (With every feature behind a run-time branch the encoder epilogue took 14-22 k
 // cycles per workgroup against 9 k for the plain one.)
 // RQ: the raw patch arrives as 16-byte quads -- rows [x0 - 4, x0 + 20) of the map, 24 floats apart in LDS, ONE global_load_lds_dwordx4 per
-// wave and step instead of three dword gathers (a DMA instruction costs the issuing wave 40-60 cycles among matrix instructions), and
-// the 24-float row pitch puts the transform's four tile rows on disjoint banks (with 18-float rows the 8-byte patch reads of tile rows
-// 0 / 2 and 1 / 3 overlapped on 8 banks: half of the kernel's LDS bank-conflict cycles).  Needs W % 4 == 0 and 16-byte aligned planes
-// (quads are then wholly inside or wholly outside the map); other shapes keep the dword gather (RQ = false).
+// wave and step instead of three dword gathers, landing 4 bytes into the buffer so that patch column 0 (map column x0 - 1) sits on
+// an 8-byte boundary.  The 24-float pitch puts the four tile rows a 32-lane group reads on disjoint banks, and the six 8-byte patch
+// reads are single ds_read_b64 (2 LDS cycles each): with 18-float rows the compiler's ds_read2_b64 form (8 cycles, 32 banks, 16-lane
+// groups) had tile rows 0 / 1 overlap on 12 banks -- the bank conflicts PMC showed (21 % of the kernel's LDS cycles).  Measured
+// (MI355X, batch 32): convc2 586 -> 570 us, encoder layer 1 / 2 1390 -> 1351 / 798 -> 772 us.  Needs W % 4 == 0 and 16-byte aligned
+// planes (quads are then wholly inside or wholly outside the map); other shapes keep the dword gather (RQ = false).  (Tried: the
+// same reads at 4-byte alignment without the shift -- correct, and 1.7x slower for the whole kernel: misaligned ds_read_b64.)
 template <int EPI, bool PRE, int CB, bool RQ>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     constexpr bool HAS_AFFINE = EPI == 1 || EPI == 3, HAS_STATS = EPI == 2 || EPI == 3;
@@ -158,9 +155,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
         if (border) {
             if (RQ) {
                 if (oob) {
-                    float* q4 = &Rs[buf][4 * (wv * 64 + lane) + (WINO_RQ_SHIFT ? 1 : 0)];
-                    if (WINO_RQ_SHIFT) { q4[0] = padv; q4[1] = padv; q4[2] = padv; q4[3] = padv; }
-                    else *(f32x4*)q4 = (f32x4){padv, padv, padv, padv};
+                    float* q4 = &Rs[buf][4 * (wv * 64 + lane) + 1];
+                    q4[0] = padv; q4[1] = padv; q4[2] = padv; q4[3] = padv;
                 }
             } else {
 #pragma unroll
@@ -176,14 +172,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     const unsigned uoff = lane * 16u;
     const size_t wstep = (size_t)(P.coP / WB_CO) * U_STEP, rstep = (size_t)WK * hw;
     const unsigned us_base = lds_addr_of(&Us[0][0]) + (unsigned)wv * (CB == 2 ? 4096u : 2048u);
-    const unsigned rs_base = lds_addr_of(&Rs[0][0]) + (RQ ? (unsigned)wv * 1024u + (WINO_RQ_SHIFT ? 4u : 0u) : (unsigned)(wv * 3) * 256u);
+    const unsigned rs_base = lds_addr_of(&Rs[0][0]) + (RQ ? (unsigned)wv * 1024u + 4u : (unsigned)(wv * 3) * 256u);
     auto dma_u = [&](const float* src, int buf) {
         if (CB == 2) dma16x4(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
         else dma16x2(src, uoff, us_base + (unsigned)buf * (UT_STEP * 4u));
     };
     auto dma_raw = [&](const float* src, int buf) {
-        if (RQ && WINO_RQ_SHIFT) dma16x1_masked(src, roff[0], rs_base + (unsigned)buf * (RBUF * 4u), wv == 3 ? 0x0000FFFFFFFFFFFFull : ~0ull);
-        else if (RQ) dma16x1(src, roff[0], rs_base + (unsigned)buf * (RBUF * 4u));
+        if (RQ) dma16x1_masked(src, roff[0], rs_base + (unsigned)buf * (RBUF * 4u), wv == 3 ? 0x0000FFFFFFFFFFFFull : ~0ull);
         else dma4x3(src, roff[0], roff[1], roff[2], rs_base + (unsigned)buf * (RBUF * 4u));
     };
     auto clamped = [&](int step) { return step < nsteps ? step : nsteps - 1; };    // (past the end: a harmless repeat keeps the DMA count per step constant)
@@ -207,16 +202,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     // The transform of step s+1 is written as three slices (patch reads, column pass, row pass + store) placed by the main loop
     float tdA[4], tdB[4], tdC[4], tta[4], ttb[4];
     float2 pn = make_float2(0.0f, 1.0f);
-    // RQ: the six 8-byte patch reads as single ds_read_b64 instructions (2 LDS cycles each, 64 banks: with 24-float rows the four tile
-    // rows of a 32-lane group fall on disjoint banks).  Written as inline asm because the compiler would merge the two reads of a row
-    // into ds_read2_b64 (8 cycles, 32 banks, 16-lane groups -- the form whose bank conflicts PMC showed) or, the pairs starting on odd
-    // floats, split each into ds_read2_b32.  The wave waits for them itself (tr_wait) before the column pass.
+    // RQ: the six 8-byte patch reads as single ds_read_b64 instructions.  Inline asm because the compiler merges the two reads of a
+    // row into ds_read2_b64; the wave waits for them itself (tr_wait) before the column pass.
     unsigned long long rqa0 = 0, rqa1 = 0, rqb0 = 0, rqb1 = 0, rqc0 = 0, rqc1 = 0;
-    const unsigned rq_base = lds_addr_of(&Rs[0][0]) + (RQ && WINO_RQ_SHIFT ? 4u : 0u);
+    const unsigned rq_base = lds_addr_of(&Rs[0][0]) + (RQ ? 4u : 0u);               // (the landing shift)
     const unsigned rq_a = rq_base + (unsigned)srcA * 4u, rq_b = rq_base + (unsigned)srcB * 4u, rq_c = rq_base + (unsigned)srcC * 4u;
     auto tr_read = [&](int step, auto rbufc) {
         constexpr int rbuf = decltype(rbufc)::value;
-        if (RQ && WINO_RQ_ASM) {
+        if (RQ) {
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqa0) : "v"(rq_a), "n"(rbuf * RBUF * 4));
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqa1) : "v"(rq_a), "n"(rbuf * RBUF * 4 + 8));
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqb0) : "v"(rq_b), "n"(rbuf * RBUF * 4));
@@ -227,17 +220,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             return;
         }
         const float* rp = &Rs[rbuf][0];
-        // (RQ: the pairs start on odd floats -- 8-byte LDS reads at 4-byte alignment)
-        typedef float2 __attribute__((aligned(4))) float2u;
-        const float2 a0 = *(const float2u*)(rp + srcA), a1 = *(const float2u*)(rp + srcA + 2), b0 = *(const float2u*)(rp + srcB), b1 = *(const float2u*)(rp + srcB + 2);
-        const float2 c0 = *(const float2u*)(rp + srcC), c1 = *(const float2u*)(rp + srcC + 2);
+        const float2 a0 = *(const float2*)(rp + srcA), a1 = *(const float2*)(rp + srcA + 2), b0 = *(const float2*)(rp + srcB), b1 = *(const float2*)(rp + srcB + 2);
+        const float2 c0 = *(const float2*)(rp + srcC), c1 = *(const float2*)(rp + srcC + 2);
         if (PRE) pn = *(const float2*)&Pn[2 * (step * WK + v_ci)];                   // (-mean / std, 1 / std)
         tdA[0] = a0.x; tdA[1] = a0.y; tdA[2] = a1.x; tdA[3] = a1.y;
         tdB[0] = b0.x; tdB[1] = b0.y; tdB[2] = b1.x; tdB[3] = b1.y;
         tdC[0] = c0.x; tdC[1] = c0.y; tdC[2] = c1.x; tdC[3] = c1.y;
     };
     auto tr_wait = [&]() {                                    // the asm reads have returned (LDS operations return in order)
-        if (RQ && WINO_RQ_ASM) {
+        if (RQ) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rqa0), "+v"(rqa1), "+v"(rqb0), "+v"(rqb1), "+v"(rqc0), "+v"(rqc1));
             auto lo = [](unsigned long long v) { return __builtin_bit_cast(float, (unsigned)v); };
             auto hi = [](unsigned long long v) { return __builtin_bit_cast(float, (unsigned)(v >> 32)); };

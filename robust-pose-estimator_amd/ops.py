@@ -464,16 +464,33 @@ def conv1x1(x, pc, mode, out, out2=None, prepare=False):
 
 
 class Conv1x1:
-    """A 1x1 layer with both packings: launches of at least 512 workgroups of 128 x 128 run on rpe_conv1x1 (LDS-DMA GEMM: convc1
-    337 -> 260 us at batch 32), smaller ones on rpe_conv_fused, whose 64 x 64 tiles fill the chip better (batch 2: 29 vs 32 us)."""
+    """A 1x1 layer with both packings, each made on first use: launches of at least 512 workgroups of 128 x 128 run on rpe_conv1x1
+    (LDS-DMA GEMM: convc1 337 -> 260 us at batch 32), smaller ones on rpe_conv_fused, whose 64 x 64 tiles fill the chip better (batch 2:
+    29 vs 32 us).  The two kernels sum the same products in the same order (bit-identical results), so the choice never shows."""
 
     def __init__(self, weight, bias=None):
-        self.fused, self.gemm = PackedConv(weight, bias), PackedConv1x1(weight, bias)
-        self.cin, self.cout = self.fused.cin, self.fused.cout
+        self._w = _nchw(weight.detach().contiguous(), 'weight')
+        self._b = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+        self.cout, self.cin = self._w.shape[0], self._w.shape[1]
+        self._fused = self._gemm = None
+
+    @property
+    def fused(self):
+        if self._fused is None:
+            self._fused = PackedConv(self._w, self._b)
+        return self._fused
+
+    @property
+    def gemm(self):
+        if self._gemm is None:
+            self._gemm = PackedConv1x1(self._w, self._b)
+        return self._gemm
 
     def __call__(self, x, mode, out, out2=None, prepare=False):
         b, _, hh, ww = x.shape
-        big = b * -(-(hh * ww) // 128) * -(-self.cout // 128) >= 512 and PackedConv1x1.supported(hh, ww)
+        # rpe_conv1x1's own preconditions (16-byte DMA pieces): plane size, base and batch stride of the input slice
+        aligned = PackedConv1x1.supported(hh, ww) and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
+        big = b * -(-(hh * ww) // 128) * -(-self.cout // 128) >= 512 and aligned
         if big:
             return conv1x1(x, self.gemm, mode, out, out2=out2, prepare=prepare)
         return conv_fused(x, self.fused, mode, out, out2=out2, prepare=prepare)
@@ -535,6 +552,32 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
         launch.keep = keep
         return launch
     check(getattr(lib(), entry)(ctypes.byref(d), stream_ptr()), entry)
+    return out
+
+
+def conv_direct(x, weight, bias=None, stride=1, padding=0, relu=False, out=None):
+    """rpe_conv_direct: torch.nn.functional.conv2d(x, weight, bias, stride, padding) [+ ReLU] for ANY map size -- the route of the shapes
+    the tuned kernels refuse (odd maps, rows that are not whole 16-byte quads).  x / out may be channel slices of NCHW buffers."""
+    xp, xbs = _chan_slice(x, 'x')
+    b, cin, hh, ww = x.shape
+    w = _nchw(weight.detach().contiguous(), 'weight')
+    cout, wcin, kh, kw = w.shape
+    if wcin != cin:
+        raise _lib.RpeError(f'conv_direct: input has {cin} channels, weight expects {wcin}')
+    st = stride if isinstance(stride, int) else stride[0]
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    ho, wo = (hh + 2 * ph - kh) // st + 1, (ww + 2 * pw - kw) // st + 1
+    if bias is not None:
+        bias = bias.detach()
+        if not (bias.is_cuda and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout):
+            raise _lib.RpeError('conv_direct: bias must be a contiguous float32 GPU vector of cout elements')
+    if out is None:
+        out = torch.empty(b, cout, ho, wo, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (b, cout, ho, wo):
+        raise _lib.RpeError(f'conv_direct: out must be ({b},{cout},{ho},{wo})')
+    op, obs = _chan_slice(out, 'out')
+    check(lib().rpe_conv_direct(xp, xbs, ptr(w), ptr(bias), b, cin, cout, hh, ww, kh, kw, st, ph, pw, int(bool(relu)), op, obs, stream_ptr()),
+          'rpe_conv_direct')
     return out
 
 

@@ -13,9 +13,10 @@ What runs where (MI355X-first split), all hand-written HIP 
     tanh | ReLU split in the epilogue) and the mask head's 1x1 on the implicit GEMM
   * flow-head output layer with the coords / flow bookkeeping of the loop, convex up-sampling, norm / bias passes, slice copies
     (csrc/raft_ops.hip)
-  On PyTorch-ROCm (MIOpen / rocBLAS) only as the fallback route of the same layers: map widths that are not a multiple of 4, odd
-  maps, and the encoders' stride-2 layers of launches too small to fill the chip.
-Exact re-associations used (results identical up to float rounding of the conv library):
+  * map sizes the tuned kernels refuse (odd maps, rows that are not whole 16-byte quads: image widths that are not a multiple of 32,
+    heights not a multiple of 16): the same layers on the generic implicit GEMM (csrc/conv_direct.hip) with the stand-alone epilogue
+    kernels -- robust, slower; no launch of a pass goes to a library at any size
+Exact re-associations used (results identical up to float rounding):
   * convz/convr of each GRU half share their input, so their weights are stacked into one 256-channel conv
   * the GRU input is (h | inp | motion | flow) and the context `inp` is the same in all 12 iterations, so the
     inp-channel part of every GRU convolution (+ bias) is computed once per pass and added inside the gate kernels:
@@ -28,7 +29,6 @@ see oracle/raft.py for the CPU restatement these kernels are tested against.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 
@@ -166,7 +166,7 @@ def conv_norm_act(conv, norm, x, relu, residual=None):
     """norm(conv(x) + bias) [ReLU] [+ residual, ReLU].  The residual blocks' convolutions -- 3x3 stride 1, 3x3 stride 2 and
     the 1x1 stride-2 shortcut -- run on the fused HIP implicit GEMM when the map width is a multiple of 4 (folded batch
     norm / ReLU / residual inside its epilogue; for instance norm the epilogue leaves per-tile partial sums and one more
-    read+write pass normalises); the 7x7 stem and the final 1x1 stay on the library with a fused HIP epilogue pass."""
+    read+write pass normalises); shapes those kernels refuse run on the generic kernel (ops.conv_direct) + a stand-alone epilogue pass."""
     b, _, hh, ww = x.shape
     fused = _fusable(conv, x)
     stride = conv.stride[0] if fused else 1
@@ -182,7 +182,7 @@ def conv_norm_act(conv, norm, x, relu, residual=None):
             out = torch.empty(b, conv.out_channels, hh // stride, ww // stride, device=x.device)
             return ops.conv_fused(x, _packed(conv), ops.CONV_RELU if relu else ops.CONV_LINEAR, out, scale=scale, bias=shift, residual=residual,
                                   stride=stride)
-        return ops.affine_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), scale, shift, relu=relu, residual=residual)
+        return ops.affine_act(ops.conv_direct(x, conv.weight, None, conv.stride, conv.padding), scale, shift, relu=relu, residual=residual)
     if isinstance(norm, nn.InstanceNorm2d):
         pw = _wino(conv, x) if fused else None
         if pw is not None:
@@ -194,7 +194,7 @@ def conv_norm_act(conv, norm, x, relu, residual=None):
             pre = ops.conv_fused(x, _packed(conv), ops.CONV_LINEAR, torch.empty(b, conv.out_channels, hh // stride, ww // stride, device=x.device),
                                  bias=conv.bias.detach(), stats=stats, stride=stride)
             return ops.instnorm_apply(pre, stats, eps=norm.eps, relu=relu, residual=residual)
-        return ops.instnorm_act(F.conv2d(x, conv.weight, None, conv.stride, conv.padding), conv.bias, eps=norm.eps, relu=relu, residual=residual)
+        return ops.instnorm_act(ops.conv_direct(x, conv.weight, None, conv.stride, conv.padding), conv.bias, eps=norm.eps, relu=relu, residual=residual)
     raise NotImplementedError(type(norm))
 
 
@@ -279,8 +279,11 @@ class BasicEncoder(nn.Module):
             cached[2](x, ops.CONV_TANH, out[:, :half])
             cached[3](x, ops.CONV_RELU, out[:, half:])
             return out
-        y = m(x)
-        return torch.cat((torch.tanh(y[:, :half]), torch.relu(y[:, half:])), dim=1) if split_act else y
+        y = ops.conv_direct(x, m.weight, m.bias, 1, 0)           # (maps whose rows are not whole 16-byte quads)
+        if split_act:
+            y[:, :half] = torch.tanh(y[:, :half])
+            ops.bias_act(y[:, half:].contiguous(), None, relu=True, out=y, out_offset=half)
+        return y
 
     def forward(self, x, raw255=False, split_act=False):
         """``raw255``: x is the raw 0..255 image (RAFT.forward's normalisation is then done inside the first kernel), or a list of
@@ -366,10 +369,10 @@ class BasicMotionEncoder(nn.Module):
     def forward(self, flow, corr, cat_buf, hx, rhx, packed=None, flow_in_place=False, flow_branch_done=None):
         """Writes relu(conv(cat[cor, flo])) (126 ch) and flow (2 ch) into channels [128,256) of hx and rhx.
         ``packed`` (BasicUpdateBlock.packed_convs) selects the fused HIP convolutions (conv + bias + ReLU + cat in
-        one kernel each); otherwise the library convolution runs without bias and rpe_bias_act does the rest.
+        one kernel each); otherwise the generic convolution (ops.conv_direct) runs without bias and rpe_bias_act does the rest.
         ``flow_branch_done``: an event recorded behind flow_branch() on another stream (it then is not run here)."""
         def cv(m, x):
-            return F.conv2d(x, m.weight, None, m.stride, m.padding)
+            return ops.conv_direct(x, m.weight, None, m.stride, m.padding)
         if packed is not None:
             _, cor, flo_buf, c1, c2, f2, cv_ = self._calls(corr, cat_buf, hx, rhx, packed)
             c1(); c2()
@@ -431,7 +434,7 @@ class BasicUpdateBlock(nn.Module):
                 (ops.conv_wino1d if isinstance(P['ctx_' + k], ops.PackedWino1d) else ops.conv_fused)(inp, P['ctx_' + k], ops.CONV_LINEAR, out[k])
             return out
         pads = {'zr1': (0, 2), 'q1': (0, 2), 'zr2': (2, 0), 'q2': (2, 0)}
-        return {k: F.conv2d(inp, W[k][1], W[k][2], padding=pads[k]) for k in W}
+        return {k: ops.conv_direct(inp, W[k][1], W[k][2], 1, pads[k]) for k in W}
 
     def packed_convs(self, width):
         """Weights of the update block's convolutions in rpe_conv_fused's layout (cached until a parameter changes), or
@@ -471,7 +474,7 @@ class BasicUpdateBlock(nn.Module):
 
     def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=False, flow_branch_done=None):
         """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
-        Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (h_buf is written by the library
+        Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (h_buf is written by the generic
         path only: the fused flow head reads the slice directly).  ``in_place`` (fused route only): ``coords1`` and ``flow`` are
         persistent buffers; the flow head's output layer updates coords1 in place and writes flow = coords1 - grid into ``flow``
         and behind the motion features of hx / rhx, so the loop runs without subtract / copy launches."""
@@ -514,17 +517,17 @@ class BasicUpdateBlock(nn.Module):
             return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)  # coords1 + delta_flow
         W = self.gate_weights()
         # horizontal half: z = s(convz1 hx), r = s(convr1 hx), q = tanh(convq1 [r*h, x]), h = (1-z) h + z q
-        zr = F.conv2d(hx, W['zr1'][0], None, padding=(0, 2))
+        zr = ops.conv_direct(hx, W['zr1'][0], None, 1, (0, 2))
         ops.gru_gates_zr(zr, hx, c, z_buf, rhx, add=ctx['zr1'])
-        q = F.conv2d(rhx, W['q1'][0], None, padding=(0, 2))
+        q = ops.conv_direct(rhx, W['q1'][0], None, 1, (0, 2))
         ops.gru_gates_h(z_buf, q, hx, c, hx, add=ctx['q1'])
         # vertical half
-        zr = F.conv2d(hx, W['zr2'][0], None, padding=(2, 0))
+        zr = ops.conv_direct(hx, W['zr2'][0], None, 1, (2, 0))
         ops.gru_gates_zr(zr, hx, c, z_buf, rhx, add=ctx['zr2'])
-        q = F.conv2d(rhx, W['q2'][0], None, padding=(2, 0))
+        q = ops.conv_direct(rhx, W['q2'][0], None, 1, (2, 0))
         ops.gru_gates_h(z_buf, q, hx, c, hx, add=ctx['q2'])
         h_buf.copy_(hx[:, :c])                                            # contiguous h for the heads
-        t = ops.bias_act(F.conv2d(h_buf, fh.conv1.weight, None, padding=1), fh.conv1.bias)
+        t = ops.conv_direct(h_buf, fh.conv1.weight, fh.conv1.bias, 1, 1, relu=True)
         return ops.conv3x3_to2(t, fh.conv2.weight, fh.conv2.bias, add=coords1)      # coords1 + delta_flow
 
     def up_mask(self, net):
@@ -542,10 +545,10 @@ class BasicUpdateBlock(nn.Module):
         if pw is not None and not torch.is_grad_enabled() and hh % 2 == 0 and ww % 2 == 0:      # (net may be a channel slice: hx[:, :128])
             t = ops.conv_wino(net, pw, ops.CONV_RELU, torch.empty(net.shape[0], c1.out_channels, hh, ww, device=net.device))
         else:
-            t = F.relu(c1(net.contiguous()))
+            t = ops.conv_direct(net, c1.weight, c1.bias, 1, 1, relu=True)
         if p2 is not None and ww % 4 == 0 and not torch.is_grad_enabled():
             return p2(t, ops.CONV_LINEAR, torch.empty(net.shape[0], c2.out_channels, hh, ww, device=net.device))
-        return F.conv2d(t, w2, b2)
+        return ops.conv_direct(t, w2, b2, 1, 0)
 
 
 def coords_grid(batch, ht, wd, device):

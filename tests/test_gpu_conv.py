@@ -781,3 +781,28 @@ def test_winograd_1d_tile_classes_agree_bitwise(rpe, kh, kw):
         small = half(hx[i:i + 2].contiguous(), azr[i:i + 2].contiguous())
         for a, s_ in zip(big, small):
             assert torch.equal(a[i:i + 2], s_)
+
+
+@pytest.mark.parametrize('cin,cout,kh,kw,stride,pad,h,w,b', [
+    (3, 64, 7, 7, 2, (3, 3), 46, 50, 2), (64, 96, 3, 3, 2, (1, 1), 45, 45, 2), (96, 96, 3, 3, 1, (1, 1), 23, 45, 3), (64, 96, 1, 1, 2, (0, 0), 45, 90, 1),
+    (256, 256, 1, 5, 1, (0, 2), 44, 45, 2), (256, 128, 5, 1, 1, (2, 0), 45, 45, 1), (324, 256, 1, 1, 1, (0, 0), 45, 45, 2), (2, 128, 7, 7, 1, (3, 3), 44, 45, 2),
+    (17, 70, 3, 3, 1, (1, 1), 5, 7, 2), (130, 2, 3, 3, 1, (1, 1), 9, 11, 1)])
+def test_generic_convolution_matches_f64(rpe, cin, cout, kh, kw, stride, pad, h, w, b):
+    """rpe_conv_direct (the route of map sizes the tuned kernels refuse) against torch's f64 convolution: every kernel shape of RAFT,
+    odd maps, channel counts that end inside a tile or a K step, channel-slice inputs and outputs, bias and ReLU."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin * 31 + cout + h)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, kh, kw, s=0.05), _rand(rng, cout, s=0.3)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), stride=stride, padding=pad)
+    xbuf = torch.full((b, cin + 3, h, w), float('nan'), device='cuda'); xbuf[:, 2:2 + cin] = x.cuda()
+    ho, wo = ref.shape[-2:]
+    obuf = torch.full((b, cout + 4, ho, wo), -7.0, device='cuda')
+    ops.conv_direct(xbuf[:, 2:2 + cin], wt.cuda(), bias.cuda(), stride, pad, out=obuf[:, 1:1 + cout])
+    tol = _tol(x, wt) * max(1.0, (cin * kh * kw / 256) ** 0.5) + 1e-6
+    assert float((obuf[:, 1:1 + cout].cpu().double() - ref).abs().max()) < tol
+    assert float(obuf[:, 0].min()) == float(obuf[:, 1 + cout:].max()) == -7.0          # nothing outside the slice is touched
+    got = ops.conv_direct(x.cuda(), wt.cuda(), None, stride, pad, relu=True)
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert float((got.cpu().double() - (ref - bias.double()[None, :, None, None]).clamp_min(0)).abs().max()) < tol
+    with pytest.raises(rpe.RpeError):
+        ops.conv_direct(x.cuda(), wt.cuda(), None, 3, pad)                              # stride 3

@@ -78,16 +78,25 @@ def test_fused_and_library_update_block_agree(models, monkeypatch):
     assert d < 1e-3 and float((hid_f - hid_l).abs().max()) < 5e-3
 
 
-def test_library_route_for_odd_widths_matches_oracle(models):
-    """Map width 45 (not a multiple of 4): rpe_conv_fused refuses, the library route runs; parity with the oracle."""
+@pytest.mark.parametrize('h,w', [(352, 360), (360, 360), (344, 400), (360, 384)])
+def test_map_sizes_the_tuned_kernels_refuse_run_on_the_generic_kernel(models, monkeypatch, h, w):
+    """1/8 maps of width 45 (rows that are not whole 16-byte quads), 45 x 45 (odd both ways) and 43 x 50: rpe_conv_fused / _wino /
+    _wino1d refuse such maps and the same layers run on rpe_conv_direct + the stand-alone epilogue kernels -- NO library convolution at
+    any size (torch's conv2d is made to raise); parity with the oracle as for the tuned route."""
     model, om, synth = models
-    h, w = 352, 360
+    import torch.nn.functional as F
+
+    def no_library(*a, **k):
+        raise AssertionError('a library convolution ran')
     fr = synth.stereo_frames(6, 1, h, w)
-    assert model.flow.update_block.packed_convs(w // 8) is None
-    flows, _, _ = model.flow(fr['image1l'].cuda(), fr['image2l'].cuda())
     with torch.no_grad():
-        oflows, _, _ = om.flow(fr['image1l'], fr['image2l'])
-    assert float((flows[-1].cpu() - oflows[-1]).abs().max()) < 1e-3
+        oflows, ohid, _ = om.flow(fr['image1l'], fr['image2l'])
+    monkeypatch.setattr(F, 'conv2d', no_library)
+    assert model.flow.update_block.packed_convs(w // 8) is None or (h // 8) % 2 == 1
+    flows, hid, _ = model.flow(fr['image1l'].cuda(), fr['image2l'].cuda())
+    d = float((flows[-1].cpu() - oflows[-1]).abs().max())
+    print(f'{h}x{w}: flow diff {d:.2e} px')
+    assert flows[-1].shape == (1, 2, h, w) and d < 1e-3 and float((hid.cpu() - ohid).abs().max()) < 5e-3
 
 
 def test_stages_match_oracle(models):
@@ -101,8 +110,10 @@ def test_stages_match_oracle(models):
         print(f'{k}: {d:.2e}')
         assert d < tol, k
     # masks are discrete: they may differ only where the oracle's own value sits on a decision boundary
-    mism = (g['mask2w'].cpu() != o['mask2w']).float().mean()
-    assert float(mism) < 2e-3
+    for k in ('mask2w', 'mask2'):
+        mism = int((g[k].cpu() != o[k]).sum())
+        print(f'{k}: {mism} pixels differ')
+        assert mism <= 50, k                                  # measured 0
     # downstream stages on IDENTICAL inputs (the oracle's flows) agree tightly
     from rpe_amd import ops
     gg = ops.depth_backproject_warp(o['stereo_flow2'].cuda(), o['time_flow'].cuda(), a['baseline'].cuda(), a['intrinsics'].cuda(),
@@ -189,7 +200,11 @@ def test_small_frames_without_weight_heads(rpe):
     pose = model.infer(**{k: v.cuda() for k, v in a.items()})
     opose = om.infer(**{k: v.clone() for k, v in a.items()})
     assert pose.data.shape == (2, 7)
-    assert float((pose.data.cpu() - opose).abs().max()) < 1e-4
+    d = (pose.data.cpu() - opose).abs().max(dim=-1).values
+    mag = opose.abs().max(dim=-1).values
+    print('config 1 (320x256, 3 iterations): per-row |pose - oracle| =', [f'{float(x):.2e}' for x in d], ' |pose| =', [f'{float(x):.2e}' for x in mag])
+    for i in range(2):                                        # 1e-6 where the 3-iteration solve stays in the unit ball, relative beyond
+        assert float(d[i]) <= 1e-6 * max(1.0, float(mag[i])), i
     info = model.pose_head.problem.last_info.cpu()
     assert info[:, 0].tolist() == [2, 2] and info[:, 2].tolist() == [4, 4]      # max_iter 3 -> max_eval 3 -> 2 iterations
 
