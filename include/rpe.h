@@ -188,6 +188,10 @@ int rpe_warp_taps(const float *flow, int n, int h, int w, int32_t *x0, int32_t *
  * queries interleaved and skewed) is private to build/lookup.
  * --------------------------------------------------------------------------------------------------------- */
 size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels);
+/* the same for a given feature_dtype of rpe_corr_build_ex: RPE_F32 / RPE_F16 need rpe_corr_pyramid_bytes; the RPE_F32X3 experiment keeps
+ * both feature maps as three bf16 planes and needs more scratch -- a pyramid that rpe_corr_build_ex(..., RPE_F32X3) writes MUST have been
+ * sized with this function and RPE_F32X3 (the library sees only the pointer; the Python binding checks the buffer length) */
+size_t rpe_corr_pyramid_bytes_ex(int b, int h8, int w8, int levels, int feature_dtype);
 /* fmap1, fmap2: (b,c,h8,w8) f32.  Computes corr[b,q1,q2] = <fmap1[:,q1], fmap2[:,q2]> / sqrt(c) and the
  * average-pooled levels. */
 int rpe_corr_build(const float *fmap1, const float *fmap2, int b, int c, int h8, int w8, int levels,

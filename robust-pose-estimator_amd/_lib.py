@@ -61,6 +61,7 @@ SIGNATURES = {
     'rpe_flow2depth': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_warp_taps': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rpe_corr_pyramid_bytes': (_sz, [_i, _i, _i, _i]),
+    'rpe_corr_pyramid_bytes_ex': (_sz, [_i, _i, _i, _i, _i]),
     'rpe_corr_build': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_build_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -86,13 +86,17 @@ __global__ __launch_bounds__(256, G1_OCC) void k_conv1x1(G1P P) {
     const int bl = lane & 31, bh = lane >> 5;
     int pxl = px0 + 4 * bl; pxl = pxl + 4 <= hw ? pxl : hw - 4;               // (hw % 4 == 0, hw >= 4)
     unsigned boff[2], boff_last[2];
+    bool past[2];                                                            // last step: this lane's row lies past the last input channel
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int k = g1_chan(4 * wv + 2 * j + bh);                           // LDS row -> input channel of the step
         boff[j] = (unsigned)((size_t)k * hw + pxl) * 4u + G1_BIAS - 1024u * j;
-        int kl = (nsteps - 1) * G1_K + k; kl = kl < cin ? kl : cin - 1;       // last step: clamp the channel
+        int kl = (nsteps - 1) * G1_K + k;
+        past[j] = kl >= cin;
+        kl = kl < cin ? kl : cin - 1;                                         // last step: clamp the channel (the row is zeroed once landed)
         boff_last[j] = (unsigned)((size_t)(kl - (nsteps - 1) * G1_K) * hw + pxl) * 4u + G1_BIAS - 1024u * j;
     }
+    const bool ragged = (cin % G1_K) != 0;                                    // (workgroup-uniform)
     const unsigned a_lds = lds_addr_of(&As[0][0]) + (unsigned)(4 * wv) * 512u, b_lds = lds_addr_of(&Bs[0][0]) + (unsigned)(4 * wv) * 512u;
     const float* xsrc = xb - G1_BIAS / 4;
     const size_t bstep = (size_t)G1_K * hw;
@@ -134,6 +138,14 @@ __global__ __launch_bounds__(256, G1_OCC) void k_conv1x1(G1P P) {
 #ifndef G1_NO_DMA
         __builtin_amdgcn_s_waitcnt(0x0F74);                                   // vmcnt(4)
 #endif
+        if (ragged && s == nsteps - 1) {
+            // rows past the last input channel were read from the clamped last channel: their weights are zero, but 0 * Inf = NaN where
+            // torch's convolution has no such term -- the rows are overwritten with zeros now that they have landed
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (past[j]) *(f32x4*)&Bs[BUF][(4 * wv + 2 * j) * 128 + lane * 4] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0)
+        }
 #ifndef G1_NO_BARRIER
         __builtin_amdgcn_s_barrier();
 #endif

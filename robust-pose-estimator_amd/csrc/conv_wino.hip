@@ -93,7 +93,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     __shared__ __attribute__((aligned(16))) float Us[3][UT_STEP];            // [ci][co][position], as packed in global memory
     __shared__ __attribute__((aligned(16))) float Vs[2][WK][WB_NT][PS];      // [ci][tile][position]
     __shared__ __attribute__((aligned(16))) float Rs[3][RBUF];               // raw input patches [ci][row][col]
-    __shared__ float Pn[PRE ? 2 * 128 : 2];                                  // PRE: (mean, 1/std) of every input channel (cin <= 128: the encoders' widths)
+    // PRE: (-mean / std, 1 / std) of every input channel (cin <= 128: the encoders' widths).  With the quad patch buffers the workgroup's
+    // LDS is exactly half a CU's 160 KB, so the 128 pairs live in the PADDING of V's first buffer (floats 16-17 of its 128 rows of 20,
+    // which neither the transform nor the fragment reads touch)
+    __shared__ float Pn[PRE && !RQ ? 2 * 128 : 2];
+    auto pn_at = [&](int i) -> float* { return PRE && RQ ? &Vs[0][i >> 5][i & 31][16] : &Pn[2 * i]; };
     // every kernel argument the set-up needs is fetched in ONE batch of scalar loads: left to the compiler they were three
     // dependent fetch - wait rounds (6-9 k cycles before the first DMA could be issued, of a 16-step workgroup's 57 k)
     asm volatile("" :: "s"(P.x), "s"(P.wp), "s"(P.out), "s"(P.bias), "s"(P.xbs), "s"(P.obs), "s"(P.cin), "s"(P.cout), "s"(P.coP), "s"(P.H),
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     if (PRE) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
         for (int i = tid; i < P.cin; i += 256) {
             const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
-            Pn[2 * i] = -m * iv; Pn[2 * i + 1] = iv;
+            float* d = pn_at(i);
+            d[0] = -m * iv; d[1] = iv;
         }
     }
     // The transform of step s+1 is written as three slices (patch reads, column pass, row pass + store) placed by the main loop
@@ -216,13 +221,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqb1) : "v"(rq_b), "n"(rbuf * RBUF * 4 + 8));
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqc0) : "v"(rq_c), "n"(rbuf * RBUF * 4));
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rqc1) : "v"(rq_c), "n"(rbuf * RBUF * 4 + 8));
-            if (PRE) pn = *(const float2*)&Pn[2 * (step * WK + v_ci)];
+            if (PRE) pn = *(const float2*)pn_at(step * WK + v_ci);
             return;
         }
         const float* rp = &Rs[rbuf][0];
         const float2 a0 = *(const float2*)(rp + srcA), a1 = *(const float2*)(rp + srcA + 2), b0 = *(const float2*)(rp + srcB), b1 = *(const float2*)(rp + srcB + 2);
         const float2 c0 = *(const float2*)(rp + srcC), c1 = *(const float2*)(rp + srcC + 2);
-        if (PRE) pn = *(const float2*)&Pn[2 * (step * WK + v_ci)];                   // (-mean / std, 1 / std)
+        if (PRE) pn = *(const float2*)pn_at(step * WK + v_ci);                       // (-mean / std, 1 / std)
         tdA[0] = a0.x; tdA[1] = a0.y; tdA[2] = a1.x; tdA[3] = a1.y;
         tdB[0] = b0.x; tdB[1] = b0.y; tdB[2] = b1.x; tdB[3] = b1.y;
         tdC[0] = c0.x; tdC[1] = c0.y; tdC[2] = c1.x; tdC[3] = c1.y;
@@ -627,7 +632,8 @@ extern "C" int rpe_conv_wino(const rpe_conv_desc* d, void* stream) {
     auto launch = [&](auto cbc, dim3 grid) {
         constexpr int CBv = decltype(cbc)::value;
 #define WINO_LAUNCH(E, PR, Q) hipLaunchKernelGGL((k_conv_wino<E, PR, CBv, Q>), grid, dim3(256), 0, s, P)
-        if (d->pre_norm) { if (epi == 2) WINO_LAUNCH(2, true, false); else WINO_LAUNCH(3, true, false); }
+        if (d->pre_norm && quads) { if (epi == 2) WINO_LAUNCH(2, true, true); else WINO_LAUNCH(3, true, true); }
+        else if (d->pre_norm) { if (epi == 2) WINO_LAUNCH(2, true, false); else WINO_LAUNCH(3, true, false); }
         else if (quads) {
             if (epi == 0) WINO_LAUNCH(0, false, true);
             else if (epi == 1) WINO_LAUNCH(1, false, true);

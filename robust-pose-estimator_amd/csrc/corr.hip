@@ -72,15 +72,21 @@ static bool make_geom(int b, int h8, int w8, int levels, PyrGeom& G) {
     return true;
 }
 
-// (6 bytes per element: the RPE_F32X3 build keeps both maps as three bf16 planes; the f32 / fp16 builds use 4 / 2 of them)
-static size_t scratch_floats(const PyrGeom& G, int c) { return (size_t)G.b * c * ((size_t)G.mp + G.np) * 3 / 2; }
+// bytes of the permuted feature maps (GEMM operands, scratch behind the pyramid): 4 per element in f32, 2 in fp16; the RPE_F32X3
+// experiment keeps both maps as three bf16 planes = 6
+static size_t scratch_bytes(const PyrGeom& G, int c, int feature_dtype) {
+    const size_t elems = (size_t)G.b * c * ((size_t)G.mp + G.np);
+    return elems * (feature_dtype == RPE_F32X3 ? 6 : 4);       // (an fp16 build fits an f32-sized buffer: one size for both)
+}
 
-extern "C" size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels) {
+extern "C" size_t rpe_corr_pyramid_bytes_ex(int b, int h8, int w8, int levels, int feature_dtype) {
     PyrGeom G;
     if (!make_geom(b, h8, w8, levels, G)) return 0;
-    // the permuted feature maps (GEMM operands, <= 256 channels) are scratch behind the pyramid
-    return ((size_t)G.total + scratch_floats(G, 256)) * 4 + 256;
+    if (feature_dtype != RPE_F32 && feature_dtype != RPE_F16 && feature_dtype != RPE_F32X3) return 0;
+    return (size_t)G.total * 4 + scratch_bytes(G, 256, feature_dtype) + 256;   // (<= 256 feature channels)
 }
+
+extern "C" size_t rpe_corr_pyramid_bytes(int b, int h8, int w8, int levels) { return rpe_corr_pyramid_bytes_ex(b, h8, w8, levels, RPE_F32); }
 
 // ------------------------------------------------------------------------------------------------ build
 // mode 0: group order  n' = (y*gx + x/8)*8 + x%8      (fmap1; padded to mp)

@@ -204,14 +204,16 @@ __global__ __launch_bounds__(64 * TO1_WAVES) void k_conv3x3_to2(const float* __r
     const bool inside = p < hw;
     const int py = inside ? (int)(p / w) : 0, px = inside ? (int)(p - (size_t)py * w) : 0;
     const float* xb = x + (size_t)bz * C * hw;
-    // neighbour offsets (clamped into the map) and 0 / 1 validity factors are the same for every channel: no conditional loads
-    int off[9]; float msk[9];
+    // neighbour offsets (clamped into the map) and validity flags are the same for every channel: no conditional loads; an out-of-map
+    // tap is SELECTED to zero after the load (a product with 0 would turn an Inf / NaN centre pixel into NaN where torch's zero padding
+    // contributes nothing)
+    int off[9]; bool msk[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int yy = py + k / 3 - 1, xx = px + k % 3 - 1;
         const bool ok = inside && yy >= 0 && yy < h && xx >= 0 && xx < w;
         off[k] = ok ? yy * w + xx : py * w + px;
-        msk[k] = ok ? 1.0f : 0.0f;
+        msk[k] = ok;
     }
     const int cq = (C + TO1_WAVES - 1) / TO1_WAVES, c_lo = wv * cq, c_hi = min(C, c_lo + cq);
     float a0 = 0.0f, a1 = 0.0f;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64 * TO1_WAVES) void k_conv3x3_to2(const float* __r
             const float* w1 = wgt + (size_t)(C + c + u) * 9;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const float t = v[u][k] * msk[k];
+                const float t = msk[k] ? v[u][k] : 0.0f;
                 a0 += t * w0[k];
                 a1 += t * w1[k];
             }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64 * TO1_WAVES) void k_conv3x3_to2(const float* __r
         const float* w1 = wgt + (size_t)(C + c) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const float t = xc[off[k]] * msk[k];
+            const float t = msk[k] ? xc[off[k]] : 0.0f;
             a0 += t * w0[k];
             a1 += t * w1[k];
         }
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(64 * TO1_WAVES) void k_conv3x3_to2(const float* __r
 // The same for maps whose width is a multiple of 4: one thread per FOUR consecutive pixels of a row.  Per channel and
 // input row it loads one aligned float4 plus its left and right neighbour (9 loads for 4 outputs instead of 36: the
 // one-pixel kernel is bound by L1 request rate, 143 us for 168 MB), always from a clamped in-range address, and zeroes
-// what lies outside the map with 0/1 factors -- no conditional loads (those compile to a branch around every load).
+// what lies outside the map by SELECTS after the loads -- no conditional loads (those compile to a branch around every load), and no
+// products with zero (0 * Inf = NaN, where torch's zero padding contributes nothing).
 #define TO2_WAVES 4                           // channel slices per workgroup: more waves in flight for a latency-bound loop
 __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* __restrict__ x, const float* __restrict__ wgt,
                                                         const float* __restrict__ bias, int C, int h, int w,
@@ -280,17 +283,16 @@ __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* 
     const bool inside = g < (hw >> 2);
     const int py = inside ? g / w4 : 0, x0 = inside ? (g - py * w4) * 4 : 0;
     const float* xb = x + (size_t)bz * C * hw;
-    int rowoff[3]; float rowm[3];
+    int rowoff[3]; bool rowk[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int yy = py + d - 1;
         const bool ok = inside && yy >= 0 && yy < h;
         rowoff[d] = (ok ? yy : py) * w + x0;
-        rowm[d] = ok ? 1.0f : 0.0f;
+        rowk[d] = ok;
     }
     const bool hasl = x0 > 0, hasr = x0 + 4 < w;
     const int offl = hasl ? -1 : 0, offr = hasr ? 4 : 3;
-    const float ml = hasl ? 1.0f : 0.0f, mr = hasr ? 1.0f : 0.0f;
     const int cq = (C + TO2_WAVES - 1) / TO2_WAVES, c_lo = wv * cq, c_hi = min(C, c_lo + cq);
     float a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     auto accumulate = [&](int c, const float4 (&m)[3], const float (&l)[3], const float (&rr)[3]) {
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* 
         const float* w1 = wgt + (size_t)(C + c) * 9;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float v[6] = {l[d] * ml * rowm[d], m[d].x * rowm[d], m[d].y * rowm[d], m[d].z * rowm[d], m[d].w * rowm[d], rr[d] * mr * rowm[d]};
+            const bool rk = rowk[d];
+            const float v[6] = {rk && hasl ? l[d] : 0.0f, rk ? m[d].x : 0.0f, rk ? m[d].y : 0.0f, rk ? m[d].z : 0.0f, rk ? m[d].w : 0.0f, rk && hasr ? rr[d] : 0.0f};
             const float k00 = w0[3 * d], k01 = w0[3 * d + 1], k02 = w0[3 * d + 2];
             const float k10 = w1[3 * d], k11 = w1[3 * d + 1], k12 = w1[3 * d + 2];
 #pragma unroll

@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
 #pragma unroll
                         for (int j = 0; j < CT; j += 4) {
                             const float4 w4 = *(const float4*)(wl + (c * 9 + t) * CT + j);
-                            acc[j] += v[c][t] * w4.x; acc[j + 1] += v[c][t] * w4.y; acc[j + 2] += v[c][t] * w4.z; acc[j + 3] += v[c][t] * w4.w;
+                            // (explicit fused multiply-adds: left to the compiler's contraction, the CT = 4 and CT = 16 instantiations came out
+                            //  with different roundings -- a frame's weights then depended on the batch it was launched in)
+                            acc[j] = fmaf(v[c][t], w4.x, acc[j]); acc[j + 1] = fmaf(v[c][t], w4.y, acc[j + 1]);
+                            acc[j + 2] = fmaf(v[c][t], w4.z, acc[j + 2]); acc[j + 3] = fmaf(v[c][t], w4.w, acc[j + 3]);
                         }
             }
         } else {
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
 #pragma unroll
                     for (int j = 0; j < CT; j += 4) {
                         const float4 w4 = *(const float4*)(wl + t * CT + j);
-                        acc[j] += v[t] * w4.x; acc[j + 1] += v[t] * w4.y; acc[j + 2] += v[t] * w4.z; acc[j + 3] += v[t] * w4.w;
+                        acc[j] = fmaf(v[t], w4.x, acc[j]); acc[j + 1] = fmaf(v[t], w4.y, acc[j + 1]);
+                        acc[j + 2] = fmaf(v[t], w4.z, acc[j + 2]); acc[j + 3] = fmaf(v[t], w4.w, acc[j + 3]);
                     }
             }
         }
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void k_u_conv3(UConvP P) {
     for (int j = 0; j < CT; ++j) {
         float v = acc[j] + (H.bias ? H.bias[co0 + j] : 0.0f);
         if (P.relu_first) v = v < 0.0f ? 0.0f : v;
-        if (H.scale) v = v * H.scale[co0 + j] + H.shift[co0 + j];
+        if (H.scale) v = fmaf(v, H.scale[co0 + j], H.shift[co0 + j]);
         if (P.relu_last) v = v < 0.0f ? 0.0f : v;
         o[(size_t)j * npix] = v;
     }
@@ -248,7 +252,10 @@ static bool unet_geo(int h8, int w8, Geo& g) {
 
 static void launch_conv3(const UConvP& P, int cout, int b, hipStream_t s) {
     const int tiles = ceil_div(P.ho * P.wo, 256);
-    if ((long long)tiles * (cout / 16) * 2 * b < 512)
+#ifndef U_CONV3_MIN_WG
+#define U_CONV3_MIN_WG 512
+#endif
+    if ((long long)tiles * (cout / 16) * 2 * b < U_CONV3_MIN_WG)
         hipLaunchKernelGGL(k_u_conv3<4>, dim3(tiles, cout / 4, 2 * b), dim3(256), 0, s, P);
     else
         hipLaunchKernelGGL(k_u_conv3<16>, dim3(tiles, cout / 16, 2 * b), dim3(256), 0, s, P);

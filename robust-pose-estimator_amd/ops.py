@@ -214,9 +214,10 @@ def warp_taps(flow):
 class CorrPyramid:
     """Opaque device buffer holding the 4-level correlation pyramid of a batch of pairs."""
 
-    def __init__(self, b, h8, w8, levels=4, radius=4, device='cuda'):
+    def __init__(self, b, h8, w8, levels=4, radius=4, device='cuda', bf16x3=False):
+        """``bf16x3``: size the scratch for the RPE_F32X3 experiment (1.5x the feature-map scratch); build(bf16x3=True) needs it."""
         self.b, self.h8, self.w8, self.levels, self.radius = b, h8, w8, levels, radius
-        nbytes = lib().rpe_corr_pyramid_bytes(b, h8, w8, levels)
+        nbytes = lib().rpe_corr_pyramid_bytes_ex(b, h8, w8, levels, 3 if bf16x3 else 0)
         if nbytes == 0:
             raise _lib.RpeError('rpe_corr_pyramid_bytes: unsupported geometry')
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -229,6 +230,8 @@ class CorrPyramid:
         b, c, h8, w8 = f1.shape
         if (b, h8, w8) != (self.b, self.h8, self.w8) or f2.shape != f1.shape:
             raise _lib.RpeError('corr build: shape mismatch')
+        if self.buf.numel() < lib().rpe_corr_pyramid_bytes_ex(b, h8, w8, self.levels, 2 if fp16_features else 3 if bf16x3 else 0):
+            raise _lib.RpeError('corr build: this pyramid was not sized for the requested feature mode (CorrPyramid(..., bf16x3=True))')
         check(lib().rpe_corr_build_ex(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, 2 if fp16_features else 3 if bf16x3 else 0, ptr(self.buf),
                                       stream_ptr()), 'rpe_corr_build_ex')
         return self

@@ -356,7 +356,7 @@ class BasicMotionEncoder(nn.Module):
                      packed['convc1_1x1'](corr, ops.CONV_RELU, cor, prepare=True),
                      c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
                      c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
-            _bounded_put(cache, key, calls)
+            _bounded_put(cache, key, calls, keep=4)
         return calls
 
     def flow_branch(self, flow, corr, cat_buf, hx, rhx, packed):
@@ -461,10 +461,10 @@ class BasicUpdateBlock(nn.Module):
                 P['ctx_' + n] = (ops.PackedWino1d if WINOGRAD else ops.PackedConv)(W[n][1], W[n][2])
             scratch = {}
 
-            def buf(name, like, c):                            # per-shape scratch for intermediate activations (two shapes kept, like RAFT._ws)
-                k = (name, like.shape[0], c, like.shape[2], like.shape[3], like.device)
+            def buf(name, like, c):                            # scratch for intermediate activations, one set per workspace (``like`` is a buffer of
+                k = (name, like.data_ptr(), like.shape[0], c, like.shape[2], like.shape[3], like.device)   # RAFT._workspace: two lanes never share one)
                 if k not in scratch:
-                    _bounded_put(scratch, k, torch.empty(like.shape[0], c, like.shape[2], like.shape[3], device=like.device), keep=6)
+                    _bounded_put(scratch, k, torch.empty(like.shape[0], c, like.shape[2], like.shape[3], device=like.device), keep=12)
                 return scratch[k]
             P['cor_buf'] = lambda like: buf('cor', like, 256)
             P['fh_buf'] = lambda like: buf('fh', like, 256)
@@ -506,7 +506,7 @@ class BasicUpdateBlock(nn.Module):
                     seq.append(ops.flow_update(P['fh_buf'](hx), fh.conv2.weight, fh.conv2.bias.detach(), coords1, coords1, flow_out=flow,
                                                dst1=hx[:, 2 * c - 2:], dst2=rhx[:, 2 * c - 2:], prepare=True))
                 calls = (key, seq)
-                _bounded_put(cache, key, calls)
+                _bounded_put(cache, key, calls, keep=4)
             if in_place:
                 for launch in calls[1]:
                     launch()
@@ -590,8 +590,9 @@ class RAFT(nn.Module):
 
     def _pyramid(self, b, h8, w8, device):
         p = self._pyr
-        if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device:
-            self._pyr = ops.CorrPyramid(b, h8, w8, self.corr_levels, self.corr_radius, device=device)
+        if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device or getattr(p, 'x3', False) != CORR_BF16X3:
+            self._pyr = ops.CorrPyramid(b, h8, w8, self.corr_levels, self.corr_radius, device=device, bf16x3=CORR_BF16X3)
+            self._pyr.x3 = CORR_BF16X3
         return self._pyr
 
     def _workspace(self, n, h8, w8, device):

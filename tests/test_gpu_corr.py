@@ -353,7 +353,7 @@ def test_bf16x3_build_is_f32_equivalent(rpe):
         ref = torch.einsum('bcq,bcp->bqp', f1.double().reshape(b, 256, -1), f2.double().reshape(b, 256, -1)) / 16.0
         errs = {}
         for name, kw in (('f32', {}), ('x3', dict(bf16x3=True))):
-            pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda(), **kw)
+            pyr = ops.CorrPyramid(b, h8, w8, device='cuda', **kw).build(f1.cuda(), f2.cuda(), **kw)
             got = pyr.export_level(0).cpu().double().reshape(b, h8 * w8, h8 * w8)
             errs[name] = float((got - ref).pow(2).mean().sqrt())
             if name == 'x3':
@@ -365,3 +365,9 @@ def test_bf16x3_build_is_f32_equivalent(rpe):
                 assert float((pyr.lookup(coords.cuda()).cpu() - oref(coords)).abs().max()) <= 4e-5 * scale
         print('rms error vs f64:', errs)
         assert errs['x3'] <= 1.25 * errs['f32'], errs
+    # the default pyramid is sized for the f32 / fp16 builds only (the experiment's three bf16 planes need 1.5x the feature scratch)
+    L = rpe.lib()
+    assert L.rpe_corr_pyramid_bytes(b, h8, w8, 4) == L.rpe_corr_pyramid_bytes_ex(b, h8, w8, 4, 0) == L.rpe_corr_pyramid_bytes_ex(b, h8, w8, 4, 2)
+    assert L.rpe_corr_pyramid_bytes_ex(b, h8, w8, 4, 3) > L.rpe_corr_pyramid_bytes(b, h8, w8, 4)
+    with pytest.raises(rpe.RpeError):
+        ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda(), bf16x3=True)

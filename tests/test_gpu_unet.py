@@ -53,3 +53,21 @@ def test_fused_heads_reject_small_grids(rpe):
     z = lambda c: torch.zeros(1, c, 32, 40, device='cuda')
     with pytest.raises(rpe.RpeError, match='too small'):
         ops.unet_heads(z(8), z(8), z(128), z(128), unet.pack_params(nets[0]), unet.pack_params(nets[1]), (256, 320))
+
+
+def test_fused_heads_do_not_depend_on_the_batch(rpe):
+    """At 640x512 a batch of 16 runs the valid 3x3 layers on 16-channel threads, a batch of 1 or 8 on 4-channel threads (launch fill):
+    same explicit fused multiply-adds in the same order, so a frame's weight maps are the same bits in any batch (the chunked sequence
+    tracker relies on it: 16-frame chunks against the reference's frame-at-a-time walk)."""
+    from rpe_amd import ops, unet
+    torch.manual_seed(0)
+    H, W = 512, 640
+    h8, w8, b = H // 8, W // 8, 16
+    n2, n3 = unet.TinyUNet(264, (H, W)).cuda().eval(), unet.TinyUNet(272, (H, W)).cuda().eval()
+    p2, p3 = unet.pack_params(n2), unet.pack_params(n3)
+    i1, i2 = torch.randn(b, 8, h8, w8, device='cuda'), torch.randn(b, 8, h8, w8, device='cuda')
+    hid, ctx = torch.randn(b, 128, h8, w8, device='cuda'), torch.randn(b, 128, h8, w8, device='cuda')
+    full = ops.unet_heads(i1, i2, hid, ctx, p2, p3, (H, W))
+    for sl in (slice(0, 1), slice(5, 13)):
+        part = ops.unet_heads(i1[sl].contiguous(), i2[sl].contiguous(), hid[sl].contiguous(), ctx[sl].contiguous(), p2, p3, (H, W))
+        assert torch.equal(part[0], full[0][sl]) and torch.equal(part[1], full[1][sl])

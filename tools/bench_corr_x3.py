@@ -25,7 +25,7 @@ for kind in ('gaussian', 'relu-like, heavy tails'):
     f1 = torch.randn(b, 256, h8, w8, device=dev); f2 = torch.randn(b, 256, h8, w8, device=dev)
     if kind != 'gaussian':
         f1 = torch.relu(f1 + 1.0) * torch.exp(0.8 * torch.randn(b, 256, 1, 1, device=dev)); f2 = torch.relu(f2 + 1.0) * torch.exp(0.8 * torch.randn(b, 256, 1, 1, device=dev))
-    pyr = ops.CorrPyramid(b, h8, w8, device=dev)
+    pyr = ops.CorrPyramid(b, h8, w8, device=dev, bf16x3=True)
     ref = torch.einsum('cq,cp->qp', f1[3].double().reshape(256, -1), f2[3].double().reshape(256, -1)) / 16.0
     scale = float(ref.abs().max())
     for name, kw in (('f32', {}), ('bf16x3', dict(bf16x3=True))):
