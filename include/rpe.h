@@ -440,7 +440,11 @@ int rpe_remap_nearest(const void *src, int src_is_u8, int c, int h, int w, const
  * 52-59 pseudo_rectify_2d): dst = cv2.warpAffine(src, [[1,0,tx],[0,1,ty]], (w,h)), i.e. INTER_LINEAR with source coordinates
  * rounded to 1/32 pixel (fixed point, AB_BITS = 10), OpenCV's 5-bit bilinear table (uint8: integer weights summing to 2^15,
  * (sum + 2^14) >> 15; float32: float weights), BORDER_CONSTANT 0.  tx = lkmat[0][2] - rkmat[0][2], ty = lkmat[1][2] - rkmat[1][2]
- * as float32 (the reference builds the matrix with .astype(np.float32)).  Planar (c,h,w) uint8 or float32. */
+ * as float32 (the reference builds the matrix with .astype(np.float32)).  Planar (c,h,w) uint8 or float32.
+ * RESTATED, UNPINNED: the arithmetic above is OpenCV 4.x's imgwarp.cpp as published, restated without cv2 in the build image; it is
+ * tested bit for bit against a scalar restatement of the same description (oracle/rectify.py), NOT against cv2.warpAffine itself --
+ * a 1-LSB difference to a particular OpenCV build (other interpolation tables, FMA contraction in remapBilinear<float>) would go
+ * unnoticed until a golden from real cv2 (oracle/gen_golden.py on a machine that has it) pins both. */
 int rpe_shift_bilinear(const void *src, int src_is_u8, int c, int h, int w, float tx, float ty, void *dst, void *stream);
 
 #ifdef __cplusplus
