@@ -283,6 +283,23 @@ def test_flow_head_with_fused_bookkeeping(rpe):
         assert torch.equal(again, ops.conv3x3_to2(x, wt, bias, add=want))
 
 
+def test_flow_head_kernels_agree_bitwise(rpe):
+    """A large launch takes the four-pixels-per-thread kernel (neighbours by DPP wave shifts), a small one the one-pixel kernel:
+    same channel slices, tap order and explicit fused multiply-adds, so a map's flow update is the same bits in any batch."""
+    from rpe_amd import ops
+    torch.manual_seed(8)
+    for (b, c, h, w) in ((32, 256, 64, 80), (40, 128, 44, 48)):
+        x = torch.randn(b, c, h, w).cuda()
+        wt, bias = (torch.randn(2, c, 3, 3) * 0.05).cuda(), torch.randn(2).cuda()
+        add = (torch.randn(b, 2, h, w) * 10).cuda()
+        big = ops.conv3x3_to2(x, wt, bias, add=add)
+        ref = F.conv2d(x.double().cpu(), wt.double().cpu(), bias.double().cpu(), padding=1) + add.double().cpu()
+        assert float((big.cpu().double() - ref).abs().max()) < 2e-4
+        for sl in (slice(0, 1), slice(b - 2, b)):
+            small = ops.conv3x3_to2(x[sl].contiguous(), wt, bias, add=add[sl].contiguous())
+            assert torch.equal(small, big[sl])
+
+
 def test_copy_planes(rpe):
     from rpe_amd import ops
     src = torch.randn(3, 10, 7, 12, device='cuda')
