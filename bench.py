@@ -392,8 +392,8 @@ def run_batch(args, rank, world, dev, dist):
         finally:
             timing['on'] = False
 
-    step()                                         # set-up pass (untimed, not a warm-up step): MIOpen picks its
-    torch.cuda.synchronize()                       # conv algorithms on first use, like a compile step
+    step()                                         # set-up pass (untimed, not a warm-up step): weights are packed and the
+    torch.cuda.synchronize()                       # persistent workspaces / launch descriptors built on first use
     for _ in range(args.warmup):
         step()
     elapsed, out = timed_region(timed_step, args.steps, 0, dev, dist)

@@ -3,8 +3,9 @@
 // Replaces (reference's RAFT submodule): core/RAFT/core/update.py SepConvGRU.forward
 //     z = sigmoid(convz(hx)); r = sigmoid(convr(hx)); q = tanh(convq(cat[r*h, x])); h = (1-z)*h + z*q
 // and core/RAFT/core/raft.py RAFT.upsample_flow (softmax over the 9 neighbours, weighted sum of 8*flow).
-// The convolutions themselves stay on MIOpen (dense contractions); these kernels remove the sigmoid / mul /
-// cat / tanh / blend round trips through HBM between them.
+// On the tuned route these gate kernels are the epilogues of the convolutions (conv_wino1d.hip, conv.hip); stand-alone they serve the
+// generic route (conv_direct.hip: map sizes the tuned kernels refuse) and remove the sigmoid / mul / cat / tanh / blend round trips
+// through HBM between the convolutions.
 #include "rpe_common.h"
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

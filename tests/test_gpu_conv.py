@@ -146,7 +146,7 @@ def test_winograd_1d_rejects_what_it_cannot_do(rpe):
 
 
 def test_fused_gates_agree_with_the_separate_kernels(rpe):
-    """Same inputs through library convolution + rpe_gru_gates_* (the path used when the width is not a multiple of 4)."""
+    """Same inputs through a plain convolution + rpe_gru_gates_* (the stand-alone gate kernels of the generic route, used when the map width is not a multiple of 4)."""
     from rpe_amd import ops
     c, b, h, w = 128, 1, 32, 40
     rng = np.random.default_rng(5)

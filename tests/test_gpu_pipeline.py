@@ -1,7 +1,7 @@
 """GPU: the host mirrors (RAFT, PoseNet, PoseEstimator) with the HIP kernels inside, against the CPU oracle with
 the SAME seeded weights on the SAME seeded stereo pairs.
 
-RAFT has no reference pin (its submodule is empty); parity here is GPU kernels + MIOpen convolutions vs the
+RAFT has no reference pin (its submodule is empty); parity here is the hand-written GPU kernels vs the
 oracle's torch-CPU restatement.  Float tolerance: flows within 1e-3 px after 12 GRU iterations (measured 2e-5),
 end-to-end pose within 1e-5 (measured 5e-10), everything downstream also compared stage-wise on identical inputs.
 """
@@ -54,8 +54,8 @@ def test_raft_matches_oracle(models):
     assert d0 < 1e-4 and d11 < 1e-3            # measured 4e-6 / 2e-5 px
     assert float((hid.cpu() - ohid).abs().max()) < 5e-3 and float((ctx.cpu() - octx).abs().max()) < 1e-3
     last_only, _, _ = model.flow(i1.cuda(), i2.cuda())
-    # (MIOpen may pick different conv algorithms call to call, so repeated runs agree to round-off, not bitwise)
-    assert len(last_only) == 1 and float((last_only[0] - flows[-1]).abs().max()) < 1e-3
+    # (repeated runs: every kernel is deterministic -- fixed summation orders, no atomics)
+    assert len(last_only) == 1 and torch.equal(last_only[0], flows[-1])
     low, _, _ = model.flow(i1.cuda(), i2.cuda(), upsample=False)
     with torch.no_grad():
         olow, _, _ = om.flow(i1, i2, upsample=False)
