@@ -93,6 +93,21 @@ def test_forward_chunk_returns_the_chained_poses_of_single_calls(seq):
     assert torch.equal(a.frame.depth, b.frame.depth) and torch.equal(a.frame.mask, b.frame.mask) and torch.equal(a.last_frame.img, b.last_frame.img)
 
 
+def test_track_sequence_in_chunks_writes_the_same_trajectory(seq):
+    """trajectory.track_sequence (the loop of scripts/infer_trajectory.py:70-91) with chunk = 4: the same poses and stamps, bit for bit."""
+    from rpe_amd import pose_estimator, trajectory
+    model, K, (L, R, M) = seq
+    out = {}
+    for chunk in (1, 4):
+        est = pose_estimator.PoseEstimator(CFG, K, 7.2 * 250.0, model, (W, H)).cuda()
+        frames = ((L[t:t + 1], R[t:t + 1], M[t:t + 1].clone(), 100 + t) for t in range(10))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            out[chunk] = trajectory.track_sequence(est, frames, start_stamp=99, chunk=chunk)
+    assert [t['timestamp'] for t in out[4]] == [t['timestamp'] for t in out[1]] == [99] + list(range(100, 110))
+    assert all(torch.equal(a['camera-pose'], b['camera-pose']) for a, b in zip(out[1], out[4]))
+
+
 def test_solve_rows_do_not_depend_on_the_batch_with_partition_rows_1(rpe):
     """rpe_solve_opts.partition_rows = 1: a row's float64 sums are grouped as if it were solved alone."""
     from rpe_amd import ops, synth
