@@ -98,6 +98,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     // which neither the transform nor the fragment reads touch)
     __shared__ float Pn[PRE && !RQ ? 2 * 128 : 2];
     auto pn_at = [&](int i) -> float* { return PRE && RQ ? &Vs[0][i >> 5][i & 31][16] : &Pn[2 * i]; };
+    // (Pn is referenced, hence allocated, only by the pre-norm kernels on the dword-gather path)
+    static_assert(sizeof(Us) + sizeof(Vs) + sizeof(Rs) + (PRE && !RQ ? sizeof(Pn) : 0) <= 81920, "two workgroups per CU: at most half of the 160 KB LDS each");
     // every kernel argument the set-up needs is fetched in ONE batch of scalar loads: left to the compiler they were three
     // dependent fetch - wait rounds (6-9 k cycles before the first DMA could be issued, of a 16-step workgroup's 57 k)
     asm volatile("" :: "s"(P.x), "s"(P.wp), "s"(P.out), "s"(P.bias), "s"(P.xbs), "s"(P.obs), "s"(P.cin), "s"(P.cout), "s"(P.coP), "s"(P.H),
