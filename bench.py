@@ -93,7 +93,9 @@ def parse_args(argv=None):
                     help="BASELINE config 5: fp16 feature maps into the correlation (upstream RAFT's mixed_precision), f32 pyramid, f64 solve")
     ap.add_argument('--corr-bf16x3', action='store_true',
                     help='EXPERIMENT (reported under its own dtype, never the headline): the correlation build with every f32 product as six bf16 products of an exact 3-way split (RPE_F32X3)')
-    ap.add_argument('--no-extras', action='store_true', help='skip the batch-1 latency / tracker / Gauss-Newton lines')
+    ap.add_argument('--no-extras', action='store_true', help='skip the batch-1 latency / tracker / Gauss-Newton lines (and the live PMC traffic passes)')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='do not run the two rocprofv3 --pmc child passes after the timed region; roofline.traffic then comes from profiles/pmc_traffic.json')
     return ap.parse_args(argv)
 
 
@@ -444,12 +446,68 @@ def run_batch(args, rank, world, dev, dist):
         'valid_fraction': float(gpu_in['mask2'].float().mean()),
         'peak_hbm_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
     }
+    if world == 1 and not args.no_extras and not args.no_live_traffic:
+        live = live_lookup_traffic(args)              # HBM bytes per lookup launch measured NOW, on this box, over this program's own launches
+        if live is not None:
+            res['roofline'].update(traffic=live['traffic_bytes_per_launch'], traffic_source=live['source'], traffic_detail=live)
     if world == 1 and not args.no_extras:             # deployment numbers, measured after the timed region on rank 0
         res['roofline_lookup_realistic'] = lookup_realistic(last_lookup['pyr'], last_lookup['out'], B, H, W, dev)
         res.update(deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_events, timing))
     if args.cpu_frames > 0 and world == 1:            # CPU baseline on rank 0 at N = 1 only
         res['cpu_baseline'] = cpu_baseline(cfg, model, frames, args.cpu_frames, pose)
     return res
+
+
+def live_lookup_traffic(args):
+    """roofline.traffic measured in THIS run: two child passes of this very program under ``rocprofv3 --pmc <one counter> --kernel-trace``
+    (FETCH_SIZE, then WRITE_SIZE: separate passes, --kernel-trace only, the program itself after ``--``, as MI355X_MICROARCH.md's HBM
+    section prescribes), after the timed region so that they disturb nothing.  Bytes per k_corr_lookup launch = 2 x FETCH_SIZE KiB x 1024
+    (gfx950 tallies a 128-byte read request at 64 bytes) + WRITE_SIZE KiB x 1024; k_pose_reduce's known 42 B / pixel in the same passes
+    is returned as the calibration.  Any failure (no rocprofv3, a timeout, an unexpected file layout) returns None and the line keeps
+    the figure of profiles/pmc_traffic.json, labelled as such."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return None
+    vals = {}
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = tempfile.mkdtemp(prefix='rpe_pmc_', dir='/tmp')
+            cmd = [exe, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--', sys.executable, os.path.abspath(__file__),
+                   '--steps', '1', '--warmup', '1', '--cpu-frames', '0', '--no-extras', '--batch', str(args.batch), '--height', str(args.height),
+                   '--width', str(args.width), '--raft-iters', str(args.raft_iters), '--solver', args.solver, '--solver-iters', str(args.solver_iters)]
+            if args.fp16_features:
+                cmd.append('--fp16-features')
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            acc = {'k_corr_lookup': [], 'k_pose_reduce': []}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get('Counter_Name') != ctr:
+                        continue
+                    for k in acc:
+                        if k in row['Kernel_Name']:
+                            acc[k].append(float(row['Counter_Value']))
+            shutil.rmtree(d, ignore_errors=True)
+            if not acc['k_corr_lookup']:
+                return None
+            vals[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items() if v}
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    rd = 2.0 * 1024.0 * vals['FETCH_SIZE']['k_corr_lookup'][0]
+    wr = 1024.0 * vals['WRITE_SIZE']['k_corr_lookup'][0]
+    out = {'traffic_bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr, 'launches': vals['FETCH_SIZE']['k_corr_lookup'][1],
+           'source': 'measured in this run: two child passes of bench.py (--steps 1 --warmup 1, same workload) under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE '
+                     '--kernel-trace; read = 2 x FETCH_SIZE KiB x 1024 (gfx950 tallies 128-byte requests at 64), write = WRITE_SIZE KiB x 1024'}
+    if 'k_pose_reduce' in vals['FETCH_SIZE']:
+        out['calibration_pose_reduce_read_bytes'] = 2.0 * 1024.0 * vals['FETCH_SIZE']['k_pose_reduce'][0]
+        out['calibration_pose_reduce_algorithmic_bytes'] = args.batch * args.height * args.width * 42
+    return out
 
 
 def lookup_rounds(pyr, coords):
