@@ -377,7 +377,9 @@ int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, 
 /* The same with a residual that is itself the RAW output of an instance-normalised convolution: residual_mean_inv (b,c,2) =
  * (mean, 1/sqrt(var + eps)) from rpe_instnorm_finalize, and the residual term becomes relu((residual - mean) * inv) -- the first
  * residual block of fnet then reads the stem's raw output twice (as input through `pre_norm`, as shortcut through this) and the
- * stem's normalised output is never written (BasicEncoder.forward: relu1(norm1(conv1 x)) -> layer1, core/RAFT/core/extractor.py). */
+ * stem's normalised output is never written (BasicEncoder.forward: relu1(norm1(conv1 x)) -> layer1, core/RAFT/core/extractor.py).
+ * relu: bit 0 = ReLU on y (as above); bit 1 = the raw residual is normalised WITHOUT a ReLU -- the shortcut of a stride-2 ResidualBlock,
+ * norm3(conv1x1 x) (extractor.py), whose normalised output then never exists as a tensor either. */
 int rpe_instnorm_apply_ex(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                           const float *residual, const float *residual_mean_inv, float *out, void *stream);
 /* mean_inv (b,c,2) = (mean, 1/sqrt(var + eps)) of each plane from the same partial sums: the `pre_norm` input of the

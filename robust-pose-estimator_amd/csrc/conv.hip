@@ -573,11 +573,12 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict_
     float4* op = (float4*)(out + (size_t)plane * hw);
     const bool rnorm = res_mi != nullptr;
     const float rmean = rnorm ? res_mi[(size_t)plane * 2] : 0.0f, rinv = rnorm ? res_mi[(size_t)plane * 2 + 1] : 1.0f;
+    const bool yrelu = relu & 1, rrelu = !(relu & 2);         // bit 1: the raw residual's own norm has no ReLU (a stride-2 block's shortcut)
     auto fin = [&](float v, float r) -> float {
         float y = (v - mean) * inv;
-        if (relu) y = y < 0.0f ? 0.0f : y;
+        if (yrelu) y = y < 0.0f ? 0.0f : y;
         if (rp) {
-            if (rnorm) { r = (r - rmean) * rinv; r = r < 0.0f ? 0.0f : r; }
+            if (rnorm) { r = (r - rmean) * rinv; if (rrelu) r = r < 0.0f ? 0.0f : r; }
             y = r + y; y = y < 0.0f ? 0.0f : y;
         }
         return y;

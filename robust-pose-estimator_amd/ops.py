@@ -729,9 +729,10 @@ def instnorm_finalize(stats, hw, eps=1e-5, channels=None):
     return mi
 
 
-def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None, residual_norm=None):
+def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None, residual_norm=None, residual_relu=True):
     """Instance norm of x (b,c,h,w) from the partial sums of conv_fused(..., stats=stats): one read + one write pass.
-    ``residual_norm`` (b,c,2) from instnorm_finalize: the residual is a RAW convolution output, normalised + ReLU'd on the fly."""
+    ``residual_norm`` (b,c,2) from instnorm_finalize: the residual is a RAW convolution output, normalised (+ ReLU'd unless
+    ``residual_relu=False``: a stride-2 block's shortcut has none) on the fly."""
     _nchw(x, 'x')
     b, c, hh, ww = x.shape
     t, tiles = _stats_layout(stats, b, c, 'instnorm_apply')
@@ -741,7 +742,8 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None, resid
                                                                and residual_norm.is_contiguous() and tuple(residual_norm.shape) == (b, c, 2))):
         raise _lib.RpeError(f'instnorm_apply: residual_norm must be a contiguous float32 ({b},{c},2) GPU tensor next to a residual')
     out = x if out is None else _nchw(out, 'out')
-    check(lib().rpe_instnorm_apply_ex(ptr(x), ptr(t), tiles, b, c, hh * ww, float(eps), int(bool(relu)), ptr(residual), ptr(residual_norm),
+    flags = int(bool(relu)) | (0 if residual_relu or residual_norm is None else 2)
+    check(lib().rpe_instnorm_apply_ex(ptr(x), ptr(t), tiles, b, c, hh * ww, float(eps), flags, ptr(residual), ptr(residual_norm),
                                       ptr(out), stream_ptr()), 'rpe_instnorm_apply_ex')
     return out
 

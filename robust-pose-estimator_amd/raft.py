@@ -92,8 +92,19 @@ class ResidualBlock(nn.Module):
                 stats1 = ops.conv_stats_buffer(b, self.conv1.out_channels, hh, ww, x.device, stride=st)
                 ops.conv_fused(x, _packed(self.conv1), ops.CONV_LINEAR, raw1, bias=self.conv1.bias.detach(), stats=stats1, stride=st)
             mi = ops.instnorm_finalize(stats1, (hh // st) * (ww // st), eps=self.norm1.eps, channels=self.conv1.out_channels)
+            res_relu = True
             if self.downsample is not None:
-                x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)
+                sc = self.downsample[0]
+                if _fusable(sc, x):
+                    # the shortcut norm3(conv1x1 x) never exists as a tensor either: its raw convolution output and (mean, 1/std) go to
+                    # the block's last pass, which normalises it on the fly (bit-identical to a pass of its own, tested)
+                    stats_sc = ops.conv_stats_buffer(b, sc.out_channels, hh, ww, x.device, stride=st)
+                    x = ops.conv_fused(x, _packed(sc), ops.CONV_LINEAR, torch.empty(b, sc.out_channels, hh // st, ww // st, device=x.device),
+                                       bias=sc.bias.detach(), stats=stats_sc, stride=st)
+                    x_norm = ops.instnorm_finalize(stats_sc, (hh // st) * (ww // st), eps=self.norm3.eps, channels=sc.out_channels)
+                    res_relu = False
+                else:
+                    x = conv_norm_act(sc, self.norm3, x, relu=False)
             ho, wo = raw1.shape[-2:]
             w2 = _wino(self.conv2, raw1)
             raw2 = torch.empty(b, self.conv2.out_channels, ho, wo, device=x.device)
@@ -103,7 +114,7 @@ class ResidualBlock(nn.Module):
             else:
                 stats2 = ops.conv_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
                 ops.conv_fused(raw1, _packed(self.conv2), ops.CONV_LINEAR, raw2, bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
-            return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x, residual_norm=x_norm)
+            return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x, residual_norm=x_norm, residual_relu=res_relu)
         y = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         if self.downsample is not None:
             x = conv_norm_act(self.downsample[0], self.norm3, x, relu=False)

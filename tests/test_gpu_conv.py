@@ -689,6 +689,11 @@ def test_instnorm_apply_with_a_raw_residual(rpe):
     own = ((res_raw.cuda() - res_mi[..., 0][:, :, None, None]) * res_mi[..., 1][:, :, None, None]).clamp_min(0)
     two_pass = ops.instnorm_apply(raw.clone(), stats, eps=1e-5, relu=True, residual=own)
     assert torch.equal(got, two_pass)
+    # a stride-2 block's shortcut: norm3 has NO ReLU (residual_relu=False) -- again the same bits as normalising it in a pass of its own
+    got_nr = ops.instnorm_apply(raw.clone(), stats, eps=1e-5, relu=True, residual=res_raw.cuda(), residual_norm=res_mi, residual_relu=False)
+    own_nr = (res_raw.cuda() - res_mi[..., 0][:, :, None, None]) * res_mi[..., 1][:, :, None, None]
+    assert torch.equal(got_nr, ops.instnorm_apply(raw.clone(), stats, eps=1e-5, relu=True, residual=own_nr))
+    assert not torch.equal(got_nr, got)
     with pytest.raises(rpe.RpeError):
         ops.instnorm_apply(raw.clone(), stats, residual_norm=res_mi)              # a norm without a residual
 
