@@ -555,6 +555,43 @@ __global__ __launch_bounds__(256) void k_instnorm_finalize(const float* __restri
     (void)hw;
 }
 
+// The same for rpe_conv_wino's TILE-MAJOR records (b, tiles, C, 3): a plane's records are 12 bytes every 12 C bytes, so the per-plane
+// merge above pulls a whole 64-byte sector per 12-byte record (1 280 records per plane behind a 256 x 320 layer: 130 us per launch).
+// Here a workgroup takes FOUR neighbouring channels of one batch item -- 48 contiguous bytes per tile -- as 64 tile slices x 4 channels;
+// the slices are combined pairwise in a fixed tree.  Two passes (mean, then the deviations about it) in f64 like plane_moments.
+__global__ __launch_bounds__(256) void k_instnorm_finalize_tm(const float* __restrict__ partials, int tiles, int C, float eps, float* __restrict__ mi) {
+    const int b = blockIdx.y, cl = threadIdx.x & 3, sl = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
+    __shared__ double sh[2][64][4];
+    const bool ok = c < C;
+    const float* pp = partials + ((size_t)b * tiles * C + (ok ? c : 0)) * 3;
+    const size_t ts = (size_t)3 * C;
+    auto tree = [&](double (*v)[4]) {                         // v[0][cl] <- sum over the 64 slices, pairwise, fixed order
+#pragma unroll
+        for (int h = 32; h >= 1; h >>= 1) {
+            __syncthreads();
+            if (sl < h) v[sl][cl] += v[sl + h][cl];
+        }
+        __syncthreads();
+    };
+    double n = 0.0, a = 0.0;
+    for (int t = sl; t < tiles; t += 64) { const double nt = (double)pp[ts * t]; n += nt; a += nt * (double)pp[ts * t + 1]; }
+    sh[0][sl][cl] = n; sh[1][sl][cl] = a;
+    tree(sh[0]); tree(sh[1]);
+    n = sh[0][0][cl]; a = sh[1][0][cl];
+    const double mean = a / n;
+    double q = 0.0;
+    for (int t = sl; t < tiles; t += 64) { const double d = (double)pp[ts * t + 1] - mean; q += (double)pp[ts * t + 2] + (double)pp[ts * t] * d * d; }
+    __syncthreads();
+    sh[0][sl][cl] = q;
+    tree(sh[0]);
+    if (sl == 0 && ok) {
+        double var = sh[0][0][cl] / n;
+        var = var < 0.0 ? 0.0 : var;
+        float* o = mi + ((size_t)b * C + c) * 2;
+        o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // Instance norm from the per-tile (n, mean, M2) records k_conv_igemm / k_stem7x7 left behind: one workgroup per (b, c)
 // plane combines them in f64 (biased variance), then normalises in ONE read + write pass:
 //   y = (x - mean) / sqrt(var + eps); if (relu) y = max(y, 0); if (residual) y = max(residual + y, 0)
@@ -750,6 +787,7 @@ extern "C" int rpe_instnorm_apply(const float* x, const float* partials, int til
 
 extern "C" int rpe_instnorm_finalize(const float* partials, int tiles, int b, int c, int hw, float eps, float* mean_inv, void* stream) {
     if (!partials || !mean_inv || tiles == 0 || b <= 0 || c <= 0 || hw <= 0) return RPE_E_BADARG;
-    hipLaunchKernelGGL(k_instnorm_finalize, dim3(b * c), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, hw, eps, mean_inv);
+    if (tiles < 0) hipLaunchKernelGGL(k_instnorm_finalize_tm, dim3(ceil_div(c, 4), b), dim3(256), 0, (hipStream_t)stream, partials, -tiles, c, eps, mean_inv);
+    else hipLaunchKernelGGL(k_instnorm_finalize, dim3(b * c), dim3(256), 0, (hipStream_t)stream, partials, tiles, c, hw, eps, mean_inv);
     return rpe_check_launch();
 }
