@@ -601,7 +601,31 @@ def deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_
     finally:
         model.pose_head.problem.lbgfs_iters = keep
     out['tracker_fps'] = F / dt
+    # the same 24 frames in chunks of 16 (PoseEstimator.forward_chunk: one RAFT pass per chunk, bit-identical poses; what
+    # SequenceTracker / bench.py --mode sequence run)
+    L, R, Mk = (torch.cat([f[i] for f in seq]) for i in range(3))
+    model.pose_head.problem.lbgfs_iters = 20
+    try:
+        for rep in range(2):
+            est = pose_estimator.PoseEstimator(slam, frames['K'][0], 7.2 * 250.0, model, (W, H)).to(dev)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                est(L[:1], R[:1], Mk[:1].clone())
+                for a in range(1, F, 16):
+                    e = min(F, a + 16)
+                    if e - a == 1:
+                        est(L[a:e], R[a:e], Mk[a:e].clone())
+                    else:
+                        est.forward_chunk(L[a:e], R[a:e], Mk[a:e].clone())
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t
+    finally:
+        model.pose_head.problem.lbgfs_iters = keep
+    out['tracker_chunk16_fps'] = F / dtc
     out['tracker_config'] = f'PoseEstimator, {F} frames one at a time, {W}x{H}, 12 GRU iters, L-BFGS 20, encoder outputs of frame t reused at t+1'
+    out['tracker_chunk16_config'] = 'the same frames through PoseEstimator.forward_chunk in chunks of 16 (one RAFT pass per chunk; poses bit-identical to one frame at a time)'
     # Gauss-Newton mode of the same step
     if args.solver != 'gn':
         prob = model.pose_head.problem
