@@ -93,6 +93,21 @@ def test_forward_chunk_returns_the_chained_poses_of_single_calls(seq):
     assert torch.equal(a.frame.depth, b.frame.depth) and torch.equal(a.frame.mask, b.frame.mask) and torch.equal(a.last_frame.img, b.last_frame.img)
 
 
+def test_forward_chunk_without_feature_reuse(seq):
+    """reuse_features=False (re-encode the previous left image like the reference does): the chunk encodes image0l itself; same bits."""
+    from rpe_amd import pose_estimator
+    model, K, (L, R, M) = seq
+    cfg = dict(CFG, reuse_features=False)
+    a = pose_estimator.PoseEstimator(cfg, K, 7.2 * 250.0, model, (W, H)).cuda()
+    b = pose_estimator.PoseEstimator(cfg, K, 7.2 * 250.0, model, (W, H)).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        single = [a(L[t:t + 1], R[t:t + 1], M[t:t + 1].clone())[0].data.reshape(1, 7).clone() for t in range(5)]
+        b(L[:1], R[:1], M[:1].clone())
+        P = b.forward_chunk(L[1:5], R[1:5], M[1:5].clone())[0]
+    assert torch.equal(P, torch.cat(single[1:])) and torch.equal(a.frame.depth, b.frame.depth) and b._enc_cache is None
+
+
 def test_track_sequence_in_chunks_writes_the_same_trajectory(seq):
     """trajectory.track_sequence (the loop of scripts/infer_trajectory.py:70-91) with chunk = 4: the same poses and stamps, bit for bit."""
     from rpe_amd import pose_estimator, trajectory
