@@ -472,8 +472,8 @@ class BasicUpdateBlock(nn.Module):
                 P['ctx_' + n] = (ops.PackedWino1d if WINOGRAD else ops.PackedConv)(W[n][1], W[n][2])
             scratch = {}
 
-            def buf(name, like, c):                            # scratch for intermediate activations, one set per workspace (``like`` is a buffer of
-                k = (name, like.data_ptr(), like.shape[0], c, like.shape[2], like.shape[3], like.device)   # RAFT._workspace: two lanes never share one)
+            def buf(name, like, c):                            # scratch for intermediate activations, one set per workspace (``like`` is one of
+                k = (name, like.data_ptr(), like.shape[0], c, like.shape[2], like.shape[3], like.device)   # RAFT._workspace's buffers)
                 if k not in scratch:
                     _bounded_put(scratch, k, torch.empty(like.shape[0], c, like.shape[2], like.shape[3], device=like.device), keep=12)
                 return scratch[k]
