@@ -43,23 +43,28 @@ __device__ __forceinline__ float half_wave_sum_s(float v) {
     return v;
 }
 
-template <int CIN, int STRIDE>
+// COB = 32-channel blocks per workgroup: 2 -> 64 output channels; 1 -> 32, for launches of a few dozen workgroups (the motion encoder's
+// convf1 of one frame pair: 80 workgroups of 64 channels on 256 CUs, each a chain of weight staging -> patch staging -> 224 matrix
+// instructions per wave): twice the workgroups, half the weights to stage and half the matrix instructions each.  Same products in
+// the same order: bit-identical outputs.
+template <int CIN, int STRIDE, int COB>
 __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     typedef StemGeo<CIN, STRIDE> G;
+    constexpr int TCO = 32 * COB;
     constexpr int SK = G::SK, SKA = G::SKA, PROWS = G::PROWS, PCOLS = G::PCOLS, PSTR = G::PSTR, TAPS = G::TAPS;
     const int SNP = P.snp;
-    __shared__ __attribute__((aligned(16))) float As[64][SKA];
+    __shared__ __attribute__((aligned(16))) float As[TCO][SKA];
     __shared__ float patch[CIN][PROWS][PSTR];
     __shared__ __attribute__((aligned(16))) int koff[SK];
     __shared__ float red[4][64][3];                          // per wave and channel: sum(v - p), sum((v - p)^2), pivot p
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int bz = blockIdx.z, cbase = blockIdx.y * 64;
+    const int bz = blockIdx.z, cbase = blockIdx.y * TCO;
     const int tiles_x = (P.Wo + SPX - 1) / SPX;
     const int ntiles = tiles_x * ((P.Ho + SPY - 1) / SPY);
     const size_t hw_in = (size_t)P.H * P.W;
     const float* xb = P.x + (size_t)bz * CIN * hw_in;
     // ---- stage weights and tap table once; then SNP patches one after the other
-    for (int i = tid; i < 64 * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)(P.wk + (size_t)cbase * SKA))[i];
+    for (int i = tid; i < TCO * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)(P.wk + (size_t)cbase * SKA))[i];
     for (int k = tid; k < SK; k += 256) {
         const int kk = k < TAPS ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
         koff[k] = (ci * PROWS + dy) * PSTR + dx;
@@ -93,9 +98,9 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     }
     __syncthreads();
     // ---- 64 (co) x 256 (px) per workgroup; wave wv owns output rows 2*wv, 2*wv+1 of the patch (32 px each)
-    f32x16 acc[2][2];
+    f32x16 acc[COB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < COB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
         const int kb = 16 * blk + 8 * lh;
         f32x4 a0[2], a1[2]; i32x4 ko[2];
         a0[0] = *(const f32x4*)&As[l31][kb];      a0[1] = *(const f32x4*)&As[l31][kb + 4];
-        a1[0] = *(const f32x4*)&As[32 + l31][kb]; a1[1] = *(const f32x4*)&As[32 + l31][kb + 4];
+        if (COB == 2) { a1[0] = *(const f32x4*)&As[TCO - 32 + l31][kb]; a1[1] = *(const f32x4*)&As[TCO - 32 + l31][kb + 4]; }
+        else { a1[0] = a0[0]; a1[1] = a0[1]; }
         ko[0] = *(const i32x4*)&koff[kb];         ko[1] = *(const i32x4*)&koff[kb + 4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -117,15 +123,17 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
             const float fa0 = a0[j >> 2][j & 3], fa1 = a1[j >> 2][j & 3];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, b1, acc[1][1], 0, 0, 0);
+            if (COB == 2) {
+                acc[COB - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, b0, acc[COB - 1][0], 0, 0, 0);
+                acc[COB - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, b1, acc[COB - 1][1], 0, 0, 0);
+            }
         }
     }
     // ---- epilogue (C/D layout: col = lane&31 = tx, row = (r&3) + 8*(r>>2) + 4*lh)
     const size_t hw = (size_t)P.Ho * P.Wo;
     float* ob = P.out + ((size_t)bz * P.cout + cbase) * hw;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < COB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
         }
     if (P.stats) {
         __syncthreads();
-        if (tid < 64) {
+        if (tid < TCO) {
             StatAcc A;
             int ncols = P.Wo - x0; ncols = ncols > SPX ? SPX : ncols;
 #pragma unroll
@@ -203,8 +211,14 @@ extern "C" int rpe_stem_conv(const float* image, int b, int cin, int h, int w, i
     // (bench: 15 360 stem patches; one frame of sequential tracking: 640)
     const long long patches = (long long)rpe_stem_tiles(h, w, stride) * (cout / 64) * b;
     P.snp = patches >= 5 * 2048 ? 5 : patches >= 2 * 2048 ? 2 : 1;
+    if (patches < 256) {                           // fewer workgroups than CUs: 32-channel workgroups (same arithmetic, bit-identical)
+        dim3 g1(rpe_stem_tiles(h, w, stride), cout / 32, b);
+        if (cin == 3) hipLaunchKernelGGL((k_stem7x7<3, 2, 1>), g1, dim3(256), 0, (hipStream_t)stream, P);
+        else hipLaunchKernelGGL((k_stem7x7<2, 1, 1>), g1, dim3(256), 0, (hipStream_t)stream, P);
+        return rpe_check_launch();
+    }
     dim3 grid(ceil_div(rpe_stem_tiles(h, w, stride), P.snp), cout / 64, b);
-    if (cin == 3) hipLaunchKernelGGL((k_stem7x7<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL((k_stem7x7<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    if (cin == 3) hipLaunchKernelGGL((k_stem7x7<3, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((k_stem7x7<2, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, P);
     return rpe_check_launch();
 }

@@ -388,6 +388,26 @@ def test_convf1_patch_kernel_matches_f64(rpe, h, w, b):
     assert got.shape == ref.shape and (got.cpu().double() - ref).abs().max() < _tol(flow, wt)
 
 
+def test_stem_small_and_large_launches_agree_bitwise(rpe):
+    """Launches of fewer than 256 patches run the 7x7 kernels on 32-channel workgroups (twice the workgroups, half the chain each):
+    same products, same order, same statistics records -- the same bits as inside a large batch."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(77)
+    # convf1: one frame pair (2 x 20 patches x 2 tiles of 64 = 80 < 256) against a batch of 8
+    flow, wt, bias = _rand(rng, 8, 2, 64, 80, s=5.0).cuda(), _rand(rng, 128, 2, 7, 7, s=0.1).cuda(), _rand(rng, 128, s=0.3).cuda()
+    ps = ops.PackedStem(wt)
+    big = ops.stem_conv(flow, ps, bias=bias, relu=True, div=1.0, mul=1.0, sub=0.0)
+    for sl in (slice(0, 2), slice(7, 8)):
+        assert torch.equal(ops.stem_conv(flow[sl].contiguous(), ps, bias=bias, relu=True, div=1.0, mul=1.0, sub=0.0), big[sl])
+    # the encoder stem with statistics: one 128 x 160 image (40 patches) against a batch of 8
+    img = torch.from_numpy(rng.integers(0, 256, size=(8, 3, 128, 160)).astype(np.float32)).cuda()
+    w3, b3 = _rand(rng, 64, 3, 7, 7, s=0.1).cuda(), _rand(rng, 64, s=0.3).cuda()
+    p3 = ops.PackedStem(w3)
+    raw8, st8 = ops.stem_conv(img, p3, bias=b3, relu=False, stats=True)
+    raw1, st1 = ops.stem_conv(img[3:4].contiguous(), p3, bias=b3, relu=False, stats=True)
+    assert torch.equal(raw1, raw8[3:4]) and torch.equal(st1, st8[3:4])
+
+
 def test_random_shapes_against_library(rpe):
     """Forty seeded random problems (channel counts that are no multiple of anything, maps that end inside tiles, every
     supported kernel shape and stride, small and large launches) against the library's f32 convolution on the same GPU."""
