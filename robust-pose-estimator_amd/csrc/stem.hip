@@ -43,6 +43,38 @@ __device__ __forceinline__ float half_wave_sum_s(float v) {
     return v;
 }
 
+// Epilogue of one patch for one wave.  sb[co][2] = (scale | 1, bias | 0) of the workgroup's channels; element offsets within the
+// (batch item, channel tile) block are 32-bit (the launcher checks the size).
+template <int COB, bool STATS, bool INSIDE>
+__device__ __forceinline__ void stem_epilogue(f32x16 (&acc)[COB][2], const StemP& P, float* __restrict__ ob, const float* sb, float* red,
+                                              int x0, int y0, int wv, int l31, int lh) {
+    const unsigned hw = (unsigned)(P.Ho * P.Wo);
+    const int ya = y0 + 2 * wv, x = x0 + l31;
+    const bool ok0 = INSIDE || ((ya < P.Ho) & (x < P.Wo)), ok1 = INSIDE || ((ya + 1 < P.Ho) & (x < P.Wo));
+    const unsigned lane_off = (unsigned)(ya * P.Wo + x) + (unsigned)(4 * lh) * hw, wo = (unsigned)P.Wo;
+    const bool relu = P.relu != 0;
+    const float* sbl = sb + 8 * lh;
+#pragma unroll
+    for (int i = 0; i < COB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cc = i * 32 + (r & 3) + 8 * (r >> 2);                // + 4 * lh: this lane's channel of the tile
+            const float2 s2 = *(const float2*)(sbl + 2 * cc);
+            float v0 = fmaf(acc[i][0][r], s2.x, s2.y), v1 = fmaf(acc[i][1][r], s2.x, s2.y);
+            if (STATS) {                                                      // sums about a pivot (the wave's first output of this channel), see k_conv_igemm
+                const float piv = __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 32)
+                                                               : __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 0));
+                const float d0 = ok0 ? v0 - piv : 0.0f, d1 = ok1 ? v1 - piv : 0.0f;
+                const float ssum = half_wave_sum_s(d0 + d1), ssq = half_wave_sum_s(fmaf(d1, d1, d0 * d0));
+                if (l31 == 31) { float* rd = red + ((wv * 64) + cc + 4 * lh) * 3; rd[0] = ssum; rd[1] = ssq; rd[2] = piv; }
+            }
+            if (relu) { v0 = v0 < 0.0f ? 0.0f : v0; v1 = v1 < 0.0f ? 0.0f : v1; }
+            const unsigned e = lane_off + (unsigned)cc * hw;
+            if (ok0) ob[e] = v0;
+            if (ok1) ob[e + wo] = v1;
+        }
+}
+
 // COB = 32-channel blocks per workgroup: 2 -> 64 output channels; 1 -> 32, for launches of a few dozen workgroups (the motion encoder's
 // convf1 of one frame pair: 80 workgroups of 64 channels on 256 CUs, each a chain of weight staging -> patch staging -> 224 matrix
 // instructions per wave): twice the workgroups, half the weights to stage and half the matrix instructions each.  Same products in
@@ -57,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     __shared__ float patch[CIN][PROWS][PSTR];
     __shared__ __attribute__((aligned(16))) int koff[SK];
     __shared__ float red[4][64][3];                          // per wave and channel: sum(v - p), sum((v - p)^2), pivot p
+    __shared__ __attribute__((aligned(8))) float sb[TCO][2];  // (scale | 1, bias | 0) per channel of the tile
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int bz = blockIdx.z, cbase = blockIdx.y * TCO;
     const int tiles_x = (P.Wo + SPX - 1) / SPX;
@@ -64,7 +97,12 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     const size_t hw_in = (size_t)P.H * P.W;
     const float* xb = P.x + (size_t)bz * CIN * hw_in;
     // ---- stage weights and tap table once; then SNP patches one after the other
+#if defined(STEM_ABL) && (STEM_ABL & 8)
+    for (int i = tid; i < TCO * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = make_float4(0.01f * i, 0.0f, 1.0f, 0.5f);
+#else
     for (int i = tid; i < TCO * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)(P.wk + (size_t)cbase * SKA))[i];
+#endif
+    if (tid < TCO) { sb[tid][0] = P.scale ? P.scale[cbase + tid] : 1.0f; sb[tid][1] = P.bias ? P.bias[cbase + tid] : 0.0f; }
     for (int k = tid; k < SK; k += 256) {
         const int kk = k < TAPS ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
         koff[k] = (ci * PROWS + dy) * PSTR + dx;
@@ -84,7 +122,11 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
             const int ci = i / (PROWS * PCOLS), rem = i - ci * (PROWS * PCOLS), r = rem / PCOLS, c = rem - r * PCOLS;
             const int yi = STRIDE * y0 - 3 + r, xi = STRIDE * x0 - 3 + c;
             const bool ok = (i < CIN * PROWS * PCOLS) & (yi >= 0) & (yi < P.H) & (xi >= 0) & (xi < P.W);
+#if defined(STEM_ABL) && (STEM_ABL & 1)
+            raw[u] = (float)i;
+#else
             raw[u] = xb[ok ? ci * hw_in + (size_t)yi * P.W + xi : 0];
+#endif
             okm |= ok ? (1u << u) : 0u;
         }
 #pragma unroll
@@ -109,7 +151,11 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     const int lane0 = (STRIDE * (2 * wv)) * PSTR + STRIDE * l31, lane1 = (STRIDE * (2 * wv + 1)) * PSTR + STRIDE * l31;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
+#if defined(STEM_ABL) && (STEM_ABL & 2)
+    for (int blk = 0; blk < (P.H == 1 ? SK / 16 : 1); ++blk) {
+#else
     for (int blk = 0; blk < SK / 16; ++blk) {
+#endif
         const int kb = 16 * blk + 8 * lh;
         f32x4 a0[2], a1[2]; i32x4 ko[2];
         a0[0] = *(const f32x4*)&As[l31][kb];      a0[1] = *(const f32x4*)&As[l31][kb + 4];
@@ -129,35 +175,19 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
             }
         }
     }
-    // ---- epilogue (C/D layout: col = lane&31 = tx, row = (r&3) + 8*(r>>2) + 4*lh)
-    const size_t hw = (size_t)P.Ho * P.Wo;
-    float* ob = P.out + ((size_t)bz * P.cout + cbase) * hw;
-#pragma unroll
-    for (int i = 0; i < COB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float sc = P.scale ? P.scale[cbase + co] : 1.0f, bi = P.bias ? P.bias[cbase + co] : 0.0f;
-            // statistics about a pivot (the wave's first output of this channel), see k_conv_igemm
-            const float v00 = acc[i][0][r] * sc + bi;
-            const float piv = P.stats ? __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(__builtin_bit_cast(int, v00), 32)
-                                                                     : __builtin_amdgcn_readlane(__builtin_bit_cast(int, v00), 0)) : 0.0f;
-            float ssum = 0.0f, ssq = 0.0f;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int y = y0 + 2 * wv + jj, x = x0 + l31;
-                if (y >= P.Ho || x >= P.Wo) continue;
-                float v = acc[i][jj][r] * sc + bi;
-                const float dv = v - piv;
-                ssum += dv; ssq += dv * dv;
-                if (P.relu) v = v < 0.0f ? 0.0f : v;
-                ob[(size_t)co * hw + (size_t)y * P.Wo + x] = v;
-            }
-            if (P.stats) {
-                ssum = half_wave_sum_s(ssum); ssq = half_wave_sum_s(ssq);
-                if (l31 == 31) { red[wv][co][0] = ssum; red[wv][co][1] = ssq; red[wv][co][2] = piv; }
-            }
-        }
+    // ---- epilogue (C/D layout: col = lane&31 = tx, row = (r&3) + 8*(r>>2) + 4*lh): v = acc * scale + bias from the LDS table,
+    // moments about a pivot, ReLU, store.  Compile-time shapes (moments or not | patch inside the map or on its border): as one
+    // loop with every feature behind a run-time test it was 64 dependent scalar-bias loads, 500 branches and 1 660 vector
+    // instructions per wave and patch -- as long as the patch's 320 matrix instructions.
+    {
+        const size_t hw = (size_t)P.Ho * P.Wo;
+        float* ob = P.out + ((size_t)bz * P.cout + cbase) * hw;
+        const bool inside = (y0 + SPY <= P.Ho) & (x0 + SPX <= P.Wo);
+        if (P.stats) { if (inside) stem_epilogue<COB, true, true>(acc, P, ob, &sb[0][0], &red[0][0][0], x0, y0, wv, l31, lh);
+                       else stem_epilogue<COB, true, false>(acc, P, ob, &sb[0][0], &red[0][0][0], x0, y0, wv, l31, lh); }
+        else { if (inside) stem_epilogue<COB, false, true>(acc, P, ob, &sb[0][0], &red[0][0][0], x0, y0, wv, l31, lh);
+               else stem_epilogue<COB, false, false>(acc, P, ob, &sb[0][0], &red[0][0][0], x0, y0, wv, l31, lh); }
+    }
     if (P.stats) {
         __syncthreads();
         if (tid < TCO) {
@@ -204,6 +234,7 @@ extern "C" int rpe_stem_conv(const float* image, int b, int cin, int h, int w, i
                              int cout, const float* bias, const float* scale, int relu, float* out, float* stats, void* stream) {
     if (!image || !packed || !out || b <= 0 || h <= 0 || w <= 0) return RPE_E_BADARG;
     if (!stem_ok(cin, stride, cout) || (stride == 2 && ((h & 1) || (w & 1))) || (((uintptr_t)packed) & 15)) return RPE_E_UNSUPPORTED;
+    if ((long long)(h / stride) * (w / stride) * 65 * 4 >= (1ll << 32)) return RPE_E_UNSUPPORTED;      // 32-bit offsets within a 64-channel output block
     StemP P;
     P.x = image; P.H = h; P.W = w; P.Ho = h / stride; P.Wo = w / stride; P.cout = cout; P.div = div; P.mul = mul; P.sub = sub; P.wk = packed;
     P.bias = bias; P.scale = scale; P.relu = relu; P.out = out; P.stats = stats;
