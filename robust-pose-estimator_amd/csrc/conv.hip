@@ -19,6 +19,7 @@
 // Zero padding: rows (y+dy outside the map) are zero-filled by the loader (whole float4s, W % 4 == 0); columns
 // (x+dx outside the row) are masked per lane when the B operand is read.
 #include "rpe_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CK 16
@@ -88,6 +89,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm = wv / WN, wn = wv % WN;
     const int W = P.W, hw = P.hw, ph = P.kh / 2;
+    // encoder epilogues: (scale | 1, bias | 0) of the tile's channel rows, staged now, read after the K loop (whose barriers publish it)
+    __shared__ __attribute__((aligned(8))) float sbt[ENC ? BM : 1][2];
+    if (ENC && tid < BM) {
+        const int co = m0 + tid;
+        sbt[tid][0] = (P.scale && co < P.cout) ? P.scale[co] : 1.0f;
+        sbt[tid][1] = (P.bias && co < P.cout) ? P.bias[co] : 0.0f;
+    }
     const int hw_in = S2 ? P.Hin * P.Win : hw;
     // weights loader: thread -> (m = tid % BM, k4 = tid / BM [+ 256/BM * u]);  packed as [step][k4][coP][4]
     const int a_m = tid % BM, a_k4 = tid / BM;
@@ -404,80 +412,93 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP P) {
     static_assert(WN * NS * 3 <= 2 * KS, "statistics scratch must fit the weights tiles");
     // Four channel rows x T column blocks per batch: the residual loads of a batch are issued back to back from clamped
     // in-range addresses (per-element validity branches made the compiler emit load - wait - store per element), then
-    // the arithmetic, then stores under the lane mask.
-    const float* resb = P.res ? P.res + (size_t)bz * P.rbs : nullptr;
-    const float* addb = P.add ? P.add + (size_t)bz * P.abs_ : nullptr;
-    float* outb = P.out + (size_t)bz * P.obs;
-    float* out2b = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+    // the arithmetic, then stores under the lane mask.  Compile-time shapes (moments or not | residual / addend / second
+    // output or none of them): with every feature behind a run-time test the stride-2 layers' epilogue was ~600 scalar branches
+    // and 64 dependent scale / bias loads per wave; (scale, bias) now come from the LDS table staged before the K loop.
+    auto epilogue = [&](auto statsc, auto extrac) {
+        constexpr bool STATS = decltype(statsc)::value, EXTRA = decltype(extrac)::value;
+        const float* resb = EXTRA && P.res ? P.res + (size_t)bz * P.rbs : nullptr;
+        const float* addb = EXTRA && P.add ? P.add + (size_t)bz * P.abs_ : nullptr;
+        float* outb = P.out + (size_t)bz * P.obs;
+        float* out2b = EXTRA && P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+        const bool relu = mode == RPE_CONV_RELU;
 #pragma unroll
-    for (int i = 0; i < T; ++i) {
-        const int row0 = wm * WT + i * 32 + 4 * lh;
+        for (int i = 0; i < T; ++i) {
+            const int row0 = wm * WT + i * 32 + 4 * lh;
 #pragma unroll
-        for (int rb = 0; rb < 16; rb += 4) {
-            size_t e[T][4]; bool ok[T][4]; float rv[T][4], av[T][4], sc[4], bi[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = m0 + row0 + r + 8 * (rb >> 2);
-                const bool cok = co < P.cout;
-                sc[r] = P.scale ? P.scale[cok ? co : 0] : 1.0f;
-                bi[r] = P.bias ? P.bias[cok ? co : 0] : 0.0f;
-#pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    const int px = n0 + wn * WT + j * 32 + l31;
-                    ok[j][r] = cok && px < hw;
-                    e[j][r] = ok[j][r] ? (size_t)co * hw + px : 0;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < T; ++j)
+            for (int rb = 0; rb < 16; rb += 4) {
+                size_t e[T][4]; bool ok[T][4]; float rv[T][4], av[T][4], sc[4], bi[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    rv[j][r] = resb ? resb[e[j][r]] : 0.0f;
-                    av[j][r] = addb ? addb[e[j][r]] : 0.0f;
+                    const int row = row0 + r + 8 * (rb >> 2), co = m0 + row;
+                    const bool cok = co < P.cout;
+                    const float2 s2 = *(const float2*)&sbt[row][0];
+                    sc[r] = s2.x; bi[r] = s2.y;
+#pragma unroll
+                    for (int j = 0; j < T; ++j) {
+                        const int px = n0 + wn * WT + j * 32 + l31;
+                        ok[j][r] = cok && px < hw;
+                        e[j][r] = ok[j][r] ? (size_t)co * hw + px : 0;
+                    }
+                }
+                if (EXTRA) {
+#pragma unroll
+                    for (int j = 0; j < T; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            rv[j][r] = resb ? resb[e[j][r]] : 0.0f;
+                            av[j][r] = addb ? addb[e[j][r]] : 0.0f;
+                        }
                 }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float vv[T];
+                for (int r = 0; r < 4; ++r) {
+                    float vv[T];
 #pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    float v = acc[i][j][rb + r];
-                    if (P.scale) v *= sc[r];
-                    v += av[j][r];
-                    v += bi[r];
-                    vv[j] = v;
-                }
-                // Instance-norm statistics are taken about a PIVOT (this wave's first column of the channel row), not about
-                // zero: sum(v - p) and sum((v - p)^2) keep their digits when |mean| >> std (a large conv bias is pure shift;
-                // E[v^2] - mean^2 from f32 sums loses mean^2/var * 1e-7 of the variance).
-                // Stride 2 (NS = T): one record per 32-pixel block of the plane, whatever the tile class -- a 64 x 64-tile launch
-                // (small batches) and a 128 x 128-tile one leave the SAME records, so the statistics of an image do not depend on
-                // how many images share the launch (the chunked sequence tracker relies on that).
-                float piv[NS], ssum[NS], ssq[NS];
+                    for (int j = 0; j < T; ++j) {
+                        if (EXTRA) { float v = acc[i][j][rb + r] * sc[r]; v += av[j][r]; v += bi[r]; vv[j] = v; }
+                        else vv[j] = fmaf(acc[i][j][rb + r], sc[r], bi[r]);
+                    }
+                    // Instance-norm statistics are taken about a PIVOT (this wave's first column of the channel row), not about
+                    // zero: sum(v - p) and sum((v - p)^2) keep their digits when |mean| >> std (a large conv bias is pure shift;
+                    // E[v^2] - mean^2 from f32 sums loses mean^2/var * 1e-7 of the variance).
+                    // Stride 2 (NS = T): one record per 32-pixel block of the plane, whatever the tile class -- a 64 x 64-tile launch
+                    // (small batches) and a 128 x 128-tile one leave the SAME records, so the statistics of an image do not depend on
+                    // how many images share the launch (the chunked sequence tracker relies on that).
+                    float piv[NS], ssum[NS], ssq[NS];
+                    if (STATS) {
 #pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) {
-                    const int vb = __builtin_bit_cast(int, vv[S2 ? s2 : 0]);
-                    piv[s2] = P.stats ? __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(vb, 32) : __builtin_amdgcn_readlane(vb, 0)) : 0.0f;
-                    ssum[s2] = 0.0f; ssq[s2] = 0.0f;
-                }
+                        for (int s2 = 0; s2 < NS; ++s2) {
+                            const int vb = __builtin_bit_cast(int, vv[S2 ? s2 : 0]);
+                            piv[s2] = __builtin_bit_cast(float, lh ? __builtin_amdgcn_readlane(vb, 32) : __builtin_amdgcn_readlane(vb, 0));
+                            ssum[s2] = 0.0f; ssq[s2] = 0.0f;
+                        }
+                    }
 #pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    float v = vv[j];
-                    if (ok[j][r]) { const float dv = v - piv[S2 ? j : 0]; ssum[S2 ? j : 0] += dv; ssq[S2 ? j : 0] += dv * dv; }
-                    if (mode == RPE_CONV_RELU) v = v < 0.0f ? 0.0f : v;
-                    if (resb) { v = rv[j][r] + v; v = v < 0.0f ? 0.0f : v; }
-                    if (ok[j][r]) { outb[e[j][r]] = v; if (out2b) out2b[e[j][r]] = v; }
-                }
-                if (P.stats) {                                   // sum over the 32 lanes that share this channel row
-                    const int row = row0 + r + 8 * (rb >> 2);
+                    for (int j = 0; j < T; ++j) {
+                        float v = vv[j];
+                        if (STATS) { const float dv = ok[j][r] ? v - piv[S2 ? j : 0] : 0.0f; ssum[S2 ? j : 0] += dv; ssq[S2 ? j : 0] = fmaf(dv, dv, ssq[S2 ? j : 0]); }
+                        if (relu) v = v < 0.0f ? 0.0f : v;
+                        if (EXTRA && resb) { v = rv[j][r] + v; v = v < 0.0f ? 0.0f : v; }
+                        if (ok[j][r]) { outb[e[j][r]] = v; if (EXTRA && out2b) out2b[e[j][r]] = v; }
+                    }
+                    if (STATS) {                                 // sum over the 32 lanes that share this channel row
+                        const int row = row0 + r + 8 * (rb >> 2);
 #pragma unroll
-                    for (int s2 = 0; s2 < NS; ++s2) {
-                        const float a = half_wave_sum(ssum[s2]), q = half_wave_sum(ssq[s2]);
-                        float* rd = red + ((wn * NS + s2) * BM + row) * 3;
-                        if (l31 == 31) { rd[0] = a; rd[1] = q; rd[2] = piv[s2]; }
+                        for (int s2 = 0; s2 < NS; ++s2) {
+                            const float a = half_wave_sum(ssum[s2]), q = half_wave_sum(ssq[s2]);
+                            float* rd = red + ((wn * NS + s2) * BM + row) * 3;
+                            if (l31 == 31) { rd[0] = a; rd[1] = q; rd[2] = piv[s2]; }
+                        }
                     }
                 }
             }
         }
+    };
+    {
+        typedef std::integral_constant<bool, true> Yes; typedef std::integral_constant<bool, false> No;
+        const bool extra = P.res || P.add || P.out2;
+        if (P.stats) { if (extra) epilogue(Yes{}, Yes{}); else epilogue(Yes{}, No{}); }
+        else { if (extra) epilogue(No{}, Yes{}); else epilogue(No{}, No{}); }
     }
     if (P.stats) {                                               // combine the WN waves that cover the same channels
         __syncthreads();
