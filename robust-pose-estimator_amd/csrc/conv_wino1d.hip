@@ -267,35 +267,49 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
     // group first transposes its 16 columns x 4 rows through LDS -- the wave's own slice of the idle weight ring -- and a lane
     // ends up with four consecutive columns of one row: every access below is 16 bytes in both orientations.
     float* tsc = &Us[0][wv * (CB == 2 ? 512 : 256)] + lk * 64;
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int tile = tw * 32 + tb * 16 + li;
-        const int oy = VERT ? y0 + 4 * (tile >> 4) + (li >> 2) : y0 + (tile >> 2), ox = VERT ? x0 + 4 * (li & 3) : x0 + 4 * (tile & 3);
-        const bool pok = (oy < H) & (ox < W);                         // (W % 4 == 0: a quad is inside or outside as a whole)
-        auto st4 = [&](float* p, size_t e, const float (&v)[4]) {
-            if (pok) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
+    // Compile-time shapes: MODE = the GRU gate (or -1: linear / ReLU / second output, tested at run time) and FAST = nothing to mask
+    // (the patch lies inside the map, every channel of the tile exists, and for GATE_ZR the z | r boundary is a tile boundary, so a
+    // workgroup is all z or all r).  As one loop with every test per row and lane the epilogue was 2 000 vector and 1 200 scalar
+    // instructions with 330 branches per wave -- a tenth of a 96-step workgroup.
+    auto epilogue = [&](auto modec, auto fastc) {
+        constexpr int MODE = decltype(modec)::value;
+        constexpr bool FAST = decltype(fastc)::value;
+        const bool rtile = co0 >= cg;                                     // (FAST GATE_ZR: uniform)
+        constexpr int NB = 4 * CB, RU = 2;                                // units of (16 tiles x 16 channels, RU of a lane's four channel rows): n = (tb * CB + cb) * 2 + half
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto where = [&](int tb, int& oy, int& ox) {
+            const int tile = tw * 32 + tb * 16 + li;
+            oy = VERT ? y0 + 4 * (tile >> 4) + (li >> 2) : y0 + (tile >> 2); ox = VERT ? x0 + 4 * (li & 3) : x0 + 4 * (tile & 3);
         };
+        // every operand of a block's gate arithmetic (four channel rows: addend, and z | h of the gates), requested at once
+        auto load_block = [&](int n, f32x4 (&av)[RU], f32x4 (&xv)[RU], f32x4 (&hv)[RU]) {
+            const int tb = (n >> 1) / CB, cb = (n >> 1) % CB, r0 = RU * (n & 1);
+            int oy, ox; where(tb, oy, ox);
+            const bool pok = FAST || ((oy < H) & (ox < W));               // (W % 4 == 0: a quad is inside or outside as a whole)
+            const size_t pxo = (size_t)oy * W + ox;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            // the four channel rows of a block: every operand of their gate arithmetic is requested first (loaded where it is used,
-            // each row waited a memory round trip behind the previous row's store -- the in-place h update keeps the compiler from
-            // moving loads across stores), then the arithmetic and the stores
-            f32x4 av_[4], xv_[4], hv_[4];
-            const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
-                const bool ok = pok && co < P.cout;
-                const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
-                av_[r] = (addb && ok) ? *(const f32x4*)(addb + e0) : zero4;
-                xv_[r] = hv_[r] = zero4;
-                if (mode == RPE_CONV_GATE_ZR) { if (ok && co >= cg) xv_[r] = *(const f32x4*)(hb + e0 - (size_t)cg * hw); }
-                else if (mode == RPE_CONV_GATE_H) { if (ok) { xv_[r] = *(const f32x4*)(zb + e0); hv_[r] = *(const f32x4*)(hb + e0); } }
+            for (int q = 0; q < RU; ++q) {
+                const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r0 + q;
+                const bool ok = FAST || (pok && co < P.cout);
+                const size_t e0 = (size_t)co * hw + pxo;
+                av[q] = (addb && ok) ? *(const f32x4*)(addb + e0) : zero4;
+                xv[q] = hv[q] = zero4;
+                if (MODE == RPE_CONV_GATE_ZR) { if (FAST ? rtile : (ok && co >= cg)) xv[q] = *(const f32x4*)(hb + e0 - (size_t)cg * hw); }
+                else if (MODE == RPE_CONV_GATE_H) { if (ok) { xv[q] = *(const f32x4*)(zb + e0); hv[q] = *(const f32x4*)(hb + e0); } }
             }
+        };
+        auto finish_block = [&](int n, const f32x4 (&av)[RU], const f32x4 (&xv)[RU], const f32x4 (&hv)[RU]) {
+            const int tb = (n >> 1) / CB, cb = (n >> 1) % CB, r0 = RU * (n & 1);
+            int oy, ox; where(tb, oy, ox);
+            const bool pok = FAST || ((oy < H) & (ox < W));
+            const size_t pxo = (size_t)oy * W + ox;
+            auto st4 = [&](float* p, size_t e, const float (&v)[4]) {
+                if (pok) *(f32x4*)(p + e) = (f32x4){v[0], v[1], v[2], v[3]};
+            };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
-                if (co >= P.cout) continue;
+            for (int q = 0; q < RU; ++q) {
+                const int r = r0 + q, co = co0 + cw * 16 * CB + cb * 16 + 4 * lk + r;
+                if (!FAST && co >= P.cout) continue;
                 float m[8];
 #pragma unroll
                 for (int p = 0; p < 8; ++p) m[p] = acc[p][cb][tb][r];
@@ -308,24 +322,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                     const f32x4 q = *(const f32x4*)&tsc[(li >> 2) * 16 + 4 * (li & 3)];  // (LDS operations of a wave execute in order)
                     v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
                 }
-                const size_t e0 = (size_t)co * hw + (size_t)oy * W + ox;
+                const size_t e0 = (size_t)co * hw + pxo;
                 const float bi = bi_[cb][r];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] + av_[r][i] + bi;
-                if (mode == RPE_CONV_GATE_ZR) {
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + av[q][i] + bi;
+                if (MODE == RPE_CONV_GATE_ZR) {
                     // z = sigmoid(.) -> out (channels < gate_channels);  r = sigmoid(.), r * h -> out2 (the other half)
                     float sg[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sg[i] = sigmoid_f(v[i]);
-                    if (co >= cg) {
+                    if (FAST ? rtile : co >= cg) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) sg[i] *= xv_[r][i];
+                        for (int i = 0; i < 4; ++i) sg[i] *= xv[q][i];
                         st4(out2b, e0 - (size_t)cg * hw, sg);
                     } else st4(outb, e0, sg);
-                } else if (mode == RPE_CONV_GATE_H) {
+                } else if (MODE == RPE_CONV_GATE_H) {
                     // h <- (1 - z) h + z tanh(.)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - xv_[r][i]) * hv_[r][i] + xv_[r][i] * tanh_f(v[i]);
+                    for (int i = 0; i < 4; ++i) v[i] = (1.0f - xv[q][i]) * hv[q][i] + xv[q][i] * tanh_f(v[i]);
                     st4(outb, e0, v);
                 } else {
                     if (mode == RPE_CONV_RELU) {                                  // NaN stays NaN, like torch.relu
@@ -336,7 +350,29 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino1d(W1P P) {
                     if (out2b) st4(out2b, e0, v);
                 }
             }
+        };
+        // unit n + 1's operands are requested BEFORE unit n's arithmetic and stores: the tensors may alias as far as the compiler
+        // knows (h is updated in place), so it keeps loads behind earlier stores -- written block by block, each block waited a
+        // memory round trip behind the previous block's stores, four times per workgroup.  An element is read and written by the
+        // same lane only, so requesting a later block's operands early is safe.
+        f32x4 av_[2][RU], xv_[2][RU], hv_[2][RU];
+        load_block(0, av_[0], xv_[0], hv_[0]);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            if (n + 1 < NB) load_block(n + 1, av_[(n + 1) & 1], xv_[(n + 1) & 1], hv_[(n + 1) & 1]);
+            finish_block(n, av_[n & 1], xv_[n & 1], hv_[n & 1]);
         }
+    };
+    {
+        typedef std::integral_constant<int, RPE_CONV_GATE_ZR> ZR; typedef std::integral_constant<int, RPE_CONV_GATE_H> GH; typedef std::integral_constant<int, -1> RT;
+        typedef std::integral_constant<bool, true> Yes; typedef std::integral_constant<bool, false> No;
+        const bool inside = (y0 + 16 <= H) & (x0 + 16 <= W) & (co0 + TCO <= P.cout);
+        if (mode == RPE_CONV_GATE_ZR) { if (inside && (cg % TCO) == 0) epilogue(ZR{}, Yes{}); else epilogue(ZR{}, No{}); }
+        // (GATE_H in full launches keeps the masked shape: measured at batch 32, the q convolutions are 3-6 % SLOWER with the unmasked one
+        // (272 vs 265 us, 245 vs 235) and 5 % faster at batch 2 -- with two workgroups per CU an epilogue that issues its 64 KB of loads
+        // and stores per wave in one burst starves the other workgroup's DMA ring; alone on a CU it is pure latency.  Same bits.)
+        else if (mode == RPE_CONV_GATE_H) { if (inside && CB == 1) epilogue(GH{}, Yes{}); else epilogue(GH{}, No{}); }
+        else { if (inside) epilogue(RT{}, Yes{}); else epilogue(RT{}, No{}); }
     }
 }
 

@@ -182,6 +182,32 @@ __device__ __forceinline__ void scatter_level0_carry(const float* __restrict__ T
     const int hl = G.h[0], wp = G.wp[0];
     const int x0 = px * 16, y0 = band * 8;
     char* lv = (char*)lvl + (size_t)bz * G.ngroups * hl * ((unsigned)wp * 32);
+    if (!LAST) {
+        // 16 slots: a thread keeps its (piece, slot, row) for all eight groups of the half tile -- which LDS array each of its four
+        // queries comes from, the addresses and the destination are set up once and advance by constants (as one flat index
+        // decomposed per item this loop was ~60 vector instructions per 16-byte piece, a third of the epilogue's)
+        const int half = tid & 1, sl = (tid >> 1) & 15, yy = tid >> 5;
+        const int y = y0 + yy, xs = x0 + sl;
+        if ((y >= hl) | (xs >= wp)) return;
+        const float* src[4]; int step[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * half + e, xx = sl - 7 + k;          // column of this patch; < 0: the previous patch's column 16 + xx
+            src[e] = xx >= 0 ? T + k * TP + yy * 16 + xx : carry + (k * 8 + yy) * 7 + xx + 7;
+            step[e] = xx >= 0 ? 8 * TP : 8 * 8 * 7;
+        }
+        char* dst = lv + (size_t)(((unsigned)(g0 * hl + y) * (unsigned)wp + (unsigned)xs) * 32u + (unsigned)half * 16u);
+        const size_t dstep = (size_t)hl * ((unsigned)wp * 32u);
+        const int ng = G.ngroups - g0 < 8 ? G.ngroups - g0 : 8;
+#pragma unroll 1
+        for (int g = 0; g < ng; ++g) {
+            *(f32x4*)dst = (f32x4){*src[0], *src[1], *src[2], *src[3]};
+            dst += dstep;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) src[e] += step[e];
+        }
+        return;
+    }
 #pragma unroll 1
     for (int u = tid; u < NITEM; u += 256) {
         const int half = u & 1, t = u >> 1;
