@@ -199,13 +199,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     const int v_base = v_ci * RCH + 2 * v_ty * RROW + 2 * v_tx + RCOL0;
     const int srcA = v_base + (v_half ? 2 : 0) * RROW, srcB = v_base + (v_half ? 1 : 2) * RROW, srcC = v_base + (v_half ? 3 : 1) * RROW;
     const float sigma = v_half ? -1.0f : 1.0f;
-    if (PRE) {                                                // (no global loads inside the K loop: hipcc would drain the DMA queue for them)
-        for (int i = tid; i < P.cin; i += 256) {
-            const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
-            float* d = pn_at(i);
-            d[0] = -m * iv; d[1] = iv;
-        }
-    }
     // The transform of step s+1 is written as three slices (patch reads, column pass, row pass + store) placed by the main loop
     float tdA[4], tdB[4], tdC[4], tta[4], ttb[4];
     float2 pn = make_float2(0.0f, 1.0f);
@@ -288,6 +281,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     dma_u(wslice, 0); dma_raw(xsrc, 0); dma_raw(xsrc + (size_t)clamped(1) * rstep, 1);
     dma_u(wslice + (size_t)clamped(1) * wstep, 1); dma_raw(xsrc + (size_t)clamped(2) * rstep, 2);
     dma_u(wslice + (size_t)clamped(2) * wstep, 2);
+    if (PRE) {
+        // (-mean / std, 1 / std) of the input channels -> LDS, requested AFTER the first DMA groups: in front of them (where this block
+        // stood) the workgroup waited one memory round trip for these pairs and then a second one for its first operands -- 15 % of a
+        // 16-step workgroup.  They are the youngest requests, so the compiler's wait for them also covers every DMA above (the counted
+        // wait below is then a no-op).  (No global loads inside the K loop: hipcc would drain the DMA queue for them.)
+        for (int i = tid; i < P.cin; i += 256) {
+            const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
+            float* d = pn_at(i);
+            d[0] = -m * iv; d[1] = iv;
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * 2 * CB + NRAW));                                        // vmcnt(U(1) + raw(2) + U(2) still in flight)
 #ifdef WINO_PHASES
     const unsigned long long phb = __builtin_readcyclecounter();
