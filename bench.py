@@ -95,6 +95,7 @@ def parse_args(argv=None):
     ap.add_argument('--corr-bf16x3', action='store_true',
                     help='EXPERIMENT (reported under its own dtype, never the headline): the correlation build with every f32 product as six bf16 products of an exact 3-way split (RPE_F32X3)')
     ap.add_argument('--no-extras', action='store_true', help='skip the batch-1 latency / tracker / Gauss-Newton lines (and the live PMC traffic passes)')
+    ap.add_argument('--one-stream', action='store_true', help='encoders one after the other on one stream (raft.ENC_STREAMS = False): for kernel-trace profiles whose per-kernel durations must not overlap')
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='do not run the two rocprofv3 --pmc child passes after the timed region; roofline.traffic then comes from profiles/pmc_traffic.json')
     return ap.parse_args(argv)
@@ -147,6 +148,9 @@ def main():
         rccl_ranks = int(ones.item())
 
     import rpe_amd  # noqa: F401  (raises if librpe_hip.so is missing: no fallback)
+    if args.one_stream:
+        from rpe_amd import raft as _raft
+        _raft.ENC_STREAMS = False
     if args.corr_bf16x3:
         from rpe_amd import raft as _raft
         _raft.CORR_BF16X3 = True                        # the labelled experiment (its own dtype string below)
@@ -268,6 +272,7 @@ def run_sequence(args, rank, world, dev, dist):
 def run_batch(args, rank, world, dev, dist):
     import rpe_amd
     from rpe_amd import pose_head, pose_net, synth  # noqa: F401
+    from rpe_amd import raft as raft_mod
 
     H, W, B = args.height, args.width, args.batch
     cfg = synth.model_config(H, W, iters=args.raft_iters, lbgfs_iters=args.solver_iters, solver=args.solver, mixed_precision=args.fp16_features)
@@ -407,12 +412,14 @@ def run_batch(args, rank, world, dev, dist):
     pose, _, depth2, weights, time_flow, stereo_flow2 = out
     conv_steps = 2                                 # diagnostic pass: the same step with every convolution launch bracketed by HIP events
     timing['conv'] = True
+    enc_streams, raft_mod.ENC_STREAMS = raft_mod.ENC_STREAMS, False     # one stream: a launch's duration is its own, not two overlapping launches'
     try:
         for _ in range(conv_steps):
             step()
         torch.cuda.synchronize()
     finally:
         timing['conv'] = False
+        raft_mod.ENC_STREAMS = enc_streams
     info = model.pose_head.problem.last_info.cpu()
     lk_ms = [a.elapsed_time(b) for a, b in lookup_events]
     lk_avg_s = sum(lk_ms) / max(1, len(lk_ms)) / 1e3

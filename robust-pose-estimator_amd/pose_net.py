@@ -47,8 +47,7 @@ class PoseNet(nn.Module):
         a division by a power of two commutes with the rounding of b / -flow.x, so the kernel is handed b / 8).
         ``ret_cache`` additionally returns the encoder outputs of ``imagel`` for reuse by the next ``infer``."""
         n = imagel.shape[0]
-        f = self.flow.encode_features((imagel, imager))
-        cn = self.flow.encode_context(imagel)
+        f, cn = self._encode_both((imagel, imager), imagel)
         flow = self.flow(None, None, upsample=upsample, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
         depth, valid = ops.flow2depth(flow, baseline if upsample else baseline / 8.0)
         if ret_cache:
@@ -93,6 +92,13 @@ class PoseNet(nn.Module):
         return self
 
     @torch.no_grad()
+    def _encode_both(self, feature_images, context_images):
+        """RAFT.encode_both (the two encoders side by side on two streams), or the two calls for a flow module that only has them."""
+        both = getattr(self.flow, 'encode_both', None)
+        if both is not None:
+            return both(feature_images, context_images)
+        return self.flow.encode_features(feature_images), self.flow.encode_context(context_images)
+
     def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None, heads=True):
         """Every stage of infer() before the solve.  ``cache1`` = {'fmap','cnet'} of image1l from the previous call
         (streaming: frame t's image2l is frame t+1's image1l), so only the two new images are encoded."""
@@ -103,16 +109,14 @@ class PoseNet(nn.Module):
         # halves and the feature encoder normalises per sample, so it is encoded once: f = (f1l | f2l | f2r) in ONE encoder batch
         # whose overlapping slices f[:2n], f[n:] ARE the two operand batches of the correlation -- no torch.cat of images or maps
         if cache1 is None:
-            f = self.flow.encode_features((image1l, image2l, image2r))
+            f, cn = self._encode_both((image1l, image2l, image2r), (image1l, image2l))
             f2l = f[n:2 * n]
             fmaps = (f[:2 * n], f[n:])
-            cn = self.flow.encode_context((image1l, image2l))
             c2l = cn[n:]
         else:
-            f = self.flow.encode_features((image2l, image2r))
+            f, c2l = self._encode_both((image2l, image2r), image2l)
             f2l = f[:n]
             fmaps = (torch.cat((cache1['fmap'], f2l), dim=0), f)
-            c2l = self.flow.encode_context(image2l)
             cn = torch.cat((cache1['cnet'], c2l), dim=0)
         flow_predictions, hidden, context = self.flow(None, None, upsample=True, fmaps=fmaps, cnet=cn)
         time_flow = flow_predictions[-1][:n].contiguous()
@@ -168,9 +172,8 @@ class PoseNet(nn.Module):
         c = imagesl.shape[0]
         intrinsics = intrinsics.expand(c, 3, 3).contiguous()
         baseline = baseline.expand(c).contiguous()
-        f = self.flow.encode_features((imagesl, imagesr))                 # (L_0..L_c-1 | R_0..R_c-1)
+        f, cn = self._encode_both((imagesl, imagesr), imagesl)          # f = (L_0..L_c-1 | R_0..R_c-1)
         fl = f[:c]
-        cn = self.flow.encode_context(imagesl)
         if cache0 is None:
             f0, c0 = self.flow.encode_features(image0l), self.flow.encode_context(image0l)
         else:

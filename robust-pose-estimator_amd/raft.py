@@ -39,6 +39,8 @@ CORR_BF16X3 = False      # EXPERIMENT: correlation products as six bf16 products
 # batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
 # launch fills the chip on its own), so it is used for small passes only.
 SIDE_STREAM = True
+ENC_STREAMS = True                                                 # RAFT.encode_both: the context encoder on the side stream beside the feature encoder
+ENC_STREAMS_MIN = 8                                                # ... for at least this many context images (below: the fork / join costs more than it hides)
 SIDE_STREAM_MAX = 8 * 5120                                     # queries per pass (batch * h/8 * w/8) up to which the side stream is used
 
 
@@ -637,6 +639,30 @@ class RAFT(nn.Module):
         """cnet on raw 0..255 images (one batch or a list of batches): (N,256,H/8,W/8) = (tanh(net) | relu(inp)), the initial
         hidden state and the context features of core/RAFT/core/raft.py, activated in the output layer's epilogue."""
         return self.cnet(images, raw255=True, split_act=True)
+
+    @torch.no_grad()
+    def encode_both(self, feature_images, context_images):
+        """(encode_features(feature_images), encode_context(context_images)).  The two encoders share nothing but their input images,
+        so on a GPU the context encoder runs on the side stream beside the feature encoder (ENC_STREAMS): two independent chains of
+        launches fill each other's tails and latencies -- at bench geometry 23.3 -> 23.0 ms for the pair (step 67.65 -> 67.24 ms); not for
+        the one to three images of sequential tracking, where the fork / join costs what it hides (138 vs 136 frames/s with it).
+        Same kernels on the same inputs: identical results."""
+        many = isinstance(context_images, (list, tuple))
+        first = context_images[0] if many else context_images
+        count = sum(t.shape[0] for t in context_images) if many else first.shape[0]
+        if not (ENC_STREAMS and first.is_cuda and count >= ENC_STREAMS_MIN):
+            return self.encode_features(feature_images), self.encode_context(context_images)
+        stream, ev_in, ev_done = self._side_stream(first.device)
+        cur = torch.cuda.current_stream(first.device)
+        ev_in.record(cur)
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev_in)                          # the images (and the weights) are ready on the caller's stream
+            cn = self.encode_context(context_images)
+            ev_done.record(stream)
+        f = self.encode_features(feature_images)
+        cur.wait_event(ev_done)
+        cn.record_stream(cur)                                 # allocated on the side stream, consumed (and freed) on the caller's
+        return f, cn
 
     @torch.no_grad()
     def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None, cnet=None):
