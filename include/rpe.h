@@ -49,7 +49,7 @@ const char *rpe_version(void);
 /* Layout version of this header's structs (rpe_conv_desc, rpe_solve_opts) and signatures: a binding compares it with the
  * RPE_ABI_VERSION it was written against before the first call (the ctypes binding does, robust-pose-estimator_amd/_lib.py).
  * 4: rpe_conv_desc is 200 bytes (stats_tiles), stride-2 statistics are one record per 32 output pixels, rpe_pose_solve_ex. */
-#define RPE_ABI_VERSION 4
+#define RPE_ABI_VERSION 5
 int rpe_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -67,6 +67,12 @@ int rpe_se3_act(const void *T, const void *pts, void *out, int64_t n, int64_t m,
 /* Trajectory chaining of core/pose/pose_estimator.py:90-91 as an inclusive scan over m relative poses:
  * P_k = P_{k-1} * inv(scale(rel_k, s)), P_{-1} = init (7 scalars, may be NULL = identity). f64 or f32.    */
 int rpe_se3_chain(const void *rel, const void *init, void *out, int64_t m, double scale, int dtype, void *stream);
+/* The whole per-frame bookkeeping of PoseEstimator.forward (core/pose/pose_estimator.py:81-91) for m consecutive relative poses:
+ * row k fails when any of its 7 scalars is NaN or any |log(rel_k)| > thr (:81) and is replaced by the identity (:83); then the chain
+ * of rpe_se3_chain.  rel_out (m,7) = the gated relative poses (may be NULL), abs_out (m,7) = the chained absolute poses, ok (m) int32 =
+ * 1 where the row passed (may be NULL).  Same arithmetic as rpe_se3_log / _inv / _mul step by step: bit-identical poses.            */
+int rpe_pose_gate_chain(const void *rel, const void *init, void *rel_out, void *abs_out, int32_t *ok, int64_t m, double scale,
+                        double thr, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Pose layer -- replaces DPoseSE3Head.objective / .solve (core/pose/pose_head.py:12-79) together with

@@ -31,7 +31,7 @@ class ConvDesc(_c.Structure):
                 ('gate_channels', _i), ('stride', _i), ('stats_tiles', _i)]
 
 
-ABI_VERSION = 4            # RPE_ABI_VERSION of include/rpe.h these struct mirrors were written against
+ABI_VERSION = 5            # RPE_ABI_VERSION of include/rpe.h these struct mirrors were written against
 
 
 class SolveOpts(_c.Structure):
@@ -49,6 +49,7 @@ SIGNATURES = {
     'rpe_se3_inv': (_i, [_vp, _vp, _i64, _i, _vp]),
     'rpe_se3_act': (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp]),
     'rpe_se3_chain': (_i, [_vp, _vp, _vp, _i64, _d, _i, _vp]),
+    'rpe_pose_gate_chain': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _i, _vp]),
     'rpe_pose_workspace_bytes': (_sz, [_i, _i, _i]),
     'rpe_pose_reduce': (_i, [_vp] * 10 + [_i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_pose_solve': (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -87,6 +87,18 @@ def se3_chain(rel, scale=1.0, init=None):
     return out
 
 
+def pose_gate_chain(rel, init, scale, thr=0.1):
+    """rpe_pose_gate_chain: PoseEstimator's failure gate and pose chaining for m relative poses (m,7) in one launch.
+    Returns (gated relative poses (m,7), absolute poses (m,7), ok (m,) int32)."""
+    rel = _dev(rel.reshape(-1, 7), None, 'rel')
+    init = _dev(init.reshape(7), rel.dtype, 'init') if init is not None else None
+    rel_out, abs_out = torch.empty_like(rel), torch.empty_like(rel)
+    ok = torch.empty(rel.shape[0], dtype=torch.int32, device=rel.device)
+    check(lib().rpe_pose_gate_chain(ptr(rel), ptr(init), ptr(rel_out), ptr(abs_out), ptr(ok), rel.shape[0], float(scale), float(thr),
+                                    _DT[rel.dtype], stream_ptr()), 'rpe_pose_gate_chain')
+    return rel_out, abs_out, ok
+
+
 # ------------------------------------------------------------------------------------------------- pose layer
 def _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight):
     f32 = torch.float32

@@ -11,6 +11,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import ops
 from .pose_net import PoseNet
 from .se3 import SE3
 
@@ -71,6 +72,7 @@ class PoseEstimator(torch.nn.Module):
         self.config = config
         self.register_buffer('intrinsics', intrinsics.unsqueeze(0).float(), persistent=False)
         self.register_buffer('scale', torch.tensor(1 / config['depth_clipping'][1]), persistent=False)
+        self._inv_scale = float(1 / self.scale)                      # (f32 division, once, on the host: what `1 / self.scale` gives per call in the reference, :90)
         self.register_buffer('baseline', torch.tensor(baseline).unsqueeze(0).float(), persistent=False)
         self._init_pose = SE3.Identity(1) if init_pose is None else init_pose.float()
         self.last_pose = self._init_pose
@@ -99,17 +101,15 @@ class PoseEstimator(torch.nn.Module):
         self.last_frame = self.frame
         self.frame = Frame(limg, rimg, mask=mask)
         rel_pose, ret_frame, flow, weights = self.get_pose_f2f()
-        rel_log = rel_pose.log()
-        if bool(torch.isnan(rel_pose.vec()).any()) or bool((torch.abs(rel_log) > 1.0e-1).any()):     # :81
-            warnings.warn('pose estimation not converged, skip.', RuntimeWarning)
-            rel_pose = SE3.IdentityLike(self.last_pose)
-            self.success = False
-        else:
-            self.success = True
-        self.last_rel_pose = rel_pose
+        # :81-91 in one launch (ops.pose_gate_chain): the gate isnan | |log| > 0.1 -> identity, de-normalisation of the depth scaling and
+        # last_pose <- last_pose * rel^-1, with ONE host synchronisation (the success flag) instead of a dozen element-wise launches and two
+        rel, pose, ok = ops.pose_gate_chain(rel_pose.data.reshape(1, 7), self.last_pose.data, self._inv_scale, 1.0e-1)
+        self.success = bool(ok[0])
+        if not self.success:
+            warnings.warn('pose estimation not converged, skip.', RuntimeWarning)                 # :82
+        self.last_rel_pose = SE3(rel)
         self.last_frame = ret_frame
-        rel_pose = rel_pose.scale(1 / self.scale)                        # :90 de-normalise the depth scaling
-        self.last_pose = self.last_pose * rel_pose.inv()                 # :91 chain transforms
+        self.last_pose = SE3(pose)
         return self.last_pose, None, flow, weights
 
     @torch.no_grad()
@@ -129,11 +129,8 @@ class PoseEstimator(torch.nn.Module):
             prev.img, limgs, rimgs, self.intrinsics, self.baseline * self.scale, depth0=prev.depth * self.scale, mask0=prev.mask,
             masks=masks, stereo_flow0=prev.flow, cache0=self._enc_cache, depth_roundtrip=self.scale)
         self._enc_cache = cache if self.reuse_features else None
-        rel = vec7.reshape(c, 7)
-        log = SE3(rel).log()
-        bad = torch.isnan(rel).any(dim=-1) | (torch.abs(log) > 1.0e-1).any(dim=-1)                   # :81, all frames at once
-        ident = SE3.IdentityLike(SE3(rel)).data
-        rel = torch.where(bad[:, None], ident, rel)
+        rel, poses, ok = ops.pose_gate_chain(vec7.reshape(c, 7), self.last_pose.data, self._inv_scale, 1.0e-1)   # :81-91, every frame
+        bad = ok == 0
         n_bad = int(bad.sum())                                             # the chunk's one host synchronisation
         for _ in range(n_bad):
             warnings.warn('pose estimation not converged, skip.', RuntimeWarning)
@@ -141,15 +138,10 @@ class PoseEstimator(torch.nn.Module):
         self.success = not bool(bad[-1]) if n_bad else True
         self.last_rel_poses = rel
         self.last_rel_pose = SE3(rel[c - 1:])
-        # :90-91 for every frame: last_pose <- last_pose * (rel scaled back to millimetres)^-1, the same three operations per frame
-        poses = []
-        scaled_inv = SE3(rel).scale(1 / self.scale).inv()
-        for i in range(c):
-            self.last_pose = self.last_pose * scaled_inv[i:i + 1]
-            poses.append(self.last_pose.data.reshape(1, 7))
+        self.last_pose = SE3(poses[c - 1:])
         self.last_frame = Frame(limgs[c - 2:c - 1], rimgs[c - 2:c - 1]) if c > 1 else prev      # (only .img of it is ever read again)
         self.frame = Frame(limgs[c - 1:], rimgs[c - 1:], depth=depth2[c - 1:] / self.scale, mask=masks[c - 1:], flow=stereo_flow[c - 1:])
-        return torch.cat(poses), None, flow, weights
+        return poses, None, flow, weights
 
     def get_pose_f2f(self):
         flow = None

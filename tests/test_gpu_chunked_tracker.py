@@ -142,3 +142,34 @@ def test_solve_rows_do_not_depend_on_the_batch_with_partition_rows_1(rpe):
         for i in range(n):
             Ti, vi, li, ii = ops.pose_solve(*[a[i:i + 1].contiguous() for a in args], iters=6, mode=mode)
             assert torch.equal(Ti, T_all[i:i + 1]) and torch.equal(vi, v_all[i:i + 1]) and torch.equal(ii, i_all[i:i + 1])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_gate_chain_kernel_equals_the_step_by_step_bookkeeping(rpe, dtype):
+    """rpe_pose_gate_chain (one launch per frame / chunk) against PoseEstimator.forward's bookkeeping written out with the SE3 operations
+    it replaced (core/pose/pose_estimator.py:81-91): isnan | |log| > 0.1 -> identity, scale, inverse, chain.  Bit for bit, on rows just
+    below / above the threshold in a translation and in a rotation component, a NaN row and ordinary rows."""
+    from rpe_amd import ops
+    from rpe_amd.se3 import SE3
+    g = torch.Generator().manual_seed(5)
+    xi = torch.randn(12, 6, generator=g, dtype=torch.float64) * torch.tensor([0.02, 0.02, 0.02, 0.01, 0.01, 0.01], dtype=torch.float64)
+    xi[2, 0], xi[3, 0] = 0.0999, 0.1001
+    xi[4, 4], xi[5, 4] = -0.0999, -0.1001
+    xi[9] = 0.0
+    rel = SE3.exp(xi.to(dtype).cuda()).data.clone()
+    rel[7, 5] = float('nan')
+    init = SE3.exp((torch.randn(1, 6, generator=g, dtype=torch.float64) * 0.3).to(dtype).cuda()).data
+    s = float(1 / torch.tensor(1 / 250.0))
+    got_rel, got_abs, ok = ops.pose_gate_chain(rel, init, s, 1.0e-1)
+    pose, want_rel, want_abs, want_ok = SE3(init), [], [], []
+    for k in range(rel.shape[0]):
+        r = SE3(rel[k:k + 1])
+        bad = bool(torch.isnan(r.vec()).any()) or bool((torch.abs(r.log()) > 1.0e-1).any())
+        if bad:
+            r = SE3.IdentityLike(pose)
+        want_ok.append(0 if bad else 1)
+        want_rel.append(r.data)
+        pose = pose * r.scale(s).inv()
+        want_abs.append(pose.data)
+    assert ok.tolist() == want_ok and want_ok == [1, 1, 1, 0, 1, 0, 1, 0, 1, 1, 1, 1]
+    assert torch.equal(got_rel, torch.cat(want_rel)) and torch.equal(got_abs, torch.cat(want_abs))
