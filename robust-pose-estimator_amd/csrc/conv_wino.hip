@@ -445,6 +445,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     }
 #endif
 
+#ifdef WINO_NO_EPI
+    {   // ablation (tools/build_variant.sh ... -DWINO_NO_EPI): no output transform, no stores -- what the epilogue costs a launch
+        float sacc = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc += acc[p][cb][r];
+        if (sacc == 12345.678f) P.out[0] = sacc;
+        return;
+    }
+#endif
     // ---- epilogue.  D layout of the 16x16 MFMA: column (tile) = lane % 16, row (channel) = 4 * (lane / 16) + r.
     // Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; then scale / bias, moments, ReLU, residual, and the store(s) into the channel slices.
     const int tl = tw * 16 + li, ty = tl >> 3, tx = tl & 7;
