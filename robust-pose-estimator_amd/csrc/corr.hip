@@ -331,14 +331,20 @@ __device__ __forceinline__ void cb_dma2(const float* base, unsigned v0, unsigned
 #ifndef CB_CARRY
 #define CB_CARRY 1
 #endif
-__global__ __launch_bounds__(256, CB_CARRY ? 2 : 3) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
+// CARRY = false: one workgroup per (band, patch) instead of one per band -- for launches whose band walk would leave most of the chip
+// on a second, nearly empty round (sequential tracking: 2 pairs = 640 band workgroups on 512 slots; 3 200 patch workgroups fill every
+// round).  No carry: level 0's skewed edge slots are completed by the neighbouring patch's workgroup, as levels 1-3's are (more
+// partial-sector writes, irrelevant at this size); 48 KB of LDS, three workgroups per CU.  The values written are the same.
+template <bool CARRY>
+__global__ __launch_bounds__(256, CARRY ? 2 : 3) void k_corr_build(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ pyr,
                                                     int K, float scale, PyrGeom G) {
     // main loop: As[3][BK][BM] | Bs[3][BK][BN] (48 KB); epilogue (aliased): T[64][TP] | T1[64][33] | T2[64][9] | T3[64][3]
     __shared__ __attribute__((aligned(16))) float smem[SMEM_MAIN > SMEM_FLOATS ? SMEM_MAIN : SMEM_FLOATS];
-    __shared__ float carry_s[CB_CARRY ? 2 * CARRY_HALF : 1];                 // level 0: the previous patch's last seven columns (28 KB)
-    float* carry = CB_CARRY ? carry_s : nullptr;
-    if (CB_CARRY) for (int i = threadIdx.x; i < 2 * CARRY_HALF; i += 256) carry_s[i] = 0.0f;   // (published by the loop's first barrier)
-    const int bz = blockIdx.z, band = blockIdx.x;
+    __shared__ float carry_s[CARRY ? 2 * CARRY_HALF : 1];                    // level 0: the previous patch's last seven columns (28 KB)
+    float* carry = CARRY ? carry_s : nullptr;
+    if (CARRY) for (int i = threadIdx.x; i < 2 * CARRY_HALF; i += 256) carry_s[i] = 0.0f;      // (published by the loop's first barrier)
+    const int bz = blockIdx.z, band = CARRY ? blockIdx.x : blockIdx.x / G.npx;
+    const int px_lo = CARRY ? 0 : blockIdx.x % G.npx, px_hi = CARRY ? G.npx : px_lo + 1;
     const int m0 = blockIdx.y * BM;
     const int M = G.mp, N = G.np;
     const float* Ab = A + (size_t)bz * K * M;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, CB_CARRY ? 2 : 3) void k_corr_build(const floa
     const float* a_l = smem + wm * 64 + l31 + lh * 128;
     const float* b_l = smem + 3 * CB_TILE + wn * 64 + l31 + lh * 128;
 
-    for (int px = 0; px < G.npx; ++px) {
+    for (int px = px_lo; px < px_hi; ++px) {
         const int n0 = (band * G.npx + px) * BN;
         const float* bsrc = Bb + n0 - CB_BIAS / 4;
         f32x16 acc[2][2];
@@ -992,7 +998,15 @@ extern "C" int rpe_corr_build_ex(const float* fmap1, const float* fmap2, int b, 
     const bool a_in_place = (w8 % 8 == 0) && G.mp == h8 * w8 && (((uintptr_t)fmap1) & 15) == 0;
     if (!a_in_place) hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.mp, 256), b * c), dim3(256), 0, s, fmap1, Ap, h8, w8, 0, G.gx, G.npx, G.mp);
     hipLaunchKernelGGL(k_permute_fmap, dim3(ceil_div(G.np, 256), b * c), dim3(256), 0, s, fmap2, Bp, h8, w8, 1, G.gx, G.npx, G.np);
-    hipLaunchKernelGGL(k_corr_build, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, a_in_place ? fmap1 : (const float*)Ap, (const float*)Bp, pyr, c,
+#ifndef CB_SMALL_WG
+#define CB_SMALL_WG 4096                          /* band workgroups below which the launch is split per patch (tools/build_variant.sh -DCB_SMALL_WG=0: never): 2 pairs 412 -> 366 us, 6 pairs 1058 -> 1030, 12 pairs 1895 -> 1862, 32 pairs equal (the carry then saves a quarter of the writes) */
+#endif
+    if (!CB_CARRY || (long long)G.nbands * (G.mp / BM) * b < CB_SMALL_WG) {   // few band workgroups: whole rounds of patch workgroups instead of a nearly empty last round of band walks
+        hipLaunchKernelGGL(k_corr_build<false>, dim3(G.nbands * G.npx, G.mp / BM, b), dim3(256), 0, s, a_in_place ? fmap1 : (const float*)Ap, (const float*)Bp, pyr, c,
+                           1.0f / sqrtf((float)c), G);
+        return rpe_check_launch();
+    }
+    hipLaunchKernelGGL(k_corr_build<true>, dim3(G.nbands, G.mp / BM, b), dim3(256), 0, s, a_in_place ? fmap1 : (const float*)Ap, (const float*)Bp, pyr, c,
                        1.0f / sqrtf((float)c), G);
     return rpe_check_launch();
 }
