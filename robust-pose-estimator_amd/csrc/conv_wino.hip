@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     if (EPI != 0) asm volatile("" :: "s"(P.scale), "s"(P.res), "s"(P.rbs), "s"(P.stats), "s"(P.pre));
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef WINO_PHASES
-    const unsigned long long ph0 = __builtin_readcyclecounter();
+    const unsigned long long ph0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();     // (shader cycles | 100 MHz reference ticks)
 #endif
 #ifdef WINO_PAD
     __shared__ float padlds[WINO_PAD];
@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoP P) {
     if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == gridDim.z / 2 && tid == 0) {
         const unsigned long long ph3 = __builtin_readcyclecounter();
         g_wino_timing[0] = ph1 - ph0; g_wino_timing[1] = ph2 - ph1; g_wino_timing[2] = ph3 - ph2; g_wino_timing[3] = pha - ph0; g_wino_timing[4] = phb - pha; g_wino_timing[5] = ph1 - phb; g_wino_timing[6] = 1;
+        g_wino_timing[7] = __builtin_amdgcn_s_memrealtime() - rt0;      // ticks of the 100 MHz reference over the workgroup's life: the shader clock it ran at
     }
 #endif
 }
