@@ -388,3 +388,22 @@ def test_bf16x3_build_is_f32_equivalent(rpe):
     assert L.rpe_corr_pyramid_bytes_ex(b, h8, w8, 4, 3) > L.rpe_corr_pyramid_bytes(b, h8, w8, 4)
     with pytest.raises(rpe.RpeError):
         ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda(), bf16x3=True)
+
+
+def test_build_launch_classes_agree_bitwise(rpe):
+    """k_corr_build walks a band's patches in one workgroup (level 0 through the LDS carry) or, for launches of fewer than 4096 band
+    workgroups, takes one workgroup per patch: the pyramid of a pair must not depend on how many pairs share the launch (the chunked
+    sequence tracker builds 32 pairs at once, the frame-at-a-time one 2).  Every level, bit for bit, at bench geometry."""
+    from rpe_amd import ops
+    torch.manual_seed(3)
+    b, c, h8, w8 = 16, 256, 64, 80                                     # 16 pairs: 5120 band workgroups -> the walk; 2 pairs -> per patch
+    f1, f2 = torch.randn(b, c, h8, w8, device='cuda'), torch.randn(b, c, h8, w8, device='cuda')
+    big = ops.CorrPyramid(b, h8, w8, device='cuda'); big.build(f1, f2)
+    small = ops.CorrPyramid(2, h8, w8, device='cuda'); small.build(f1[5:7].contiguous(), f2[5:7].contiguous())
+    for level in range(4):
+        lb, ls = big.export_level(level), small.export_level(level)   # (pairs * queries, h_l, w_l)
+        assert torch.equal(lb.reshape(b, h8 * w8, *lb.shape[1:])[5:7], ls.reshape(2, h8 * w8, *ls.shape[1:]))
+    # and the lookups read the same values through both layouts' edges
+    coords = torch.rand(2, 2, h8, w8, device='cuda') * torch.tensor([w8, h8], device='cuda').view(1, 2, 1, 1)
+    cb = torch.zeros(b, 2, h8, w8, device='cuda'); cb[5:7] = coords
+    assert torch.equal(big.lookup(cb)[5:7], small.lookup(coords))

@@ -350,3 +350,25 @@ def test_whole_infer_is_graph_capturable(models):
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.data, eager)
+
+
+@pytest.mark.gpu
+def test_encoders_side_by_side_equal_one_after_the_other(rpe):
+    """RAFT.encode_both runs the context encoder on a side stream beside the feature encoder (batches of >= 8 context images): the
+    same kernels on the same inputs, so both outputs must equal the one-stream ones bit for bit -- also when the call is repeated
+    (allocator reuse across the two streams) and when the result is consumed right away on the caller's stream."""
+    from rpe_amd import raft as raft_mod, synth, pose_net
+    torch.manual_seed(2)
+    model = synth.init_synthetic_weights(pose_net.PoseNet(synth.model_config(128, 160)), seed=7).eval().cuda()
+    imgs = [torch.rand(8, 3, 128, 160, device='cuda') * 255 for _ in range(3)]
+    assert raft_mod.ENC_STREAMS and raft_mod.ENC_STREAMS_MIN <= 16
+    keep, raft_mod.ENC_STREAMS = raft_mod.ENC_STREAMS, False
+    try:
+        f0, c0 = model.flow.encode_both(imgs, imgs[:2])
+    finally:
+        raft_mod.ENC_STREAMS = keep
+    for _ in range(3):
+        f1, c1 = model.flow.encode_both(imgs, imgs[:2])
+        s = (f1.sum() + c1.sum()).item()                                # consumed at once on the caller's stream
+        assert torch.equal(f1, f0) and torch.equal(c1, c0) and s == s
+        del f1, c1
