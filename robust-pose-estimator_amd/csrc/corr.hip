@@ -656,7 +656,7 @@ __device__ __forceinline__ void make_taps(float c, int size, TapAxis& T) {
 }
 
 #ifndef LK_WAVES
-#define LK_WAVES 4
+#define LK_WAVES 2
 #endif
 #ifndef LK_NT
 #define LK_NT 5                                // bit 0: non-temporal loads of the pyramid, bit 1: non-temporal stores of the output,
