@@ -385,7 +385,9 @@ int rpe_instnorm_apply(const float *x, const float *partials, int tiles, int b, 
  * residual block of fnet then reads the stem's raw output twice (as input through `pre_norm`, as shortcut through this) and the
  * stem's normalised output is never written (BasicEncoder.forward: relu1(norm1(conv1 x)) -> layer1, core/RAFT/core/extractor.py).
  * relu: bit 0 = ReLU on y (as above); bit 1 = the raw residual is normalised WITHOUT a ReLU -- the shortcut of a stride-2 ResidualBlock,
- * norm3(conv1x1 x) (extractor.py), whose normalised output then never exists as a tensor either. */
+ * norm3(conv1x1 x) (extractor.py), whose normalised output then never exists as a tensor either.
+ * tiles == 0: `partials` is not records but the (b,c,2) (mean, 1/sqrt(var + eps)) pairs rpe_instnorm_finalize made of them (eps is
+ * then unused): the pass is a pure stream, several workgroups per plane -- the faster form behind large maps. */
 int rpe_instnorm_apply_ex(const float *x, const float *partials, int tiles, int b, int c, int hw, float eps, int relu,
                           const float *residual, const float *residual_mean_inv, float *out, void *stream);
 /* mean_inv (b,c,2) = (mean, 1/sqrt(var + eps)) of each plane from the same partial sums: the `pre_norm` input of the

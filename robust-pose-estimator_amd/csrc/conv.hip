@@ -587,6 +587,10 @@ __global__ __launch_bounds__(256) void k_instnorm_finalize_tm(const float* __res
     const float* pp = partials + ((size_t)b * tiles * C + (ok ? c : 0)) * 3;
     const size_t ts = (size_t)3 * C;
     auto tree = [&](double (*v)[4]) {                         // v[0][cl] <- sum over the 64 slices, pairwise, fixed order
+#ifdef FIN_NOTREE
+        __syncthreads();
+        return;
+#endif
 #pragma unroll
         for (int h = 32; h >= 1; h >>= 1) {
             __syncthreads();
@@ -594,14 +598,42 @@ __global__ __launch_bounds__(256) void k_instnorm_finalize_tm(const float* __res
         }
         __syncthreads();
     };
+    // a thread's records (every 64th tile) are requested at once and kept for the second pass: as two loops of load - accumulate the
+    // launch was two chains of ten dependent memory round trips (58 us behind a 256 x 320 layer)
+    constexpr int RMAX = 20;                               // (1 280 records per plane behind a 256 x 320 layer = 20 per thread)
+    float rn[RMAX], rm[RMAX], rq[RMAX];
+    const bool held = tiles <= 64 * RMAX;
+    if (held) {
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) {
+            const int t = sl + 64 * j;
+            const float* r = pp + ts * (size_t)(t < tiles ? t : 0);
+#ifdef FIN_NOLOAD
+            const float v0 = 128.0f, v1 = 0.5f + 0.001f * t, v2 = 3.0f;
+#else
+            const float v0 = r[0], v1 = r[1], v2 = r[2];
+#endif
+            rn[j] = t < tiles ? v0 : 0.0f; rm[j] = v1; rq[j] = v2;
+        }
+    }
     double n = 0.0, a = 0.0;
-    for (int t = sl; t < tiles; t += 64) { const double nt = (double)pp[ts * t]; n += nt; a += nt * (double)pp[ts * t + 1]; }
+    if (held) {
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) if (sl + 64 * j < tiles) { const double nt = (double)rn[j]; n += nt; a += nt * (double)rm[j]; }
+    } else {
+        for (int t = sl; t < tiles; t += 64) { const double nt = (double)pp[ts * t]; n += nt; a += nt * (double)pp[ts * t + 1]; }
+    }
     sh[0][sl][cl] = n; sh[1][sl][cl] = a;
     tree(sh[0]); tree(sh[1]);
     n = sh[0][0][cl]; a = sh[1][0][cl];
     const double mean = a / n;
     double q = 0.0;
-    for (int t = sl; t < tiles; t += 64) { const double d = (double)pp[ts * t + 1] - mean; q += (double)pp[ts * t + 2] + (double)pp[ts * t] * d * d; }
+    if (held) {
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) if (sl + 64 * j < tiles) { const double d = (double)rm[j] - mean; q += (double)rq[j] + (double)rn[j] * d * d; }
+    } else {
+        for (int t = sl; t < tiles; t += 64) { const double d = (double)pp[ts * t + 1] - mean; q += (double)pp[ts * t + 2] + (double)pp[ts * t] * d * d; }
+    }
     __syncthreads();
     sh[0][sl][cl] = q;
     tree(sh[0]);
@@ -620,12 +652,20 @@ __global__ __launch_bounds__(256) void k_instnorm_finalize_tm(const float* __res
 // convolution and relu((r - mean) * inv) is applied to it here (the stem's normalised output never exists as a tensor).
 __global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict__ x, const float* __restrict__ partials, int tiles, int C, int hw,
                                                         float eps, int relu, const float* __restrict__ residual, const float* __restrict__ res_mi,
-                                                        float* __restrict__ out) {
-    const int plane = blockIdx.x;
+                                                        float* __restrict__ out, int split) {
+    // tiles == 0: ``partials`` = (b, C, 2) (mean, 1/std) pairs of rpe_instnorm_finalize, and ``split`` workgroups share a plane, consecutive
+    // workgroups taking consecutive 16-20 KB slices of memory.  (With the records merged here -- 640 twelve-byte records per plane behind
+    // a 256 x 320 Winograd layer, one 64-byte sector each, twice -- every workgroup began with ~10 us of dependent loads: 654 us per
+    // layer-1 launch against 572 with the pairs given and 530 with them given and 16 workgroups per plane.)
+    const int plane = blockIdx.x / split, part = blockIdx.x % split;
     __shared__ double sh[8];
-    double dmean, dvar;
-    plane_moments(partials, tiles, C, plane, 256, sh, dmean, dvar);
-    const float mean = (float)dmean, inv = (float)(1.0 / sqrt(dvar + (double)eps));
+    float mean, inv;
+    if (tiles == 0) { mean = partials[(size_t)plane * 2]; inv = partials[(size_t)plane * 2 + 1]; }
+    else {
+        double dmean, dvar;
+        plane_moments(partials, tiles, C, plane, 256, sh, dmean, dvar);
+        mean = (float)dmean; inv = (float)(1.0 / sqrt(dvar + (double)eps));
+    }
     const float4* xp = (const float4*)(x + (size_t)plane * hw);
     const float4* rp = residual ? (const float4*)(residual + (size_t)plane * hw) : nullptr;
     float4* op = (float4*)(out + (size_t)plane * hw);
@@ -650,8 +690,10 @@ __global__ __launch_bounds__(256) void k_instnorm_apply(const float* __restrict_
 #define INA_NT 3                                /* bit 0: loads, bit 1: stores */
 #endif
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int n4 = hw >> 2;
-    int i = threadIdx.x;
+    const int n4all = hw >> 2;
+    const int per = ((n4all + split - 1) / split + 3) & ~3;                   // this workgroup's slice of the plane (whole 64-byte pieces)
+    const int n4 = (part + 1) * per < n4all ? (part + 1) * per : n4all;
+    int i = part * per + threadIdx.x;
     for (; i + (INA_UNROLL - 1) * (int)blockDim.x < n4; i += INA_UNROLL * blockDim.x) {
         f4 v[INA_UNROLL], r[INA_UNROLL];
 #pragma unroll
@@ -794,10 +836,12 @@ extern "C" int rpe_conv_stats_tiles_batch(int cout, int h, int w, int stride, in
 
 extern "C" int rpe_instnorm_apply_ex(const float* x, const float* partials, int tiles, int b, int c, int hw, float eps, int relu,
                                      const float* residual, const float* residual_mean_inv, float* out, void* stream) {
-    if (!x || !partials || !out || tiles == 0 || b <= 0 || c <= 0 || hw <= 0 || (residual_mean_inv && !residual)) return RPE_E_BADARG;
+    if (!x || !partials || !out || b <= 0 || c <= 0 || hw <= 0 || (residual_mean_inv && !residual)) return RPE_E_BADARG;
     if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, c, hw, eps, relu, residual,
-                       residual_mean_inv, out);
+    int split = 1;                                   // tiles == 0 (moments given): slices of >= 16 KB, at most 16 per plane
+    if (tiles == 0) while (split < 16 && (long long)hw * 4 / (split * 2) >= 16384) split *= 2;
+    hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c * split), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, c, hw, eps, relu, residual,
+                       residual_mean_inv, out, split);
     return rpe_check_launch();
 }
 

@@ -743,11 +743,18 @@ def instnorm_finalize(stats, hw, eps=1e-5, channels=None):
 
 def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None, residual_norm=None, residual_relu=True):
     """Instance norm of x (b,c,h,w) from the partial sums of conv_fused(..., stats=stats): one read + one write pass.
+    ``stats`` may also be the (b,c,2) result of instnorm_finalize on those sums (``eps`` is then already in it): the pass is then a
+    pure stream with several workgroups per plane, the faster form behind large maps (the records are merged once, not per workgroup).
     ``residual_norm`` (b,c,2) from instnorm_finalize: the residual is a RAW convolution output, normalised (+ ReLU'd unless
     ``residual_relu=False``: a stride-2 block's shortcut has none) on the fly."""
     _nchw(x, 'x')
     b, c, hh, ww = x.shape
-    t, tiles = _stats_layout(stats, b, c, 'instnorm_apply')
+    if isinstance(stats, torch.Tensor) and stats.dim() == 3:              # (mean, 1/std) pairs of instnorm_finalize: a pure streaming pass
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.is_contiguous() and tuple(stats.shape) == (b, c, 2)):
+            raise _lib.RpeError(f'instnorm_apply: precomputed moments must be a contiguous float32 ({b},{c},2) GPU tensor (instnorm_finalize)')
+        t, tiles = stats, 0
+    else:
+        t, tiles = _stats_layout(stats, b, c, 'instnorm_apply')
     if residual is not None and _nchw(residual, 'residual').shape != x.shape:
         raise _lib.RpeError('instnorm_apply: residual must have the shape of x')
     if residual_norm is not None and (residual is None or not (residual_norm.is_cuda and residual_norm.dtype == torch.float32

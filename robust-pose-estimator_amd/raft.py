@@ -116,6 +116,8 @@ class ResidualBlock(nn.Module):
             else:
                 stats2 = ops.conv_stats_buffer(b, self.conv2.out_channels, ho, wo, x.device)
                 ops.conv_fused(raw1, _packed(self.conv2), ops.CONV_LINEAR, raw2, bias=self.conv2.bias.detach(), stats=stats2, pre_norm=mi)
+            if isinstance(stats2, ops.TileMajorStats):            # merge the Winograd kernel's records once (a small launch), then stream
+                stats2 = ops.instnorm_finalize(stats2, ho * wo, eps=self.norm2.eps, channels=self.conv2.out_channels)
             return ops.instnorm_apply(raw2, stats2, eps=self.norm2.eps, relu=True, residual=x, residual_norm=x_norm, residual_relu=res_relu)
         y = conv_norm_act(self.conv1, self.norm1, x, relu=True)
         if self.downsample is not None:

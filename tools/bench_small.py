@@ -19,5 +19,8 @@ st = ops.conv_wino_stats_buffer(nb, c, hh, ww, dev)
 ops.conv_wino(raw, ops.PackedWino(wt, None), ops.CONV_LINEAR, out, bias=torch.zeros(c, device=dev), stats=st)
 med, mn = timeit(lambda: ops.instnorm_apply(raw, st, relu=True, residual=res, out=out), 10)
 print(f'instnorm_apply (48 x 64 x 256 x 320, residual): {med:7.1f} us (min {mn:.1f})  {3 * raw.numel() * 4 / med / 1e3:7.1f} GB/s')
+mi = ops.instnorm_finalize(st, hh * ww, channels=c)
+med, mn = timeit(lambda: ops.instnorm_apply(raw, mi, relu=True, residual=res, out=out), 10)
+print(f'instnorm_apply with the moments given (finalize first; 16 workgroups per plane): {med:7.1f} us (min {mn:.1f})  {3 * raw.numel() * 4 / med / 1e3:7.1f} GB/s')
 med, mn = timeit(lambda: ops.instnorm_finalize(st, hh * ww, channels=c), 20)
 print(f'instnorm_finalize (tile-major records of 48 x 64 x 256 x 320): {med:7.1f} us (min {mn:.1f})')
