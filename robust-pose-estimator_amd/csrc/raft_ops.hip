@@ -321,7 +321,11 @@ __global__ __launch_bounds__(64 * TO2_WAVES) void k_conv3x3_to2_x4(const float* 
                 }
         }
     };
-    constexpr int UN = 4;                                            // channels whose loads are issued before any is used:
+#ifndef TO2_UN
+#define TO2_UN 2                                /* 2: 78 registers, three 8-wave workgroups per CU -- all 640 workgroups of a 32-pair launch are resident at once
+                                                   (4: 113 registers, two per CU and a second, quarter-full round: 60.5 vs 54 us; 6 and 8: 83-90 us) */
+#endif
+    constexpr int UN = TO2_UN;                                       // channels whose loads are issued before any is used:
     int c = c_lo;                                                    // the loop is latency-bound
     for (; c + UN <= c_hi; c += UN) {
         float4 m[UN][3]; float ed[UN][3];
