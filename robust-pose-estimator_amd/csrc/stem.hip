@@ -242,7 +242,10 @@ extern "C" int rpe_stem_conv(const float* image, int b, int cin, int h, int w, i
     // (bench: 15 360 stem patches; one frame of sequential tracking: 640)
     const long long patches = (long long)rpe_stem_tiles(h, w, stride) * (cout / 64) * b;
     P.snp = patches >= 5 * 2048 ? 5 : patches >= 2 * 2048 ? 2 : 1;
-    if (patches < 256) {                           // fewer workgroups than CUs: 32-channel workgroups (same arithmetic, bit-identical)
+#ifndef STEM_SMALL_PATCHES
+#define STEM_SMALL_PATCHES 256
+#endif
+    if (patches < STEM_SMALL_PATCHES) {            // fewer workgroups than CUs: 32-channel workgroups (same arithmetic, bit-identical)
         dim3 g1(rpe_stem_tiles(h, w, stride), cout / 32, b);
         if (cin == 3) hipLaunchKernelGGL((k_stem7x7<3, 2, 1>), g1, dim3(256), 0, (hipStream_t)stream, P);
         else hipLaunchKernelGGL((k_stem7x7<2, 1, 1>), g1, dim3(256), 0, (hipStream_t)stream, P);
