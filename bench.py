@@ -540,23 +540,24 @@ def lookup_rounds(pyr, coords):
 def lookup_realistic(pyr, out, B, H, W, dev):
     """The lookup kernel on coordinates a TRAINED network would produce: the ground-truth temporal flow (first B pairs) and stereo
     flow (last B pairs: disparities 8..60 px with depth edges) of seeded synthetic scenes with foreground occluders
-    (synth.ground_truth_flows), sampled at the 1/8 grid's cell centres.  Same pyramid, same launch geometry, HIP events over 30 launches."""
+    (synth.ground_truth_flows), sampled at the 1/8 grid's cell centres.  Same pyramid, same launch geometry, median of 60 launches timed by HIP events."""
     from rpe_amd import synth
     tf, sf = synth.ground_truth_flows(seed=777, n=B, h=H, w=W)
     flow8 = torch.cat((tf, sf))[:, :, 4::8, 4::8].contiguous() / 8.0
     h8, w8 = H // 8, W // 8
     ys, xs = torch.meshgrid(torch.arange(h8, dtype=torch.float32), torch.arange(w8, dtype=torch.float32), indexing='ij')
     coords = (torch.stack((xs, ys))[None] + flow8).contiguous().to(dev)
-    for _ in range(3):
+    # The scenes above are made on the host (seconds): the GPU has dropped to its idle clocks meanwhile, and a window of 30 launches (3 ms)
+    # right after it once measured 313 us per launch.  ~40 ms of the same launches first, then the MEDIAN of 60 individually timed ones.
+    for _ in range(400):
         pyr.lookup(coords, out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 30
-    e0.record()
-    for _ in range(reps):
-        pyr.lookup(coords, out)
-    e1.record()
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / reps / 1e3
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+    for a, b in ev:
+        a.record(); pyr.lookup(coords, out); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    t = ts[len(ts) // 2] / 1e3
     alg = lookup_algorithmic_bytes(2 * B, h8, w8)
     d = flow8[B:, 0]
     return {'kernel': 'k_corr_lookup', 'bound': 'hbm', 'achieved': alg / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
