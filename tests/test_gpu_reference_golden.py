@@ -148,6 +148,31 @@ def test_tracker_matches_reference(case):
         assert float((_sub(est.frame.depth).cpu() - g['depth_last_sub']).abs().median()) <= 1e-3
 
 
+def test_chunked_tracker_matches_reference(case):
+    """The same reference run (core/pose/pose_estimator.py on three frames, tests/golden/tracker.npz) through forward_chunk: frame 0 by
+    forward, frames 1 and 2 as ONE pass of PoseNet.infer_chunk -- the reference's own poses, masks and depth, not only the bits of the
+    frame-at-a-time route."""
+    model, _, _, synth = case
+    from rpe_amd import pose_estimator
+    g = load_golden('tracker.npz')
+    frames, K, bf = osynth.tracker_case(synth)
+    cfg = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=8, conf_weighing=True)
+    est = pose_estimator.PoseEstimator(cfg, K, bf, model, (W, H)).cuda()
+    l0, r0, m0 = frames[0]
+    P0, _, _, _ = est(l0.cuda(), r0.cuda(), m0.clone().cuda())
+    assert float((P0.data.cpu().reshape(7) - g['abs_poses'][0]).abs().max()) <= 2e-3
+    ls, rs = torch.cat([f[0] for f in frames[1:]]).cuda(), torch.cat([f[1] for f in frames[1:]]).cuda()
+    ms = torch.cat([f[2] for f in frames[1:]]).clone().cuda()
+    poses, _, _, _ = est.forward_chunk(ls, rs, ms)
+    for i in range(1, len(frames)):
+        d = float((poses[i - 1].cpu() - g['abs_poses'][i]).abs().max())
+        print(f'frame {i} (chunked): abs pose diff {d:.2e} mm')
+        assert d <= 2e-3
+        assert int((ms[i - 1:i].cpu() != _unpack(g['masks'][i], frames[i][2].shape)).sum()) <= 50
+    assert bool(est.successes.all())
+    assert float((_sub(est.frame.depth).cpu() - g['depth_last_sub']).abs().median()) <= 1e-3
+
+
 class _Scripted(torch.nn.Module):
     """Prescribed relative poses in place of PoseNet (as in the generator), with this package's infer() signature."""
 
