@@ -499,7 +499,7 @@ def live_lookup_traffic(args):
                    '--width', str(args.width), '--raft-iters', str(args.raft_iters), '--solver', args.solver, '--solver-iters', str(args.solver_iters)]
             if args.fp16_features:
                 cmd.append('--fp16-features')
-            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
                 return None
             acc = {'k_corr_lookup': [], 'k_pose_reduce': []}
