@@ -155,7 +155,14 @@ def check(status, what):
         raise RpeError(f'{what} failed with {_ERR.get(status, status)}')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
+    """torch's current HIP stream of the current device as a void*.  (The raw accessor is ~10x cheaper than building a
+    torch.cuda.Stream object per launch -- a frame of sequential tracking is ~330 launches.)"""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -424,7 +424,8 @@ class BasicUpdateBlock(nn.Module):
             `inp` (128 ch, identical in every GRU iteration).
         Returns dict name -> (w_var, w_ctx, bias) for 'zr1', 'q1', 'zr2', 'q2'."""
         g = self.gru
-        key = tuple(p._version for p in g.parameters()) + tuple(p.data_ptr() for p in g.parameters())
+        gp = [t for m in (g.convz1, g.convr1, g.convq1, g.convz2, g.convr2, g.convq2) for t in (m.weight, m.bias)]
+        key = tuple(p._version for p in gp) + tuple(p.data_ptr() for p in gp)
         if self._stacked is None or self._stacked[0] != key:
             c = self.hidden_dim
 
@@ -459,8 +460,9 @@ class BasicUpdateBlock(nn.Module):
         e, fh = self.encoder, self.flow_head
         mods = (e.convc1, e.convc2, e.convf2, e.conv, fh.conv1)
         keymods = mods + (e.convf1,)
-        key = tuple(p._version for m in keymods for p in m.parameters()) + tuple(p.data_ptr() for m in keymods for p in m.parameters()) + \
-            (id(self.gate_weights()),)
+        # (the convolutions' own weight / bias attributes: walking module.parameters() costs ~100 us a call, and this runs 26 times a frame)
+        ps = [t for m in keymods for t in (m.weight, m.bias) if t is not None]
+        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (id(self.gate_weights()),)
         if getattr(self, '_packed', None) is None or self._packed[0] != key:
             W = self.gate_weights()
             P = {n: ops.PackedConv(m.weight, m.bias) for n, m in zip(('convc1', 'convc2', 'convf2', 'conv', 'fh1'), mods)}
@@ -549,7 +551,8 @@ class BasicUpdateBlock(nn.Module):
         """.25 * mask(net) (upstream scales the mask to balance gradients).  The 3x3 layer + ReLU runs on the Winograd kernel, the
         factor is folded into the 1x1 layer's parameters (a power of two: bit-identical to scaling the result)."""
         c1, c2 = self.mask[0], self.mask[2]
-        key = tuple(p._version for p in self.mask.parameters()) + tuple(p.data_ptr() for p in self.mask.parameters())
+        mp = (c1.weight, c1.bias, c2.weight, c2.bias)
+        key = tuple(p._version for p in mp) + tuple(p.data_ptr() for p in mp)
         cached = getattr(self, '_mask_packed', None)
         if cached is None or cached[0] != key:
             pw = ops.PackedWino(c1.weight, c1.bias) if WINOGRAD and c1.weight.is_cuda else None
