@@ -718,6 +718,35 @@ def test_instnorm_apply_with_a_raw_residual(rpe):
         ops.instnorm_apply(raw.clone(), stats, residual_norm=res_mi)              # a norm without a residual
 
 
+@pytest.mark.parametrize('b,c,h,w', [(3, 64, 256, 320), (2, 96, 128, 160), (2, 128, 64, 80), (1, 64, 44, 52)])
+def test_instnorm_apply_with_the_moments_given(rpe, b, c, h, w):
+    """rpe_instnorm_apply_ex with tiles = 0: the (mean, 1/std) pairs of rpe_instnorm_finalize instead of the records, the plane split
+    over up to 16 workgroups (16 at 256 x 320, 4 at 128 x 160, 1 below 32 KB; 44 x 52 = 2288 pixels: a plane that is no whole number of
+    64-byte pieces per workgroup).  Against the f64 evaluation, and equal to the records route up to the rounding of the pairs to f32;
+    every element written exactly once (NaN canaries), nothing outside the tensor."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(b * 7 + c + h)
+    x, wt, bias = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, s=0.5)
+    res = _rand(rng, b, c, h, w, s=0.7)
+    pw = ops.PackedWino(wt.cuda(), None)
+    stats = ops.conv_wino_stats_buffer(b, c, h, w, 'cuda')
+    raw = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=stats)
+    mi = ops.instnorm_finalize(stats, h * w, eps=1e-5, channels=c)
+    buf = torch.full((b * c * h * w + 64,), float('nan'), device='cuda')
+    out = buf[32:32 + b * c * h * w].view(b, c, h, w)
+    got = ops.instnorm_apply(raw, mi, relu=True, residual=res.cuda(), out=out)
+    assert bool(torch.isnan(buf[:32]).all()) and bool(torch.isnan(buf[32 + b * c * h * w:]).all()) and not bool(torch.isnan(got).any())
+    rec = ops.instnorm_apply(raw.clone(), stats, eps=1e-5, relu=True, residual=res.cuda())
+    pre = raw.cpu().double()
+    mean, var = pre.mean((2, 3), keepdim=True), pre.var((2, 3), unbiased=False, keepdim=True)
+    ref = (res.double() + ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)).clamp_min(0)
+    scale = float((pre - mean).abs().max() / torch.sqrt(var + 1e-5).min())
+    assert float((got.cpu().double() - ref).abs().max()) < 4e-7 * scale + 1e-6
+    assert float((got - rec).abs().max()) < 4e-7 * scale + 1e-6
+    with pytest.raises(rpe.RpeError):
+        ops.instnorm_apply(raw, mi[:, :c - 1].contiguous(), relu=True)
+
+
 @pytest.mark.parametrize('cin,cout,h,w,mode', [(324, 256, 44, 48, 'relu'), (256, 576, 44, 48, 'linear'), (128, 256, 64, 80, 'tanh'), (20, 70, 6, 12, 'linear')])
 def test_conv1x1_routes_agree_bitwise(rpe, cin, cout, h, w, mode):
     """ops.Conv1x1 sends a launch to rpe_conv1x1 (128 x 128 tiles on LDS-DMA rings) or to rpe_conv_fused (128- or 64-wide tiles) by its
