@@ -206,6 +206,30 @@ def test_encoder_block_epilogues_match_f64(rpe, c, h, w, b):
     assert (three - got2).abs().max() < 2e-5 * inv
 
 
+def test_encoder_epilogue_moments_with_addend_and_second_output(rpe):
+    """The encoder epilogue of rpe_conv_fused is instantiated per shape (moments or not) x (residual / addend / second output or none of
+    them): the combination the encoders themselves never use -- moments TOGETHER with an addend and a second output -- against f64:
+    values, both outputs, and the (count, mean, M2) records of v = conv + addend + bias."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(77)
+    b, c, h, w = 2, 64, 36, 40
+    x, wt, bias, add = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, s=0.5), _rand(rng, b, c, h, w, s=0.4)
+    pc = ops.PackedConv(wt.cuda(), bias.cuda())
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1) + add.double()
+    stats = ops.conv_stats_buffer(b, c, h, w, 'cuda')
+    o2 = torch.full((b, c + 3, h, w), -7.0, device='cuda')
+    got = ops.conv_fused(x.cuda(), pc, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), out2=o2[:, 2:2 + c], add=add.cuda(), stats=stats)
+    assert float((got.cpu().double() - ref).abs().max()) < _tol(x, wt) * 1.5
+    assert torch.equal(o2[:, 2:2 + c], got) and bool((o2[:, :2] == -7.0).all()) and bool((o2[:, 2 + c:] == -7.0).all())
+    st = stats.cpu().double()
+    n = st[..., 0].sum(-1)
+    assert float(n.min()) == float(n.max()) == h * w
+    mean = (st[..., 0] * st[..., 1]).sum(-1) / n
+    m2 = (st[..., 2] + st[..., 0] * (st[..., 1] - mean[..., None]) ** 2).sum(-1)
+    assert float((mean - ref.mean((2, 3))).abs().max()) < 1e-5
+    assert float((m2 / n - ref.var((2, 3), unbiased=False)).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize('cin,cout,kh,kw,mode', [(256, 256, 1, 5, 'zr'), (256, 128, 5, 1, 'relu'), (256, 192, 3, 3, 'relu'), (324, 256, 1, 1, 'relu')])
 def test_large_and_small_tiles_agree_bitwise(rpe, cin, cout, kh, kw, mode):
     """rpe_conv_fused picks 128x128 / 64x256 tiles for launches that fill the chip and 64x64 tiles for small ones
