@@ -399,6 +399,13 @@ def test_stem_conv_matches_f64(rpe, h, w, b):
     out = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True)
     inv = float((1 / torch.sqrt(var + 1e-5)).max())
     assert (out.cpu().double() - ((pre - mean) / torch.sqrt(var + 1e-5)).clamp_min(0)).abs().max() < (tol + 2e-6) * inv * 2
+    # scale AND moments in one launch (no caller of this package does; the epilogue's table and moment code must still compose)
+    both, st2 = ops.stem_conv(img.cuda(), ps, bias=shift.cuda(), scale=scale.cuda(), relu=False, stats=True)
+    lin = conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    assert (both.cpu().double() - lin).abs().max() < tol * 2.5
+    s2 = st2.cpu().double()
+    assert float(s2[..., 0].sum(-1).min()) == float(s2[..., 0].sum(-1).max()) == lin.shape[-1] * lin.shape[-2]
+    assert float(((s2[..., 0] * s2[..., 1]).sum(-1) / s2[..., 0].sum(-1) - lin.mean((2, 3))).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize('h,w,b', [(64, 80, 3), (44, 48, 2), (13, 37, 1)])
