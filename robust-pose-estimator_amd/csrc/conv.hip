@@ -839,7 +839,13 @@ extern "C" int rpe_instnorm_apply_ex(const float* x, const float* partials, int 
     if (!x || !partials || !out || b <= 0 || c <= 0 || hw <= 0 || (residual_mean_inv && !residual)) return RPE_E_BADARG;
     if ((hw & 3) || !al16(x) || !al16(out) || (residual && !al16(residual))) return RPE_E_UNSUPPORTED;
     int split = 1;                                   // tiles == 0 (moments given): slices of >= 16 KB, at most 16 per plane
-    if (tiles == 0) while (split < 16 && (long long)hw * 4 / (split * 2) >= 16384) split *= 2;
+#ifndef INA_MAXSPLIT
+#define INA_MAXSPLIT 16
+#endif
+#ifndef INA_MINBYTES
+#define INA_MINBYTES 16384
+#endif
+    if (tiles == 0) while (split < INA_MAXSPLIT && (long long)hw * 4 / (split * 2) >= INA_MINBYTES) split *= 2;
     hipLaunchKernelGGL(k_instnorm_apply, dim3(b * c * split), dim3(256), 0, (hipStream_t)stream, x, partials, tiles, c, hw, eps, relu, residual,
                        residual_mean_inv, out, split);
     return rpe_check_launch();
