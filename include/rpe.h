@@ -342,6 +342,16 @@ size_t rpe_conv_wino_packed_floats(int cout, int cin);
 int rpe_conv_wino_stats_tiles(int h, int w);
 int rpe_conv_wino_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv_wino(const rpe_conv_desc *desc, void *stream);
+/* LABELLED VARIANT of rpe_conv_wino (never in a headline number; bench.py --conv-bf16x3): the same convolution, descriptor fields,
+ * epilogues and moment records, with every f32 product of the Winograd domain evaluated as six bf16 products of an exact three-way
+ * split (x = hi + mid + lo) on the 16-bit matrix cores, f32 accumulation: f32-equivalent error (tests/test_gpu_conv_x3.py holds it to
+ * 1.25x the f32 kernels'), 3/8 of the matrix time (csrc/conv_wino_x3.hip).  Needs cin % 16 == 0, w % 4 == 0, even h, 16-byte
+ * aligned tensors; anything else -> RPE_E_UNSUPPORTED (the caller uses rpe_conv_wino).  desc->packed must come from
+ * rpe_conv_wino_x3_pack (rpe_conv_wino_x3_packed_bytes bytes, 0 = unsupported shape; 16-byte aligned).  Same reference layers as
+ * rpe_conv_wino (core/RAFT/core/update.py, extractor.py; call sites core/pose/pose_net.py:47,65,129). */
+size_t rpe_conv_wino_x3_packed_bytes(int cout, int cin);
+int rpe_conv_wino_x3_pack(const float *weight, int cout, int cin, void *packed, void *stream);
+int rpe_conv_wino_x3(const rpe_conv_desc *desc, void *stream);
 /* The same operation for 1x5 / 5x1 stride-1 convolutions (w % 4 == 0, cin % 4 == 0; tensors 16-byte aligned) with every
  * epilogue mode of rpe_conv_fused incl. the GRU gates (add, hidden, zgate, out2, gate_channels), as Winograd F(4,5) along the
  * filter axis on the f32 matrix cores: 8 products per 4 outputs instead of 20 (csrc/conv_wino1d.hip; SepConvGRU's convz|convr

@@ -639,6 +639,26 @@ class PackedWino:
         return tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 4 == 0 and hh % 2 == 0 and ww % 2 == 0
 
 
+class PackedWinoX3:
+    """Weights of a 3x3 stride-1 convolution for rpe_conv_wino_x3, the LABELLED bf16x3 variant of rpe_conv_wino: U = G g G^T in f32,
+    then the exact three-way bf16 split.  conv_wino() takes either packing and runs the kernel that belongs to it."""
+    x3 = True
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        n = lib().rpe_conv_wino_x3_packed_bytes(self.cout, self.cin) if (self.kh, self.kw) == (3, 3) else 0
+        if n == 0:
+            raise _lib.RpeError('PackedWinoX3: needs a (cout, cin % 16 == 0, 3, 3) weight')
+        self.packed = torch.empty(n // 4, dtype=torch.float32, device=w.device)       # (three bf16 planes; float32 storage for the descriptor)
+        check(lib().rpe_conv_wino_x3_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv_wino_x3_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(weight, hh, ww):
+        return tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 16 == 0 and hh % 2 == 0 and ww % 4 == 0
+
+
 def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=None, stats=None, pre_norm=None, prepare=False):
     """rpe_conv_wino: out = epilogue(conv3x3(x; pw) * scale + bias) by Winograd F(2x2,3x3); tensors are channel slices of NCHW
     buffers.  ``stats`` (conv_wino_stats_buffer) / ``pre_norm`` / ``residual`` / ``scale``: the encoders' epilogues, as conv_fused."""
@@ -676,7 +696,7 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
     d.stats, d.pre_norm = ptr(stats), ptr(pre_norm)
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.stride = b, cin, pw.cout, hh, ww, 3, 3, mode, 1
     if prepare:
-        fn, ref, keep = lib().rpe_conv_wino, ctypes.byref(d), (d, x, pw, out, out2, scale, bias, residual, stats, pre_norm)
+        fn, ref, keep = (lib().rpe_conv_wino_x3 if getattr(pw, 'x3', False) else lib().rpe_conv_wino), ctypes.byref(d), (d, x, pw, out, out2, scale, bias, residual, stats, pre_norm)
 
         def launch():
             st = fn(ref, stream_ptr())
@@ -685,7 +705,10 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
             return keep[3]
         launch.keep = keep
         return launch
-    check(lib().rpe_conv_wino(ctypes.byref(d), stream_ptr()), 'rpe_conv_wino')
+    if getattr(pw, 'x3', False):
+        check(lib().rpe_conv_wino_x3(ctypes.byref(d), stream_ptr()), 'rpe_conv_wino_x3')
+    else:
+        check(lib().rpe_conv_wino(ctypes.byref(d), stream_ptr()), 'rpe_conv_wino')
     return out
 
 
