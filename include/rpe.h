@@ -48,7 +48,8 @@ extern "C" {
 const char *rpe_version(void);
 /* Layout version of this header's structs (rpe_conv_desc, rpe_solve_opts) and signatures: a binding compares it with the
  * RPE_ABI_VERSION it was written against before the first call (the ctypes binding does, robust-pose-estimator_amd/_lib.py).
- * 4: rpe_conv_desc is 200 bytes (stats_tiles), stride-2 statistics are one record per 32 output pixels, rpe_pose_solve_ex. */
+ * 5: rpe_conv_desc is 200 bytes (stats_tiles), stride-2 statistics are one record per 32 output pixels, rpe_pose_solve_ex, rpe_pose_gate_chain.
+ * Entry points added since (rpe_conv_wino_x3*) change no struct and no existing signature: the version stays 5. */
 #define RPE_ABI_VERSION 5
 int rpe_abi_version(void);
 
@@ -114,8 +115,10 @@ int rpe_pose_solve_opts(const float *flow, const float *pcl1, const float *pcl2,
                         int history_size, double *T_out, float *vec7, float *log6, int32_t *info, void *workspace,
                         void *stream);
 
-/* The same with the options in a sized struct (new fields can follow without breaking callers: struct_size must be
- * sizeof(rpe_solve_opts) of the header the caller was built against).
+/* The same with the options in a sized struct: struct_size = sizeof(rpe_solve_opts) of the header the caller was built against.  The library
+ * accepts any struct_size >= the layout it knows (fields are only ever appended, so a newer caller's longer struct carries this layout as
+ * its prefix) and returns RPE_E_BADARG for a shorter one; a field appended later is read only when struct_size covers it and takes its
+ * documented default otherwise.
  *   partition_rows: the pixel reduction sums per-block partials in a fixed order, and the number of blocks per row is chosen so that
  *   ONE round of workgroups covers the batch -- so a row's float64 sums are grouped differently in a 16-row launch than alone.
  *   0 = that default; p > 0 = the partition a p-row batch would get.  With p = 1 every row's iterates are bit-identical to solving

@@ -587,10 +587,6 @@ __global__ __launch_bounds__(256) void k_instnorm_finalize_tm(const float* __res
     const float* pp = partials + ((size_t)b * tiles * C + (ok ? c : 0)) * 3;
     const size_t ts = (size_t)3 * C;
     auto tree = [&](double (*v)[4]) {                         // v[0][cl] <- sum over the 64 slices, pairwise, fixed order
-#ifdef FIN_NOTREE
-        __syncthreads();
-        return;
-#endif
 #pragma unroll
         for (int h = 32; h >= 1; h >>= 1) {
             __syncthreads();
@@ -608,11 +604,7 @@ __global__ __launch_bounds__(256) void k_instnorm_finalize_tm(const float* __res
         for (int j = 0; j < RMAX; ++j) {
             const int t = sl + 64 * j;
             const float* r = pp + ts * (size_t)(t < tiles ? t : 0);
-#ifdef FIN_NOLOAD
-            const float v0 = 128.0f, v1 = 0.5f + 0.001f * t, v2 = 3.0f;
-#else
             const float v0 = r[0], v1 = r[1], v2 = r[2];
-#endif
             rn[j] = t < tiles ? v0 : 0.0f; rm[j] = v1; rq[j] = v2;
         }
     }

@@ -136,6 +136,26 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
 #endif
         dma_raw7(xb + (size_t)step * rstep, rr, rs_base + (unsigned)buf * (X_RBUF * 4u));
     };
+    // the same seven chunks one at a time (main loop: one per matrix-instruction group)
+    unsigned rr_[7] = {0, 0, 0, 0, 0, 0, 0};
+    const float* dma_src = xb;
+    unsigned dma_lds = 0;
+    auto dma_begin = [&](int step, int buf) {
+        const u32x4 r0 = *(const u32x4*)&smem[ROFF_AT + 8 * tid], r1 = *(const u32x4*)&smem[ROFF_AT + 8 * tid + 4];
+        rr_[0] = r0[0]; rr_[1] = r0[1]; rr_[2] = r0[2]; rr_[3] = r0[3]; rr_[4] = r1[0]; rr_[5] = r1[1]; rr_[6] = r1[2];
+#ifdef X3_DMA_HOT
+        step = 0;
+#endif
+        dma_src = wave_uniform(xb + (size_t)step * rstep - 768);
+        dma_lds = rs_base + (unsigned)buf * (X_RBUF * 4u);
+    };
+    auto dma_chunk = [&rr_, &dma_src, &dma_lds](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        unsigned keep;
+        const unsigned la = dma_lds + (k >= 4 ? 4096u : 0u);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(rr_[k]), "s"(dma_src), "s"(la), "n"((k & 3) * 1024) : "memory");
+    };
     // after landing: the lane patches ITS quads (no barrier needed in front): padding, and with PRE relu((x - mean) / std) in place
     auto fix_raw = [&](int step, int buf) {
         if (!PRE && !border) return;
@@ -165,26 +185,30 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     const char* ubase = (const char*)P.wp + ((size_t)(co0 / X_CO) * 4 + wv) * X_U_WAVE + (size_t)((co0 % X_CO) / 32) * 3072;
     const size_t ustep = (size_t)nct * 4 * X_U_WAVE;
     u32x4 A[4][NCB][3];
-    auto load_a = [&A, ubase, ustep, a_lane](int step, auto nuc) {
-        constexpr int nu = decltype(nuc)::value;
+    // one plane of A[nu] (both channel blocks): requested piece by piece, spread over the matrix-instruction groups (a block of six
+    // requests stalls the wave's issue ~30 cycles each while the matrix pipe drains)
+    auto load_piece = [&A, ubase, ustep, a_lane](int step, auto nuc, auto plc) {
+        constexpr int nu = decltype(nuc)::value, pl = decltype(plc)::value;
 #ifdef X3_A_HOT
         step = 0;                                                                      // ablation: every step re-reads step 0's fragments
 #endif
-        const float* p0 = wave_uniform((const float*)(ubase + (size_t)step * ustep + nu * 6144));
-        asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:1024\n\tglobal_load_dwordx4 %2, %3, %4 offset:2048"
-                     : "=&v"(A[nu][0][0]), "=&v"(A[nu][0][1]), "=&v"(A[nu][0][2]) : "v"(a_lane), "s"(p0) : "memory");
-        if (NCB == 2) {
-            const float* p1 = wave_uniform(p0 + 768);
-            asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:1024\n\tglobal_load_dwordx4 %2, %3, %4 offset:2048"
-                         : "=&v"(A[nu][NCB - 1][0]), "=&v"(A[nu][NCB - 1][1]), "=&v"(A[nu][NCB - 1][2]) : "v"(a_lane), "s"(p1) : "memory");
-        }
+        const float* p0 = wave_uniform((const float*)(ubase + (size_t)step * ustep + nu * 6144 + pl * 1024));
+        if (NCB == 2) asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:3072"
+                                   : "=&v"(A[nu][0][pl]), "=&v"(A[nu][NCB - 1][pl]) : "v"(a_lane), "s"(p0) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(A[nu][0][pl]) : "v"(a_lane), "s"(p0) : "memory");
     };
-    // A[nu] has landed when at most `younger` = the later positions' 3 NCB (3 - nu) requests are outstanding.  The LDS-DMA requests that sit
-    // between A[1] and A[2] in program order are NOT counted: ordinary loads return in order among themselves, but (measured: wrong
-    // results with the DMAs counted) not with respect to LDS-DMA, so the count must hold whichever of the DMAs are still in flight.
-    // nu = 3 waits for everything, DMA included: that is also the "patch has landed" wait of the step.
+    auto load_a = [&](int step, auto nuc) {
+        load_piece(step, nuc, std::integral_constant<int, 2>{}); load_piece(step, nuc, std::integral_constant<int, 1>{}); load_piece(step, nuc, std::integral_constant<int, 0>{});
+    };
+    // Request order of the ordinary loads (pieces of NCB loads; lo, mid, hi = planes 2, 1, 0 in the order they fall dead in a stage):
+    //   A'[0] lo mid | hi  A'[1] lo mid | hi  A'[2] lo mid | hi  A'[3] lo mid || next step: A'[3] hi
+    // (stages (0,tb1) | (1,tb1) | (2,tb1) | (3,tb1) || (0,tb0) of the next step).  A[nu] has landed when at most `younger` pieces are
+    // outstanding: at stage (0,tb0) 8 (A[3] hi is requested after the wait), then 6, 3, 0.  The LDS-DMA requests in between are NOT
+    // counted: ordinary loads return in order among themselves, but (measured: wrong results with the DMAs counted) not with respect to
+    // LDS-DMA, so the count must hold whichever DMAs are still in flight.  nu = 3 waits for everything: that is also the "patch has
+    // landed" wait of the step.
     auto wait_a = [](auto nuc) {
-        constexpr int nu = decltype(nuc)::value, younger = 3 * NCB * (3 - nu);
+        constexpr int nu = decltype(nuc)::value, younger = NCB * (nu == 0 ? 8 : nu == 1 ? 6 : nu == 2 ? 3 : 0);
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(younger) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     // after q0 + 1's those of the next stage's first pair (qn, tbn, bufn; skipped when `chain` is false: the next stage sits behind the
     // barrier).  PROD = false: matrix instructions only.  The fences keep the four vector chains apart: the scheduler prices registers
     // against the unified 512-entry file, but vector instructions cannot use the accumulator half, and the allocator then spills.
-    auto stage = [&](auto prodc, auto nuc, auto tbc, auto slc, auto npc, auto tbpc, auto q0c, unsigned bufp, auto qnc, auto tbnc, unsigned bufn, bool chain) {
+    auto stage = [&](auto prodc, auto nuc, auto tbc, auto slc, auto npc, auto tbpc, auto q0c, unsigned bufp, auto qnc, auto tbnc, unsigned bufn, bool chain, auto vm) {
         constexpr bool PROD = decltype(prodc)::value;
         constexpr int sl = decltype(slc)::value, np = decltype(npc)::value, q0 = decltype(q0c)::value;
         typedef std::integral_constant<int, 1 - sl> SP; typedef std::integral_constant<int, 2 * np> NA; typedef std::integral_constant<int, 2 * np + 1> NB;
@@ -307,25 +331,24 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
 #ifdef X3_WAIT_ALL
         wait_a(nuc);
 #else
-        if (decltype(tbc)::value == 0) wait_a(nuc);
-#endif            // (first use of A[nu] in the step; at its second, in tile block 1, it is resident --
+        if (decltype(tbc)::value == 0) wait_a(nuc);            // (first use of A[nu] in the step; at its second, in tile block 1, it is resident --
                                                                 //  and the younger requests counted above are not the ones in flight there)
+#endif
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(nuc, tbc, slc, I0{}); if (PRODV) finish_nu(Q0{}, SP{}, NA{}); __builtin_amdgcn_sched_barrier(0);
-        mfma_group(nuc, tbc, slc, I1{}); if (PRODV) finish_nu(Q0{}, SP{}, NB{}); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(nuc, tbc, slc, I0{}); vm(I0{}); if (PRODV) finish_nu(Q0{}, SP{}, NA{}); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(nuc, tbc, slc, I1{}); vm(I1{}); if (PRODV) finish_nu(Q0{}, SP{}, NB{}); __builtin_amdgcn_sched_barrier(0);
         if (PRODV) { wait_reads(); row_pass(npc); if (chain) issue_reads(qnc, tbnc, bufn); }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group(nuc, tbc, slc, I2{}); if (PRODV) finish_nu(Q1{}, SP{}, NA{}); __builtin_amdgcn_sched_barrier(0);
-        mfma_group(nuc, tbc, slc, I3{}); if (PRODV) finish_nu(Q1{}, SP{}, NB{}); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(nuc, tbc, slc, I2{}); vm(I2{}); if (PRODV) finish_nu(Q1{}, SP{}, NA{}); __builtin_amdgcn_sched_barrier(0);
+        mfma_group(nuc, tbc, slc, I3{}); vm(I3{}); if (PRODV) finish_nu(Q1{}, SP{}, NB{}); __builtin_amdgcn_sched_barrier(0);
     };
     typedef std::true_type PY;
 
-    // ---- prologue: requests in the steady-state order DMA(0) | A[0] A[1] | DMA(1) | A[2] A[3]
+    // ---- prologue: DMA(0), A(0) except A[3]'s hi plane (the loop's first stage requests it, as in every step), DMA(1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               // (the offsets are in LDS)
     dma_raw(0, 0);
-    load_a(0, I0{}); load_a(0, I1{});
-    dma_raw(nsteps > 1 ? 1 : 0, 1);
-    load_a(0, I2{}); load_a(0, I3{});
+    load_a(0, I0{}); load_a(0, I1{}); load_a(0, I2{}); load_piece(0, I3{}, I2{}); load_piece(0, I3{}, I1{});
+    dma_begin(nsteps > 1 ? 1 : 0, 1); dma_chunk(I0{}); dma_chunk(I1{});             // (chunks 2-6 of DMA(1): the loop's first two stages)
     if (PRE) {
         for (int i = tid; i < P.cin; i += 256) {
             const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
@@ -363,28 +386,60 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
         const unsigned nxt = cur ^ (X_RBUF * 4u);
         const int s1 = s + 1 < nsteps ? s + 1 : nsteps - 1, s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;
         XSTAMP(0);
-        //    produce    matrix (nu, tb, slot) | builds (pair, tile block, first channel pair, buffer) | next reads
-        stage(PY{}, I0{}, I0{}, I0{}, I1{}, I0{}, I0{}, cur, I2{}, I0{}, cur, true); XSTAMP(1);
-        stage(PY{}, I1{}, I0{}, I0{}, I1{}, I0{}, I2{}, cur, I0{}, I1{}, cur, true); XSTAMP(2);
-        stage(PY{}, I2{}, I0{}, I1{}, I0{}, I1{}, I0{}, cur, I2{}, I1{}, cur, true); XSTAMP(3);
-        stage(PY{}, I3{}, I0{}, I1{}, I0{}, I1{}, I2{}, cur, I0{}, I1{}, cur, true); XSTAMP(4);
-        stage(PY{}, I0{}, I1{}, I0{}, I1{}, I1{}, I0{}, cur, I2{}, I1{}, cur, true); XSTAMP(5);
-        load_a(s1, I0{});
-        stage(PY{}, I1{}, I1{}, I0{}, I1{}, I1{}, I2{}, cur, I0{}, I0{}, cur, false); XSTAMP(6);
-        load_a(s1, I1{});
+        //    produce    matrix (nu, tb, slot) | builds (pair, tile block, first channel pair, buffer) | next reads | memory requests per group
+        // Memory requests, at most one instruction group per matrix-instruction group and wave (the four waves run in lockstep and share
+        // the CU's one address unit: bunched, the seven DMA chunks of a step cost each wave ~100 cycles apiece):
+        //   tile block 1 stages: the planes of A(s+1)[nu], each in the group after its last use (lo: group 0, mid: 2, hi: 3 of stage (nu, 1))
+        //   stages (2,1), (3,1): DMA(s+2) chunks 0, 1 -> raw(s)'s buffer, free after the barrier;   stages (0,0), (1,0) of step s+1: chunks 2-6
+        //   (all of DMA(s+2) has been requested two stages before stage (3,0)'s wait for everything)
+        auto none = [](auto) {};
+        typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 5> I5; typedef std::integral_constant<int, 6> I6;
+        dma_begin(s1, (int)(nxt != 0));                                               // (chunks 2-6 of DMA(s+1))
+        stage(PY{}, I0{}, I0{}, I0{}, I1{}, I0{}, I0{}, cur, I2{}, I0{}, cur, true, [&](auto g) {
+            if (decltype(g)::value == 0) load_piece(s, I3{}, I0{});
+            if (decltype(g)::value == 1) dma_chunk(I2{});
+            if (decltype(g)::value == 2) dma_chunk(I3{});
+            if (decltype(g)::value == 3) dma_chunk(I4{}); }); XSTAMP(1);
+        stage(PY{}, I1{}, I0{}, I0{}, I1{}, I0{}, I2{}, cur, I0{}, I1{}, cur, true, [&](auto g) {
+            if (decltype(g)::value == 0) dma_chunk(I5{});
+            if (decltype(g)::value == 1) dma_chunk(I6{}); }); XSTAMP(2);
+        stage(PY{}, I2{}, I0{}, I1{}, I0{}, I1{}, I0{}, cur, I2{}, I1{}, cur, true, none); XSTAMP(3);
+        stage(PY{}, I3{}, I0{}, I1{}, I0{}, I1{}, I2{}, cur, I0{}, I1{}, cur, true, none); XSTAMP(4);
+        stage(PY{}, I0{}, I1{}, I0{}, I1{}, I1{}, I0{}, cur, I2{}, I1{}, cur, true, [&](auto g) {
+            if (decltype(g)::value == 1) load_piece(s1, I0{}, I2{});
+            if (decltype(g)::value == 3) load_piece(s1, I0{}, I1{}); }); XSTAMP(5);
+        stage(PY{}, I1{}, I1{}, I0{}, I1{}, I1{}, I2{}, cur, I0{}, I0{}, cur, false, [&](auto g) {
+            if (decltype(g)::value == 0) load_piece(s1, I0{}, I0{});
+            if (decltype(g)::value == 1) load_piece(s1, I1{}, I2{});
+            if (decltype(g)::value == 3) load_piece(s1, I1{}, I1{}); }); XSTAMP(6);
         fix_raw(s1, (int)(nxt != 0));
+        dma_begin(s2, (int)(cur != 0));                                               // (chunks 0, 1 of DMA(s+2))
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         XSTAMP(7);
         __builtin_amdgcn_s_barrier();
+        // the barrier releases the four waves in the same cycle, and from then on they would present every memory request to the CU's one
+        // address unit together (each waiting for the other three: ~50 cycles per request).  Stagger them by X3_STAGGER cycles per wave.
+#ifndef X3_STAGGER
+#define X3_STAGGER 0            /* (swept 0 / 16 / 32 / 64 on convc2: 505 / 512 / 512 / 520 us -- the request cost is not contention between the waves) */
+#endif
+        if (X3_STAGGER) {
+            if (wv & 1) { for (int i = 0; i < X3_STAGGER / 16; ++i) asm volatile("s_nop 15"); }
+            if (wv & 2) { for (int i = 0; i < X3_STAGGER / 8; ++i) asm volatile("s_nop 15"); }
+        }
         XSTAMP(8);
-        dma_raw(s2, (int)(cur != 0));
         issue_reads(I0{}, I0{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
         XSTAMP(9);
-        stage(PY{}, I2{}, I1{}, I1{}, I0{}, I0{}, I0{}, nxt, I2{}, I0{}, nxt, true); XSTAMP(10);
-        load_a(s1, I2{});
-        stage(PY{}, I3{}, I1{}, I1{}, I0{}, I0{}, I2{}, nxt, I0{}, I0{}, nxt, true); XSTAMP(11);
-        load_a(s1, I3{});
+        stage(PY{}, I2{}, I1{}, I1{}, I0{}, I0{}, I0{}, nxt, I2{}, I0{}, nxt, true, [&](auto g) {
+            if (decltype(g)::value == 0) load_piece(s1, I1{}, I0{});
+            if (decltype(g)::value == 1) load_piece(s1, I2{}, I2{});
+            if (decltype(g)::value == 2) dma_chunk(I0{});
+            if (decltype(g)::value == 3) load_piece(s1, I2{}, I1{}); }); XSTAMP(10);
+        stage(PY{}, I3{}, I1{}, I1{}, I0{}, I0{}, I2{}, nxt, I0{}, I0{}, nxt, true, [&](auto g) {
+            if (decltype(g)::value == 0) load_piece(s1, I2{}, I0{});
+            if (decltype(g)::value == 1) load_piece(s1, I3{}, I2{});
+            if (decltype(g)::value == 2) dma_chunk(I1{});
+            if (decltype(g)::value == 3) load_piece(s1, I3{}, I1{}); }); XSTAMP(11);
         cur = nxt;
     }
 #ifdef X3_TIMING

@@ -596,7 +596,9 @@ extern "C" int rpe_pose_solve_ex(const float* flow, const float* pcl1, const flo
                                  const uint8_t* mask1, const uint8_t* mask2, const float* K, const float* loss_weight,
                                  int n, int h, int w, int mode, int iters, const rpe_solve_opts* opts, double* T_out, float* vec7, float* log6,
                                  int32_t* info, void* workspace, void* stream) {
-    if (!opts || opts->struct_size != (int)sizeof(rpe_solve_opts)) return RPE_E_BADARG;
+    // a caller built against a later header passes a LONGER struct: the fields this library knows are a prefix of it.  Shorter = an older
+    // layout this library cannot complete (no field has been appended yet: the first one will read its default when struct_size stops before it)
+    if (!opts || opts->struct_size < (int)sizeof(rpe_solve_opts)) return RPE_E_BADARG;
     const int history_size = opts->history_size;
     const double tolerance_grad = opts->tolerance_grad, tolerance_change = opts->tolerance_change;
     if (history_size < 1 || history_size > HIST || !(tolerance_grad >= 0.0) || !(tolerance_change >= 0.0) || opts->partition_rows < 0) return RPE_E_BADARG;

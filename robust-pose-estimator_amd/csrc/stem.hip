@@ -97,11 +97,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     const size_t hw_in = (size_t)P.H * P.W;
     const float* xb = P.x + (size_t)bz * CIN * hw_in;
     // ---- stage weights and tap table once; then SNP patches one after the other
-#if defined(STEM_ABL) && (STEM_ABL & 8)
-    for (int i = tid; i < TCO * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = make_float4(0.01f * i, 0.0f, 1.0f, 0.5f);
-#else
     for (int i = tid; i < TCO * SKA / 4; i += 256) ((float4*)&As[0][0])[i] = ((const float4*)(P.wk + (size_t)cbase * SKA))[i];
-#endif
     if (tid < TCO) { sb[tid][0] = P.scale ? P.scale[cbase + tid] : 1.0f; sb[tid][1] = P.bias ? P.bias[cbase + tid] : 0.0f; }
     for (int k = tid; k < SK; k += 256) {
         const int kk = k < TAPS ? k : 0, ci = kk / 49, dy = (kk % 49) / 7, dx = kk % 7;
@@ -122,11 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
             const int ci = i / (PROWS * PCOLS), rem = i - ci * (PROWS * PCOLS), r = rem / PCOLS, c = rem - r * PCOLS;
             const int yi = STRIDE * y0 - 3 + r, xi = STRIDE * x0 - 3 + c;
             const bool ok = (i < CIN * PROWS * PCOLS) & (yi >= 0) & (yi < P.H) & (xi >= 0) & (xi < P.W);
-#if defined(STEM_ABL) && (STEM_ABL & 1)
-            raw[u] = (float)i;
-#else
             raw[u] = xb[ok ? ci * hw_in + (size_t)yi * P.W + xi : 0];
-#endif
             okm |= ok ? (1u << u) : 0u;
         }
 #pragma unroll
@@ -151,11 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_stem7x7(StemP P) {
     const int lane0 = (STRIDE * (2 * wv)) * PSTR + STRIDE * l31, lane1 = (STRIDE * (2 * wv + 1)) * PSTR + STRIDE * l31;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-#if defined(STEM_ABL) && (STEM_ABL & 2)
-    for (int blk = 0; blk < (P.H == 1 ? SK / 16 : 1); ++blk) {
-#else
     for (int blk = 0; blk < SK / 16; ++blk) {
-#endif
         const int kb = 16 * blk + 8 * lh;
         f32x4 a0[2], a1[2]; i32x4 ko[2];
         a0[0] = *(const f32x4*)&As[l31][kb];      a0[1] = *(const f32x4*)&As[l31][kb + 4];

@@ -99,6 +99,7 @@ class PoseNet(nn.Module):
             return both(feature_images, context_images)
         return self.flow.encode_features(feature_images), self.flow.encode_context(context_images)
 
+    @torch.no_grad()
     def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None, heads=True):
         """Every stage of infer() before the solve.  ``cache1`` = {'fmap','cnet'} of image1l from the previous call
         (streaming: frame t's image2l is frame t+1's image1l), so only the two new images are encoded."""
@@ -195,6 +196,9 @@ class PoseNet(nn.Module):
         stereo_flow1 = torch.cat((stereo_flow0, stereo_flow2[:c - 1]), dim=0)
         image1l = torch.cat((image0l, imagesl[:c - 1]), dim=0)
         g = ops.depth_backproject_warp(stereo_flow2, time_flow, baseline, intrinsics, depth1, image1l, imagesl, stereo_flow1, masks)
+        if self.use_weights and not FUSED_HEADS:
+            # the A/B switch selects the module route in stages(); here it would silently break forward_chunk == c forward calls
+            raise RuntimeError('infer_chunk runs the fused weight heads only: set pose_net.FUSED_HEADS = True (or walk the frames with infer)')
         if self.use_weights and not (self.weight_head_2d.training or self.weight_head_3d.training):
             w2d, w3d = ops.unet_heads(g['inp1'], g['inp2'], hidden, context, pack_params(self.weight_head_2d[0]),
                                       pack_params(self.weight_head_3d[0]), self.config['image_shape'])

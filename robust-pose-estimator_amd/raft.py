@@ -35,6 +35,12 @@ from . import ops
 # Module-level route constants (no environment switches in the product: tools/ and bench.py's labelled experiments set these attributes)
 WINOGRAD = True          # 3x3 layers as F(2x2,3x3), the GRU's 1x5 / 5x1 as F(4,5); False = the direct implicit GEMM (A/B measurements)
 CORR_BF16X3 = False      # EXPERIMENT: correlation products as six bf16 products of an exact 3-way split (bench.py --corr-bf16x3)
+CONV_BF16X3 = False      # LABELLED VARIANT (bench.py --conv-bf16x3; never the headline): the update block's 3x3 layers with >= 128 input
+#                          channels (convc2, conv, FlowHead.conv1, the mask head's 3x3) through rpe_conv_wino_x3 -- Winograd products as six
+#                          bf16 products of an exact 3-way split -- and the correlation build through k_corr_build_x3.  The layers it does
+#                          NOT cover (measured no faster: short K loops) stay on the f32 matrix cores: the encoders, convf2, the GRU's
+#                          1x5 / 5x1 layers, convc1 and the other 1x1 layers, the stems.
+X3_MIN_CIN = 128         # rpe_conv_wino_x3 pays from 8 K steps of 16 channels on
 # The motion encoder's flow branch (convf1 -> convf2) on a side stream beside lookup -> convc1 -> convc2.  Measured (MI355X, 640x512):
 # batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
 # launch fills the chip on its own), so it is used for small passes only.
@@ -361,7 +367,9 @@ class BasicMotionEncoder(nn.Module):
         if calls is None:
             cor = packed['cor_buf'](corr)
             flo = packed['flo_buf'](corr)
-            wino = packed['wino'] if corr.shape[-1] % 2 == 0 and corr.shape[-2] % 2 == 0 else {}
+            wino = dict(packed['wino']) if corr.shape[-1] % 2 == 0 and corr.shape[-2] % 2 == 0 else {}
+            if wino and corr.shape[-1] % 4 == 0:
+                wino.update(packed.get('wino_x3', {}))          # (CONV_BF16X3: conv_wino runs the kernel that belongs to the packing)
 
             def c3(name, x, out, out2=None):            # a 3x3 layer: Winograd when available, else the direct implicit GEMM
                 if name in wino:
@@ -462,13 +470,16 @@ class BasicUpdateBlock(nn.Module):
         keymods = mods + (e.convf1,)
         # (the convolutions' own weight / bias attributes: walking module.parameters() costs ~100 us a call, and this runs 26 times a frame)
         ps = [t for m in keymods for t in (m.weight, m.bias) if t is not None]
-        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (id(self.gate_weights()),)
+        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (id(self.gate_weights()), CONV_BF16X3)
         if getattr(self, '_packed', None) is None or self._packed[0] != key:
             W = self.gate_weights()
             P = {n: ops.PackedConv(m.weight, m.bias) for n, m in zip(('convc1', 'convc2', 'convf2', 'conv', 'fh1'), mods)}
             # the four 3x3 layers also in Winograd form (rpe_conv_wino: 2.25x fewer matrix FLOPs); used on even maps
             P['wino'] = {n: ops.PackedWino(m.weight, m.bias) for n, m in zip(('convc2', 'convf2', 'conv', 'fh1'), mods[1:])
                          if ops.PackedWino.supported(m.weight, 2, 2)} if WINOGRAD else {}
+            # the labelled bf16x3 variant's packings of the same layers (used on maps rpe_conv_wino_x3 accepts: even h, w % 4 == 0)
+            P['wino_x3'] = {n: ops.PackedWinoX3(m.weight, m.bias) for n, m in zip(('convc2', 'convf2', 'conv', 'fh1'), mods[1:])
+                            if n != 'convf2' and m.in_channels >= X3_MIN_CIN and ops.PackedWinoX3.supported(m.weight, 2, 4)} if (WINOGRAD and CONV_BF16X3) else {}
             P['convf1'] = ops.PackedStem(e.convf1.weight)
             P['convc1_1x1'] = ops.Conv1x1(e.convc1.weight, e.convc1.bias)
             for n in ('zr1', 'q1', 'zr2', 'q2'):
@@ -516,7 +527,8 @@ class BasicUpdateBlock(nn.Module):
                                      prepare=True))
                     seq.append(gconv(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
                 if 'fh1' in P['wino'] and hx.shape[-1] % 2 == 0 and hx.shape[-2] % 2 == 0:
-                    seq.append(ops.conv_wino(hx[:, :c], P['wino']['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+                    pfh = P['wino_x3']['fh1'] if 'fh1' in P.get('wino_x3', {}) and hx.shape[-1] % 4 == 0 else P['wino']['fh1']
+                    seq.append(ops.conv_wino(hx[:, :c], pfh, ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
                 else:
                     seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
                 if in_place:
@@ -552,14 +564,15 @@ class BasicUpdateBlock(nn.Module):
         factor is folded into the 1x1 layer's parameters (a power of two: bit-identical to scaling the result)."""
         c1, c2 = self.mask[0], self.mask[2]
         mp = (c1.weight, c1.bias, c2.weight, c2.bias)
-        key = tuple(p._version for p in mp) + tuple(p.data_ptr() for p in mp)
+        hh, ww = net.shape[-2:]
+        x3 = CONV_BF16X3 and c1.in_channels >= X3_MIN_CIN and ops.PackedWinoX3.supported(c1.weight, hh, ww)
+        key = tuple(p._version for p in mp) + tuple(p.data_ptr() for p in mp) + (x3,)
         cached = getattr(self, '_mask_packed', None)
         if cached is None or cached[0] != key:
-            pw = ops.PackedWino(c1.weight, c1.bias) if WINOGRAD and c1.weight.is_cuda else None
+            pw = (ops.PackedWinoX3 if x3 else ops.PackedWino)(c1.weight, c1.bias) if WINOGRAD and c1.weight.is_cuda else None
             w2, b2 = (0.25 * c2.weight).detach(), (0.25 * c2.bias).detach()
             self._mask_packed = cached = (key, pw, w2, b2, ops.Conv1x1(w2, b2) if c2.weight.is_cuda else None)
         _, pw, w2, b2, p2 = cached
-        hh, ww = net.shape[-2:]
         if pw is not None and not torch.is_grad_enabled() and hh % 2 == 0 and ww % 2 == 0:      # (net may be a channel slice: hx[:, :128])
             t = ops.conv_wino(net, pw, ops.CONV_RELU, torch.empty(net.shape[0], c1.out_channels, hh, ww, device=net.device))
         else:
@@ -608,9 +621,10 @@ class RAFT(nn.Module):
 
     def _pyramid(self, b, h8, w8, device):
         p = self._pyr
-        if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device or getattr(p, 'x3', False) != CORR_BF16X3:
-            self._pyr = ops.CorrPyramid(b, h8, w8, self.corr_levels, self.corr_radius, device=device, bf16x3=CORR_BF16X3)
-            self._pyr.x3 = CORR_BF16X3
+        x3 = CORR_BF16X3 or CONV_BF16X3
+        if p is None or (p.b, p.h8, p.w8) != (b, h8, w8) or p.buf.device != device or getattr(p, 'x3', False) != x3:
+            self._pyr = ops.CorrPyramid(b, h8, w8, self.corr_levels, self.corr_radius, device=device, bf16x3=x3)
+            self._pyr.x3 = x3
         return self._pyr
 
     def _workspace(self, n, h8, w8, device):
@@ -687,7 +701,7 @@ class RAFT(nn.Module):
             fmap1, fmap2 = f[:N], f[N:]
         else:
             fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
-        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision, bf16x3=CORR_BF16X3)
+        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision, bf16x3=(CORR_BF16X3 or CONV_BF16X3) and not self.mixed_precision)
         if cnet is None:
             cnet = self.encode_context(image1)                # (tanh(net) | relu(inp))
         c = self.hidden_dim

@@ -45,14 +45,26 @@ class _Tree(nn.Module):
             setattr(self, k, v)
 
 
+def _blob_sources(net):
+    """Every tensor pack_params reads, fetched from the modules' current attributes."""
+    out = []
+    for st in list(net.encoder.enc_blocks) + list(net.decoder.dec_blocks):
+        n = st.norm
+        out += [st.conv1.weight, st.conv1.bias, st.conv2.weight, st.conv2.bias, n.weight, n.bias, n.running_mean, n.running_var]
+    for upc in net.decoder.upconvs:
+        out += [upc.weight, upc.bias]
+    out += [net.head.weight, net.head.bias]
+    return [t for t in out if t is not None]
+
+
 def pack_params(net):
     """The parameter blob rpe_unet_heads reads (layout: csrc/unet.hip): 3x3 weights as [cin][9][cout], transposed-conv weights as
     [cin][4][cout], inference-mode batch norm as per-channel (scale, shift) -- after conv1 + bias in the encoder stages
     (conv-norm-relu-conv), after the ReLU in the decoder stages (conv-relu-norm-conv).  Cached until a parameter changes."""
-    tensors = getattr(net, '_rpe_tensors', None)          # (walking parameters() / buffers() costs ~0.1 ms per head and frame: the Parameter and
-    if tensors is None:                                    #  buffer OBJECTS are listed once; their versions and addresses are what can change)
-        tensors = net._rpe_tensors = (list(net.parameters()), list(net.buffers()))
-    key = tuple(p._version for p in tensors[0]) + tuple(p.data_ptr() for p in tensors[0]) + tuple(b._version for b in tensors[1])
+    # the module's CURRENT Parameter and buffer objects every call (load_state_dict(assign=True) or re-assigning conv.weight replaces the
+    # objects: a list cached once would keep serving the old blob); ~40 attribute reads, cheaper than walking parameters() / buffers()
+    tensors = _blob_sources(net)
+    key = tuple(id(t) for t in tensors) + tuple(t._version for t in tensors) + tuple(t.data_ptr() for t in tensors)
     cached = getattr(net, '_rpe_blob', None)
     if cached is not None and cached[0] == key:
         return cached[1]

@@ -1,0 +1,158 @@
+"""GPU: rpe_conv_wino_x3 -- the LABELLED bf16x3 variant of the Winograd F(2x2,3x3) convolution (csrc/conv_wino_x3.hip): every f32 product of
+the Winograd domain as six bf16 products of an exact three-way split on the 16-bit matrix cores, f32 accumulation.
+
+What "f32-equivalent" means here and how it is held: the variant replaces rpe_conv_wino (csrc/conv_wino.hip, f32 matrix cores), with which
+it shares the f32 Winograd transforms bit for bit; only the products differ.  So its error against the f64 convolution is compared with
+THAT kernel's on the same data -- RMS at most 1.25x (measured 0.85-0.88x: the split drops terms below 2^-24 of a product and
+accumulates in the matrix core's f32 adder tree instead of a serial fma chain) -- and, like rpe_conv_wino itself, with the direct f32
+kernel's (RMS <= 3x, max <= 4x: the Winograd transforms' cost, test_gpu_conv.py).  The f64 bars of test_gpu_conv.py's Winograd tests are
+kept unchanged for every epilogue."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_conv import _errs, _rand, _tol, _trained_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('cin,cout,h,w,b', [(256, 192, 64, 80, 2), (128, 64, 64, 80, 1), (256, 126, 44, 48, 2), (128, 256, 32, 40, 1),
+                                            (16, 20, 6, 12, 3), (64, 96, 128, 160, 1), (32, 32, 16, 16, 2), (48, 160, 18, 20, 1)])
+def test_x3_matches_f64(rpe, cin, cout, h, w, b):
+    """The update block's shapes, ragged channel counts (126; 20), the trailing 32-channel tile (96, 160, 32), maps that are not whole
+    16 x 16 patches (44 x 48, 6 x 12, 18 x 20), one K step (cin = 16).  Same bar as test_winograd_3x3_matches_f64.  Destinations are
+    channel slices; out2 receives a copy; neighbours stay untouched; the prepared launcher gives the same bits."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + h)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, 3, 3, s=0.05), _rand(rng, cout, s=0.5)
+    assert ops.PackedWinoX3.supported(wt, h, w)
+    px = ops.PackedWinoX3(wt.cuda(), bias.cuda())
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    obuf = torch.full((b, cout + 8, h, w), -7.0, device='cuda')
+    o2buf = torch.full((b, cout + 4, h, w), -7.0, device='cuda')
+    xbuf = torch.zeros(b, cin + 4, h, w, device='cuda')                      # the input is a channel slice too (16-byte aligned planes)
+    xbuf[:, 4:] = x.cuda()
+    ops.conv_wino(xbuf[:, 4:], px, ops.CONV_RELU, obuf[:, 4:4 + cout], out2=o2buf[:, 4:])
+    got = obuf[:, 4:4 + cout].cpu().double()
+    assert (got - ref.clamp_min(0)).abs().max() < 3 * _tol(x, wt)
+    assert torch.equal(obuf[:, 4:4 + cout], o2buf[:, 4:])
+    assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all() and (o2buf[:, :4] == -7.0).all()
+    lin = ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    assert (lin.cpu().double() - ref).abs().max() < 3 * _tol(x, wt)
+    out3 = torch.empty(b, cout, h, w, device='cuda')
+    ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, out3, prepare=True)()
+    assert torch.equal(out3, lin)
+    # deterministic: fixed summation order, no atomics
+    assert torch.equal(ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda')), lin)
+
+
+def test_x3_rejects_what_it_cannot_do(rpe):
+    from rpe_amd import ops
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWinoX3(torch.zeros(8, 24, 3, 3, device='cuda'))            # cin % 16
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWinoX3(torch.zeros(8, 16, 1, 5, device='cuda'))
+    px = ops.PackedWinoX3(torch.zeros(8, 16, 3, 3, device='cuda'))
+    for hh, ww in ((7, 12), (8, 10)):                                         # odd height; rows that are not whole 16-byte quads
+        with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
+            ops.conv_wino(torch.zeros(1, 16, hh, ww, device='cuda'), px, ops.CONV_RELU, torch.empty(1, 8, hh, ww, device='cuda'))
+    shifted = torch.zeros(16 * 6 * 12 + 1, device='cuda')[1:].view(1, 16, 6, 12)        # an input that is not 16-byte aligned
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
+        ops.conv_wino(shifted, px, ops.CONV_RELU, torch.empty(1, 8, 6, 12, device='cuda'))
+
+
+@pytest.mark.parametrize('c,h,w,b', [(64, 64, 80, 3), (96, 44, 48, 2), (128, 32, 40, 2)])
+def test_x3_encoder_epilogues_match_f64(rpe, c, h, w, b):
+    """The encoders' epilogues on the variant, same references and bars as test_winograd_encoder_epilogues_match_f64: folded batch norm +
+    ReLU + residual + ReLU; instance-norm moments (the SAME record regions and layout as rpe_conv_wino: the consumers do not know which
+    kernel ran -- counts equal exactly, means / M2 to rounding); the input normalised + ReLU'd on the way in (pre_norm)."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(c + h + 1)
+    x, wt, bias = _rand(rng, b, c, h, w), _rand(rng, c, c, 3, 3, s=0.05), _rand(rng, c, s=0.5)
+    res = _rand(rng, b, c, h, w).abs()
+    scale, shift = _rand(rng, c).abs() + 0.5, _rand(rng, c, s=0.3)
+    px, pw = ops.PackedWinoX3(wt.cuda(), None), ops.PackedWino(wt.cuda(), None)
+    conv = F.conv2d(x.double(), wt.double(), None, padding=1)
+    ref = (res.double() + (conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]).clamp_min(0)).clamp_min(0)
+    got = ops.conv_wino(x.cuda(), px, ops.CONV_RELU, torch.empty(b, c, h, w, device='cuda'), scale=scale.cuda(), bias=shift.cuda(), residual=res.cuda())
+    assert (got.cpu().double() - ref).abs().max() < 3 * _tol(x, wt) * 2.5
+    pre = conv + bias.double()[None, :, None, None]
+    mean, var = pre.mean((2, 3)), pre.var((2, 3), unbiased=False)
+    stats, stats32 = ops.conv_wino_stats_buffer(b, c, h, w, 'cuda'), ops.conv_wino_stats_buffer(b, c, h, w, 'cuda')
+    stats.tensor.fill_(float('nan'))
+    raw = ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=stats)
+    raw32 = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=stats32)
+    assert (raw.cpu().double() - pre).abs().max() < 3 * _tol(x, wt)
+    st, st32 = stats.cpu().double(), stats32.cpu().double()                  # tile-major: (b, records, c, 3)
+    assert not torch.isnan(st).any()                                          # every record of the f32 kernel's layout is written
+    assert torch.equal(st[..., 0], st32[..., 0])                              # the same pixel counts, record by record
+    assert float(st[..., 0].sum(1).min()) == float(st[..., 0].sum(1).max()) == h * w
+    live = st[..., 0] > 0
+    assert float((st[..., 1] - st32[..., 1])[live].abs().max()) < 1e-4 and float(((st[..., 2] - st32[..., 2])[live].abs() / (st32[..., 2][live] + 1e-3)).max()) < 1e-3
+    mi = ops.instnorm_finalize(stats, h * w, eps=1e-5).cpu().double()
+    assert float((mi[..., 0] - mean).abs().max()) < 1e-5 and float((mi[..., 1] * torch.sqrt(var + 1e-5) - 1).abs().max()) < 2e-5
+    ref2 = (res.double() + ((pre - mean[:, :, None, None]) / torch.sqrt(var + 1e-5)[:, :, None, None]).clamp_min(0)).clamp_min(0)
+    got2 = ops.instnorm_apply(raw, stats, eps=1e-5, relu=True, residual=res.cuda())
+    inv = float((1 / torch.sqrt(var + 1e-5)).max())
+    assert (got2.cpu().double() - ref2).abs().max() < (3 * _tol(x, wt) + 2e-6) * inv * 2
+    m_i = torch.stack((_rand(rng, b, c, s=0.3), _rand(rng, b, c).abs() + 0.5), dim=-1).contiguous()
+    xin = ((x.double() - m_i[..., 0].double()[:, :, None, None]) * m_i[..., 1].double()[:, :, None, None]).clamp_min(0)
+    ref3 = F.conv2d(xin, wt.double(), bias.double(), padding=1)
+    got3 = ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), pre_norm=m_i.cuda())
+    assert (got3.cpu().double() - ref3).abs().max() < 3 * _tol(xin.float(), wt) + 1e-5
+    # moments + pre_norm together (fnet's second convolution of a block), against the f32 kernel
+    s_a, s_b = ops.conv_wino_stats_buffer(b, c, h, w, 'cuda'), ops.conv_wino_stats_buffer(b, c, h, w, 'cuda')
+    g_a = ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=s_a, pre_norm=m_i.cuda())
+    g_b = ops.conv_wino(x.cuda(), pw, ops.CONV_LINEAR, torch.empty(b, c, h, w, device='cuda'), bias=bias.cuda(), stats=s_b, pre_norm=m_i.cuda())
+    assert (g_a - g_b).abs().max() < 3 * _tol(xin.float(), wt) + 1e-5
+    ma, mb = ops.instnorm_finalize(s_a, h * w).cpu(), ops.instnorm_finalize(s_b, h * w).cpu()
+    assert float((ma[..., 0] - mb[..., 0]).abs().max()) < 1e-5 and float(((ma[..., 1] - mb[..., 1]).abs() / mb[..., 1]).max()) < 2e-5
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [(256, 192, 64, 80), (128, 256, 64, 80), (64, 64, 128, 160), (256, 126, 44, 48)])
+@pytest.mark.parametrize('flow_channels', [False, True])
+def test_x3_error_relative_to_the_f32_kernels_on_trained_like_statistics(rpe, cin, cout, h, w, flow_channels):
+    """Trained-like statistics (post-ReLU activations with a positive mean, a saturated hidden state, +-50 px flow channels, heavy-tailed
+    weights with outliers: test_gpu_conv._trained_like), error against the f64 convolution:
+      * RMS at most 1.25x the f32 Winograd kernel's (rpe_conv_wino: the kernel the variant replaces) -- the f32-equivalence bar (measured
+        0.85-0.88x);
+      * max at most 1.25x the larger of the two f32 kernels' maxima (the maximum over ~10^6 outputs is an extreme-value statistic: against
+        rpe_conv_wino alone it reads 0.8-1.3x from one seed to the next while staying at 0.25-0.55x the direct kernel's);
+      * at most 3x (RMS) / 4x (max) the direct f32 kernel's (rpe_conv_fused), the bar rpe_conv_wino itself is held to."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout * 7 + h + int(flow_channels))
+    b = 2
+    x, wt, bias = _trained_like(rng, b, cin, cout, 3, 3, h, w, flow_channels)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    direct = ops.conv_fused(x.cuda(), ops.PackedConv(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    wino = ops.conv_wino(x.cuda(), ops.PackedWino(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    x3 = ops.conv_wino(x.cuda(), ops.PackedWinoX3(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    dmax, drms = _errs(direct, ref)
+    wmax, wrms = _errs(wino, ref)
+    xmax, xrms = _errs(x3, ref)
+    print(f'3x3 {cin}->{cout} flow_channels={flow_channels}: |out| {float(ref.abs().max()):.1f}; direct max {dmax:.2e} rms {drms:.2e}; f32 winograd max {wmax:.2e} '
+          f'rms {wrms:.2e}; bf16x3 winograd max {xmax:.2e} rms {xrms:.2e}; x3 / f32-winograd {xmax / wmax:.2f} / {xrms / wrms:.2f}; x3 / direct {xmax / dmax:.2f} / {xrms / drms:.2f}')
+    assert xrms <= 1.25 * wrms and xmax <= 1.25 * max(wmax, dmax)
+    assert xrms <= 3.0 * drms and xmax <= 4.0 * dmax
+
+
+def test_x3_special_values(rpe):
+    """Inf / NaN inputs poison exactly the outputs they reach (no zero-times-Inf NaNs elsewhere: out-of-map patch elements are zeros, never
+    clamped copies), and subnormal-scale data comes through: the truncation split is exact down to the f32 subnormal range."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(5)
+    x, wt = _rand(rng, 1, 16, 16, 16), _rand(rng, 32, 16, 3, 3, s=0.05)
+    x[0, 3, 7, 9] = float('inf'); x[0, 5, 0, 0] = float('nan')
+    px = ops.PackedWinoX3(wt.cuda(), None)
+    got = ops.conv_wino(x.cuda(), px, ops.CONV_LINEAR, torch.empty(1, 32, 16, 16, device='cuda')).cpu()
+    bad = ~torch.isfinite(got)
+    reach = torch.zeros(16, 16, dtype=torch.bool)
+    reach[5:11, 7:13] = True                    # the 2x2 tiles whose 4x4 patches contain (7, 9): rows 6..9 / cols 8..11 as outputs, +-1 tile
+    reach[0:2, 0:2] = True
+    assert bad[0].any(0)[7, 9] and bad[0].any(0)[0, 0]
+    assert not bad[0].any(0)[~reach].any()
+    xs = (_rand(rng, 1, 16, 16, 16) * 1e-30).cuda()
+    ref = F.conv2d(xs.cpu().double(), wt.double(), None, padding=1)
+    gs = ops.conv_wino(xs, px, ops.CONV_LINEAR, torch.empty(1, 32, 16, 16, device='cuda')).cpu().double()
+    assert (gs - ref).abs().max() < 1e-5 * ref.abs().max()

@@ -62,9 +62,43 @@ def test_raft_matches_oracle(models):
     assert low[-1].shape == (2, 2, H // 8, W // 8) and float((low[-1].cpu() - olow[-1]).abs().max()) < 5e-3
 
 
+def test_raft_matches_oracle_with_the_bf16x3_variant(models, monkeypatch):
+    """raft.CONV_BF16X3 (bench.py --conv-bf16x3): convc2 / conv / FlowHead.conv1 / the mask head's 3x3 through rpe_conv_wino_x3 and the
+    correlation through k_corr_build_x3.  Same pair, same oracle, same bars as test_raft_matches_oracle: the variant is f32-equivalent."""
+    model, om, synth = models
+    from rpe_amd import ops, raft
+    fr = synth.stereo_frames(3, 1, H, W)
+    i1 = torch.cat((fr['image1l'], fr['image2l']))
+    i2 = torch.cat((fr['image2l'], fr['image2r']))
+    base, hid0, _ = model.flow(i1.cuda(), i2.cuda(), all_flows=True)
+    ran = []
+    real = ops.conv_wino
+
+    def spy(x, pw, *a, **k):
+        ran.append(type(pw).__name__)
+        return real(x, pw, *a, **k)
+    monkeypatch.setattr(raft, 'CONV_BF16X3', True)
+    monkeypatch.setattr(ops, 'conv_wino', spy)
+    try:
+        flows, hid, ctx = model.flow(i1.cuda(), i2.cuda(), all_flows=True)
+    finally:
+        monkeypatch.undo()
+        model.flow(i1.cuda(), i2.cuda())                     # back on the f32 packings for the tests that follow
+    assert ran.count('PackedWinoX3') >= 4                    # convc2, conv, FlowHead.conv1 (prepared once), the mask head
+    with torch.no_grad():
+        oflows, ohid, octx = om.flow(i1, i2)
+    d0 = float((flows[0].cpu() - oflows[0]).abs().max())
+    d11 = float((flows[-1].cpu() - oflows[-1]).abs().max())
+    dv = float((flows[-1] - base[-1]).abs().max())
+    print(f'bf16x3 variant: flow diff vs oracle iter0 {d0:.2e} px, iter11 {d11:.2e} px; vs the f32 route {dv:.2e} px')
+    assert d0 < 1e-4 and d11 < 1e-3
+    assert float((hid.cpu() - ohid).abs().max()) < 5e-3 and float((ctx.cpu() - octx).abs().max()) < 1e-3
+
+
 def test_fused_and_library_update_block_agree(models, monkeypatch):
-    """The update block has two GPU routes: fused implicit-GEMM convolutions (map width % 4 == 0) and the library
-    convolutions + separate gate / bias kernels (any width).  Same weights, same pair -> same flow to round-off."""
+    """The update block has two GPU routes: the tuned convolutions (rpe_conv_wino / _wino1d / _conv1x1 / _conv_fused with fused gate and
+    bias epilogues; map width % 4 == 0) and the generic kernel rpe_conv_direct + separate gate / bias kernels (any width; no library
+    convolution on either route).  Same weights, same pair -> same flow to round-off."""
     model, om, synth = models
     fr = synth.stereo_frames(5, 1, H, W)
     i1, i2 = fr['image1l'].cuda(), fr['image2l'].cuda()
