@@ -666,6 +666,26 @@ def deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_
     finally:
         model.pose_head.problem.lbgfs_iters = keep
     out['tracker_fps'] = F / dt
+    # the same walk with the next frame's encoders prefetched on a side stream (PoseEstimator.submit / result; poses bit-identical)
+    model.pose_head.problem.lbgfs_iters = 20
+    try:
+        for rep in range(2):
+            est = pose_estimator.PoseEstimator(slam, frames['K'][0], 7.2 * 250.0, model, (W, H)).to(dev)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                est.submit(seq[0][0], seq[0][1], seq[0][2].clone())
+                for i in range(F):
+                    if i + 1 < F:
+                        est.submit(seq[i + 1][0], seq[i + 1][1], seq[i + 1][2].clone())
+                    est.result()
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t
+    finally:
+        model.pose_head.problem.lbgfs_iters = keep
+    out['tracker_prefetch_fps'] = F / dtp
+    out['tracker_prefetch_config'] = 'the same frames through PoseEstimator.submit / result: frame t+1 is encoded on a side stream while frame t\'s update loop runs (poses bit-identical)'
     # the same 24 frames in chunks of 16 (PoseEstimator.forward_chunk: one RAFT pass per chunk, bit-identical poses; what
     # SequenceTracker / bench.py --mode sequence run)
     L, R, Mk = (torch.cat([f[i] for f in seq]) for i in range(3))

@@ -82,6 +82,8 @@ class PoseEstimator(torch.nn.Module):
         # encoders normalise per sample); set reuse_features=False to re-encode like the reference does
         self.reuse_features = config.get('reuse_features', True)
         self._enc_cache = None
+        self._pending = []                                            # submit() / result(): frames whose encoders are already on the side stream
+        self._prefetch_stream = None
 
     @property
     def device(self):
@@ -92,18 +94,71 @@ class PoseEstimator(torch.nn.Module):
         self.last_pose = self._init_pose
         self.frame = self.last_frame = None
         self._enc_cache = None
+        self._pending = []
         return self
 
     @torch.no_grad()
-    def forward(self, limg, rimg, mask):
+    def submit(self, limg, rimg, mask):
+        """Pipelined form of ``forward`` for a caller that has the next frame before it needs this one's pose (a video file, a camera
+        queue; scripts/infer_trajectory.py:57,71-77 iterates a DataLoader): ``submit(frame t+1)`` then ``result()`` -> frame t's pose.
+        submit() puts the frame's encoder work (PoseNet.encode_frame: fnet on both images, cnet on the left one -- it depends on nothing
+        else) on a side stream at once; the frame waits in a queue until result() runs the rest of ``forward`` for the oldest queued
+        frame.  With frame t+1 submitted before result() is called for frame t, its encoders (~1.3 ms of launches) run beside frame t's
+        update loop, whose ~100 launches per iteration leave most of the chip idle at batch 1.  Same kernels, same inputs: the poses are
+        bit-identical to calling forward() frame by frame (tests/test_gpu_pipeline.py).  Requires reuse_features (the default)."""
+        if not self.reuse_features:
+            raise RuntimeError('submit / result reuse the encoder outputs across frames: construct the estimator with reuse_features=True')
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(limg.device))          # the images are ready on the caller's stream NOW (recorded later, the
+        self._pending.append([limg, rimg, mask, None, None, ready])   #  event would sit behind the running frame's whole queue)
+        if len(self._pending) == 1:
+            self._start_encoders(self._pending[0])            # nothing is running that it could hide behind: start at once
+
+    def _start_encoders(self, item):
+        """Frame ``item``'s encoder work onto the side stream (once)."""
+        if item[3] is not None:
+            return
+        limg, rimg = item[0], item[1]
+        dev = limg.device
+        if self._prefetch_stream is None or self._prefetch_stream.device != dev:
+            self._prefetch_stream = torch.cuda.Stream(device=dev)
+        side = self._prefetch_stream
+        with torch.cuda.stream(side):
+            side.wait_event(item[5])
+            item[3] = self.model.encode_frame(limg, rimg)
+            item[4] = torch.cuda.Event()
+            item[4].record(side)
+        for t in (limg, rimg):
+            t.record_stream(side)
+
+    @torch.no_grad()
+    def result(self):
+        """``forward`` for the oldest submitted frame, on its prefetched encoder outputs.  The NEXT queued frame's encoders are started
+        once this frame's work has been handed to the GPU and before the host waits for its success flag: they then run beside the tail
+        of this frame -- the last update iterations, the weight heads and the 20-iteration solve, whose launches occupy a few
+        workgroups each."""
+        if not self._pending:
+            raise RuntimeError('result() without a submitted frame')
+        self._start_encoders(self._pending[0])
+        limg, rimg, mask, enc, done, _ = self._pending.pop(0)
+        cur = torch.cuda.current_stream(limg.device)
+        cur.wait_event(done)
+        for t in enc.values():
+            t.record_stream(cur)                              # allocated on the side stream, consumed (and freed) on the caller's
+        return self.forward(limg, rimg, mask, _enc=enc)
+
+    @torch.no_grad()
+    def forward(self, limg, rimg, mask, _enc=None):
         """limg, rimg: (1,3,h,w) 0..255; mask: (1,1,h,w) True = valid.  Returns (absolute pose SE3, None, flow, weights)."""
         self.last_pose = self.last_pose.to(limg.device)
         self.last_frame = self.frame
         self.frame = Frame(limg, rimg, mask=mask)
-        rel_pose, ret_frame, flow, weights = self.get_pose_f2f()
+        rel_pose, ret_frame, flow, weights = self.get_pose_f2f(_enc)
         # :81-91 in one launch (ops.pose_gate_chain): the gate isnan | |log| > 0.1 -> identity, de-normalisation of the depth scaling and
         # last_pose <- last_pose * rel^-1, with ONE host synchronisation (the success flag) instead of a dozen element-wise launches and two
         rel, pose, ok = ops.pose_gate_chain(rel_pose.data.reshape(1, 7), self.last_pose.data, self._inv_scale, 1.0e-1)
+        if self._pending:
+            self._start_encoders(self._pending[0])            # (submit / result) the next frame's encoders, before the host waits for this one
         self.success = bool(ok[0])
         if not self.success:
             warnings.warn('pose estimation not converged, skip.', RuntimeWarning)                 # :82
@@ -143,12 +198,12 @@ class PoseEstimator(torch.nn.Module):
         self.frame = Frame(limgs[c - 1:], rimgs[c - 1:], depth=depth2[c - 1:] / self.scale, mask=masks[c - 1:], flow=stereo_flow[c - 1:])
         return poses, None, flow, weights
 
-    def get_pose_f2f(self):
+    def get_pose_f2f(self, enc=None):
         flow = None
         if self.last_frame is None:
             rel = SE3.IdentityLike(self.last_pose)
             depth, stereo_flow, valid, cache = self.model.flow2depth(self.frame.img, self.frame.rimg,
-                                                                     self.baseline * self.scale, ret_cache=True)
+                                                                     self.baseline * self.scale, ret_cache=True, enc=enc)
             self._enc_cache = cache if self.reuse_features else None
             self.frame.depth = depth / self.scale
             self.frame.flow = stereo_flow
@@ -157,7 +212,7 @@ class PoseEstimator(torch.nn.Module):
             self.last_frame.img, self.frame.img, self.intrinsics, self.baseline * self.scale,
             depth1=self.last_frame.depth * self.scale, image2r=self.frame.rimg, mask1=self.last_frame.mask,
             mask2=self.frame.mask, stereo_flow1=self.last_frame.flow, ret_details=True,
-            cache1=self._enc_cache, ret_cache=True)
+            cache1=self._enc_cache, ret_cache=True, enc2=enc if self._enc_cache is not None else None)
         self._enc_cache = cache if self.reuse_features else None
         rel = SE3(rel.data.reshape(1, 7))
         self.frame.depth = depth2 / self.scale

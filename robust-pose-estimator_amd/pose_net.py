@@ -41,13 +41,22 @@ class PoseNet(nn.Module):
         return self
 
     @torch.no_grad()
-    def flow2depth(self, imagel, imager, baseline, upsample=True, ret_cache=False):
+    @torch.no_grad()
+    def encode_frame(self, imagel, imager):
+        """The encoder work of one new stereo frame -- fnet(left | right) and cnet(left) -- as ``infer(..., cache1=..., enc2=...)`` and
+        ``flow2depth(..., enc=...)`` accept it: {'f': (2n,256,h/8,w/8), 'c': (n,256,h/8,w/8)}.  It depends on the frame's two images
+        only, so a tracker can run it for frame t+1 (on a side stream) while frame t's update loop is still on the GPU
+        (PoseEstimator.submit / result); the kernels and their inputs are the same, the results bit-identical."""
+        f, c = self._encode_both((imagel, imager), imagel)
+        return dict(f=f, c=c)
+
+    def flow2depth(self, imagel, imager, baseline, upsample=True, ret_cache=False, enc=None):
         """pose_net.py:127-135 -> (depth (n,1,h,w), stereo flow (n,2,h,w), valid (n,1,h,w) bool).
         ``upsample=False``: everything at 1/8 resolution, the flow in 1/8-pixel units and the depth divided by 8 (:131-132;
         a division by a power of two commutes with the rounding of b / -flow.x, so the kernel is handed b / 8).
         ``ret_cache`` additionally returns the encoder outputs of ``imagel`` for reuse by the next ``infer``."""
         n = imagel.shape[0]
-        f, cn = self._encode_both((imagel, imager), imagel)
+        f, cn = (enc['f'], enc['c']) if enc is not None else self._encode_both((imagel, imager), imagel)
         flow = self.flow(None, None, upsample=upsample, fmaps=(f[:n], f[n:]), cnet=cn)[0][-1]
         depth, valid = ops.flow2depth(flow, baseline if upsample else baseline / 8.0)
         if ret_cache:
@@ -100,9 +109,10 @@ class PoseNet(nn.Module):
         return self.flow.encode_features(feature_images), self.flow.encode_context(context_images)
 
     @torch.no_grad()
-    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None, heads=True):
+    def stages(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1=None, heads=True, enc2=None):
         """Every stage of infer() before the solve.  ``cache1`` = {'fmap','cnet'} of image1l from the previous call
-        (streaming: frame t's image2l is frame t+1's image1l), so only the two new images are encoded."""
+        (streaming: frame t's image2l is frame t+1's image1l), so only the two new images are encoded -- or not even those when
+        ``enc2`` = encode_frame(image2l, image2r) was computed ahead of the call (needs cache1)."""
         n = image1l.shape[0]
         intrinsics = intrinsics.expand(n, 3, 3).contiguous()
         baseline = baseline.expand(n).contiguous()
@@ -115,7 +125,7 @@ class PoseNet(nn.Module):
             fmaps = (f[:2 * n], f[n:])
             c2l = cn[n:]
         else:
-            f, c2l = self._encode_both((image2l, image2r), image2l)
+            f, c2l = (enc2['f'], enc2['c']) if enc2 is not None else self._encode_both((image2l, image2r), image2l)
             f2l = f[:n]
             fmaps = (torch.cat((cache1['fmap'], f2l), dim=0), f)
             cn = torch.cat((cache1['cnet'], c2l), dim=0)
@@ -143,8 +153,10 @@ class PoseNet(nn.Module):
 
     @torch.no_grad()
     def infer(self, image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1,
-              ret_details=False, cache1=None, ret_cache=False):
-        s = self.stages(image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1)
+              ret_details=False, cache1=None, ret_cache=False, enc2=None):
+        if enc2 is not None and cache1 is None:
+            raise ValueError('infer: enc2 (the new frame encoded ahead of the call) needs cache1 (the previous frame\'s encoder outputs)')
+        s = self.stages(image1l, image2l, intrinsics, baseline, depth1, image2r, mask1, mask2, stereo_flow1, cache1, enc2=enc2)
         mask2.copy_(s['mask2'])                               # `mask2 &= valid` mutates the caller's tensor (:77)
         n = image1l.shape[0]
         lw = self.loss_weight.detach()[None, :].repeat(n, 1)

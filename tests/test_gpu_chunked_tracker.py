@@ -47,6 +47,40 @@ def _walk(seq, chunk, first, last):
                 pose=est.last_pose.data.clone(), warnings=n_warn)
 
 
+def test_prefetched_encoders_are_bit_identical_to_frame_at_a_time(seq):
+    """PoseEstimator.submit / result: frame t+1's encoders run on a side stream while frame t's update loop is on the GPU (the reference's
+    frame-at-a-time deployment, scripts/infer_trajectory.py:57,71-77, with the next frame read one iteration early).  Same kernels on the
+    same inputs: every absolute pose, gate decision, relative pose and the Frame left behind equal the plain forward() walk bit for
+    bit -- on the ten-frame sequence with the broken frame 5 (its NaNs reach pairs 4 and 5, both gated)."""
+    from rpe_amd import pose_estimator
+    model, K, (L, R, M) = seq
+    make = lambda: pose_estimator.PoseEstimator(CFG, K, 7.2 * 250.0, model, (W, H)).cuda()
+    get = lambda t: (L[t:t + 1], R[t:t + 1], M[t:t + 1].clone())
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        plain = make()
+        ref = []
+        for t in range(10):
+            P, _, _, _ = plain(*get(t))
+            ref.append((P.data.clone(), plain.success, plain.last_rel_pose.data.clone() if t else None))
+        piped = make()
+        got = []
+        piped.submit(*get(0))
+        for t in range(10):
+            if t + 1 < 10:
+                piped.submit(*get(t + 1))                       # the next frame's encoders start before this frame's pose is asked for
+            P, _, _, _ = piped.result()
+            got.append((P.data.clone(), piped.success, piped.last_rel_pose.data.clone() if t else None))
+    assert [g[1] for g in got] == [r[1] for r in ref] and [r[1] for r in ref][5:7] == [False, False]
+    for t, (g, r) in enumerate(zip(got, ref)):
+        assert torch.equal(g[0], r[0]), t
+        assert t == 0 or torch.equal(g[2], r[2]), t
+    for k in ('depth', 'mask', 'flow'):
+        assert torch.equal(getattr(piped.frame, k), getattr(plain.frame, k)), k
+    with pytest.raises(RuntimeError):
+        piped.result()                                          # nothing submitted
+
+
 def test_chunked_block_walk_is_bit_identical_to_frame_at_a_time(seq):
     base = _walk(seq, 1, 0, 9)
     assert base['ok'].tolist()[4:6] == [False, False] and bool(base['ok'][:4].all())     # both gated pairs, and converged ones
