@@ -194,19 +194,22 @@ def timed_region(step, steps, warmup, dev, dist):
     def barrier():
         if dist is not None:
             dist.barrier()
+    def sync():
+        if torch.device(dev).type == 'cuda':             # (the gloo tests drive the sequence pass on CPU tensors)
+            torch.cuda.synchronize()
     out = None
     for _ in range(warmup):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     busy = time.perf_counter() - t0                  # this rank's own work, without waiting for the others
     barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     own = busy / max(1, steps)
     RANK_MS.clear()
@@ -225,19 +228,32 @@ def timed_region(step, steps, warmup, dev, dist):
     return elapsed, out
 
 
-def run_sequence(args, rank, world, dev, dist):
-    """BASELINE config 4: a stereo sequence sharded over the ranks in contiguous blocks with a one-frame halo
-    (rpe_amd.sharding, scripts/infer_trajectory.py:57,71-97 + core/pose/pose_estimator.py:81-91 of the reference),
-    every rank walking its block in chunks of --seq-chunk frames, ONE all-gather of the relative poses, then gate + prefix product.
-    A step = tracking the whole sequence once; value = frames/s over the whole job."""
+def sequence_pass(track, n_frames, rank, steps, warmup, dev, dist):
+    """K timed walks of a sharded sequence: ``track()`` -> (poses (F,7), rel, ok) on every rank (sharding.SequenceTracker.track or
+    sharding.track_sharded: each rank's block, ONE all-gather of the relative poses, gate + prefix product), then the check that every
+    rank holds the SAME trajectory (MIN and MAX over ranks of a checksum agree).  Used by --mode sequence and, when world > 1, by the
+    batch mode's extra line (the number that exercises the collective); the gloo test drives it on the CPU oracle."""
+    elapsed, (poses, rel, ok) = timed_region(track, steps, warmup, dev, dist)
+    chk = torch.nan_to_num(poses.double()).mul(torch.arange(1, poses.numel() + 1, device=poses.device, dtype=torch.float64).reshape(poses.shape)).sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = bool(float(lo) == float(hi))
+    if not same:
+        print(f'bench.py sequence pass: rank {rank}: trajectory checksums differ across ranks ({float(lo)!r} .. {float(hi)!r})', file=sys.stderr)
+    return {'elapsed': elapsed, 'frames_per_s': n_frames * steps / elapsed if elapsed > 0 else 0.0, 'poses': poses, 'rel': rel, 'ok': ok, 'same': same,
+            'checksum': float(chk)}
+
+
+def sequence_tracker(args, rank, world, dev, frames_per_gpu):
+    """(SequenceTracker, total frames) over synthetic frames sharded in contiguous blocks with a one-frame halo, this rank's frames in HBM."""
     from rpe_amd import pose_estimator, pose_net, sharding, synth
-    H, W, Fg = args.height, args.width, args.seq_frames
-    F = Fg * world
+    H, W = args.height, args.width
+    F = frames_per_gpu * world
     cfg = synth.model_config(H, W, iters=args.raft_iters, lbgfs_iters=20, solver=args.solver)   # infer_f2f.yaml:11
     model = synth.init_synthetic_weights(pose_net.PoseNet(cfg), seed=1234).eval().to(dev)
     slam = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=20, conf_weighing=True)
-    blocks = sharding.block_partition(F - 1, world)
-    s, e = blocks[rank]
+    s, e = sharding.block_partition(F - 1, world)[rank]
     cache = {}
     for t in range(s, e + 1):                               # this rank's frames incl. the halo, resident in HBM
         fr = synth.stereo_frames(seed=5000 + t, n=1, h=H, w=W)
@@ -245,22 +261,25 @@ def run_sequence(args, rank, world, dev, dist):
     K = synth.intrinsics(H, W)
     make = lambda: pose_estimator.PoseEstimator(slam, K, 7.2 * 250.0, model, (W, H)).to(dev)
     get = lambda t: (cache[t][0], cache[t][1], cache[t][2].clone())
-    tracker = sharding.SequenceTracker(make, get, chunk=args.seq_chunk)
+    return sharding.SequenceTracker(make, get, chunk=args.seq_chunk), F
+
+
+def run_sequence(args, rank, world, dev, dist):
+    """BASELINE config 4: a stereo sequence sharded over the ranks in contiguous blocks with a one-frame halo
+    (rpe_amd.sharding, scripts/infer_trajectory.py:57,71-97 + core/pose/pose_estimator.py:81-91 of the reference),
+    every rank walking its block in chunks of --seq-chunk frames, ONE all-gather of the relative poses, then gate + prefix product.
+    A step = tracking the whole sequence once; value = frames/s over the whole job."""
+    H, W, Fg = args.height, args.width, args.seq_frames
+    tracker, F = sequence_tracker(args, rank, world, dev, Fg)
     import warnings
 
     def step():
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')                 # unrelated synthetic frames: many pairs fail the |log| gate
             return tracker.track(F, rank, world)
-    elapsed, (poses, rel, ok) = timed_region(step, args.steps, args.warmup, dev, dist)
-    # every rank must hold the SAME trajectory after the all-gather + prefix product: MIN and MAX over ranks of a checksum agree
-    chk = torch.nan_to_num(poses.double()).mul(torch.arange(1, poses.numel() + 1, device=dev, dtype=torch.float64).reshape(poses.shape)).sum().reshape(1)
-    lo, hi = chk.clone(), chk.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    same = bool(float(lo) == float(hi))
+    seq = sequence_pass(step, F, rank, args.steps, args.warmup, dev, dist)
+    elapsed, poses, ok, same, chk = seq['elapsed'], seq['poses'], seq['ok'], seq['same'], seq['checksum']
     if not same:                                            # a sharded run whose ranks disagree about the trajectory is a failed run
-        print(f'bench.py --mode sequence: rank {rank}: trajectory checksums differ across ranks ({float(lo)!r} .. {float(hi)!r})', file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
         sys.exit(3)
@@ -278,7 +297,7 @@ def run_sequence(args, rank, world, dev, dist):
                    'frames': F, 'frames_per_gpu': Fg, 'chunk': args.seq_chunk, 'parallelism': f'sequence blocks x{world}'},
         'rank_ms_per_step': dict(RANK_MS),
         'poses_finite': bool(torch.isfinite(poses).all()), 'pairs_accepted': int(ok.sum()), 'poses_shape': list(poses.shape),
-        'poses_equal_on_all_ranks': same, 'poses_checksum': float(chk),
+        'poses_equal_on_all_ranks': same, 'poses_checksum': chk,
     }
 
 
@@ -420,6 +439,22 @@ def run_batch(args, rank, world, dev, dist):
         step()
     elapsed, out = timed_region(timed_step, args.steps, 0, dev, dist)
 
+    seq_line = None
+    if world > 1 and dist is not None and not args.no_extras:
+        # The batch metric shards frames with no data-path collective; the multi-GPU number that exercises the all-gather of relative poses
+        # and the prefix product is a SEQUENCE walk.  A short one (one chunk of 16 + halo per GPU, one timed walk) on every rank, after
+        # the timed region, so that a scaling run's line carries it.  (N > 1 has never been run on hardware in this pool.)
+        import warnings
+        tracker, Fs = sequence_tracker(args, rank, world, dev, 17)
+
+        def seq_step():
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                return tracker.track(Fs, rank, world)
+        sp = sequence_pass(seq_step, Fs, rank, 1, 1, dev, dist)
+        seq_line = {'sequence_frames_per_s': sp['frames_per_s'], 'sequence_frames': Fs, 'sequence_poses_equal_on_all_ranks': sp['same'],
+                    'sequence_config': f'SequenceTracker.track, {Fs} frames ({17} per GPU, contiguous blocks + 1-frame halo, chunks of {args.seq_chunk}), one all-gather of (frames,8) f32; 1 warm-up + 1 timed walk'}
+        del tracker
     if rank != 0:
         return None
     pose, _, depth2, weights, time_flow, stereo_flow2 = out
@@ -496,6 +531,8 @@ def run_batch(args, rank, world, dev, dist):
                             'counts': 'k_conv_igemm + k_conv1x1 + k_conv_wino + k_conv_wino1d (executed) + k_corr_build; stems, heads and element-wise passes not counted'}
     if args.conv_bf16x3:
         res['conv_bf16x3_families'] = X3_FAMILIES
+    if seq_line is not None:
+        res.update(seq_line)
     if world == 1 and not args.no_extras and not args.conv_bf16x3 and not args.corr_bf16x3 and not args.fp16_features:
         # the labelled bf16x3 variant of the same step, measured AFTER the timed region (the headline above is pure f32)
         raft_mod.CONV_BF16X3 = True

@@ -45,8 +45,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifdef X3_TIMING
 // Experiment hook (tools/build_variant.sh ... -DX3_TIMING): s_memtime stamps at the stage boundaries of the main loop, summed over the
 // steps of one mid-grid workgroup's wave 0; read back with rpe_debug_x3_timing.
-__device__ unsigned long long g_x3_timing[16];
-extern "C" int rpe_debug_x3_timing(unsigned long long* out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_x3_timing), 128) == hipSuccess ? 0 : -1; }
+__device__ unsigned long long g_x3_timing[24];
+extern "C" int rpe_debug_x3_timing(unsigned long long* out24) { return hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_x3_timing), 192) == hipSuccess ? 0 : -1; }
 #define XSTAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); Tacc[i] += now_ - Tlast; Tlast = now_; } while (0)
 #else
 #define XSTAMP(i)
@@ -149,12 +149,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
         dma_src = wave_uniform(xb + (size_t)step * rstep - 768);
         dma_lds = rs_base + (unsigned)buf * (X_RBUF * 4u);
     };
-    auto dma_chunk = [&rr_, &dma_src, &dma_lds](auto kc) {
+    auto dma_chunk = [&rr_, &dma_src, &dma_lds](auto kc, unsigned long long lanes) {
         constexpr int k = decltype(kc)::value;
         unsigned keep;
         const unsigned la = dma_lds + (k >= 4 ? 4096u : 0u);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(rr_[k]), "s"(dma_src), "s"(la), "n"((k & 3) * 1024) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %5\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(rr_[k]), "s"(dma_src), "s"(la), "n"((k & 3) * 1024), "s"(lanes) : "memory");
     };
     // after landing: the lane patches ITS quads (no barrier needed in front): padding, and with PRE relu((x - mean) / std) in place
     auto fix_raw = [&](int step, int buf) {
@@ -187,16 +187,19 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     u32x4 A[4][NCB][3];
     // one plane of A[nu] (both channel blocks): requested piece by piece, spread over the matrix-instruction groups (a block of six
     // requests stalls the wave's issue ~30 cycles each while the matrix pipe drains)
-    auto load_piece = [&A, ubase, ustep, a_lane](int step, auto nuc, auto plc) {
+    auto load_piece_if = [&A, ubase, ustep, a_lane](unsigned long long lanes, int step, auto nuc, auto plc) {
         constexpr int nu = decltype(nuc)::value, pl = decltype(plc)::value;
 #ifdef X3_A_HOT
         step = 0;                                                                      // ablation: every step re-reads step 0's fragments
 #endif
         const float* p0 = wave_uniform((const float*)(ubase + (size_t)step * ustep + nu * 6144 + pl * 1024));
-        if (NCB == 2) asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:3072"
-                                   : "=&v"(A[nu][0][pl]), "=&v"(A[nu][NCB - 1][pl]) : "v"(a_lane), "s"(p0) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(A[nu][0][pl]) : "v"(a_lane), "s"(p0) : "memory");
+        // (the loop runs with all 64 lanes: EXEC is restored to -1; "+v": under an empty mask the old values stay)
+        if (NCB == 2) asm volatile("s_mov_b64 exec, %4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:3072\n\ts_mov_b64 exec, -1"
+                                   : "+v"(A[nu][0][pl]), "+v"(A[nu][NCB - 1][pl]) : "v"(a_lane), "s"(p0), "s"(lanes) : "memory");
+        else asm volatile("s_mov_b64 exec, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, -1" : "+v"(A[nu][0][pl]) : "v"(a_lane), "s"(p0), "s"(lanes) : "memory");
     };
+    const unsigned long long all_lanes = __ballot(true);           // (a register pair, not a 64-bit literal: s_mov_b64 takes no such immediate)
+    auto load_piece = [&](int step, auto nuc, auto plc) { load_piece_if(all_lanes, step, nuc, plc); };
     auto load_a = [&](int step, auto nuc) {
         load_piece(step, nuc, std::integral_constant<int, 2>{}); load_piece(step, nuc, std::integral_constant<int, 1>{}); load_piece(step, nuc, std::integral_constant<int, 0>{});
     };
@@ -346,9 +349,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
 
     // ---- prologue: DMA(0), A(0) except A[3]'s hi plane (the loop's first stage requests it, as in every step), DMA(1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               // (the offsets are in LDS)
+#ifdef X3_TIMING
+    const unsigned long long Tp1 = __builtin_readcyclecounter();
+#endif
     dma_raw(0, 0);
     load_a(0, I0{}); load_a(0, I1{}); load_a(0, I2{}); load_piece(0, I3{}, I2{}); load_piece(0, I3{}, I1{});
-    dma_begin(nsteps > 1 ? 1 : 0, 1); dma_chunk(I0{}); dma_chunk(I1{});             // (chunks 2-6 of DMA(1): the loop's first two stages)
+    if (nsteps > 1) { dma_begin(1, 1); dma_chunk(I0{}, all_lanes); dma_chunk(I1{}, all_lanes); }          // (chunks 2-6 of DMA(1): the loop's first two stages)
     if (PRE) {
         for (int i = tid; i < P.cin; i += 256) {
             const float m = P.pre[((size_t)bz * P.cin + i) * 2], iv = P.pre[((size_t)bz * P.cin + i) * 2 + 1];
@@ -359,9 +365,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // DMA(0) has landed (no order between DMA and ordinary loads: wait for all)
     }
+#ifdef X3_TIMING
+    const unsigned long long Tp2 = __builtin_readcyclecounter();
+#endif
     fix_raw(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef X3_TIMING
+    const unsigned long long Tp3 = __builtin_readcyclecounter();
+#endif
     // B[tile block 0][positions 0, 1] of step 0 -> slot 0 (no matrix work to run beside it), then the reads quarter 0 starts with
     issue_reads(I0{}, I0{}, 0u); wait_reads(); row_pass(I0{}); issue_reads(I1{}, I0{}, 0u); finish_nu(I0{}, I0{}, I0{}); finish_nu(I0{}, I0{}, I1{});
     wait_reads(); row_pass(I0{}); issue_reads(I2{}, I0{}, 0u); finish_nu(I1{}, I0{}, I0{}); finish_nu(I1{}, I0{}, I1{});
@@ -374,9 +386,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     //   BARRIER (DMA(s+1) landed long ago: it is older than A(s)[2]; its patch-up happens here) ; DMA(s+2) -> raw(s)'s buffer
     //   k = 3: tile block 0, positions 0, 1 of step s+1 from raw(s+1)
     // A(s+1)[nu] is requested after A(s)[nu]'s last use (the tile block 1 stage of nu), three stages before its first.
-    // One loop body for every step: past the end, the next step's requests and fragments are harmless repeats of the last step's (a
-    // peeled last step had register spills, and a spill of an A fragment whose load is still in flight stores garbage: the allocator
-    // does not know these loads are asynchronous).
+    // One loop body for every step (a peeled last step had register spills, and a spill of an A fragment whose load is still in flight
+    // stores garbage: the allocator does not know these loads are asynchronous).  Past the end no request is made (empty EXEC mask, see m1 / m2); the fragments built
+    // for a step past the end are computed from whatever the other buffer holds and never used.
 #ifdef X3_TIMING
     unsigned long long Tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Tlast = __builtin_readcyclecounter();
     const unsigned long long Tstart = Tlast;
@@ -384,7 +396,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     unsigned cur = 0;                                                                 // byte offset of raw(s)'s buffer
     for (int s = 0; s < nsteps; ++s) {
         const unsigned nxt = cur ^ (X_RBUF * 4u);
-        const int s1 = s + 1 < nsteps ? s + 1 : nsteps - 1, s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;
+        const int s1 = s + 1, s2 = s + 2;
+        const bool more1 = s1 < nsteps, more2 = s2 < nsteps;
+        // No request is made for a step past the end: the request instructions are issued with an empty EXEC mask (no memory access, the
+        // destination registers keep their values) instead of being branched around -- a branch would cut a stage's instruction groups
+        // into basic blocks, and matrix and vector instructions are interleaved within a block only.
+        const unsigned long long m1 = more1 ? all_lanes : 0ull, m2 = more2 ? all_lanes : 0ull;
         XSTAMP(0);
         //    produce    matrix (nu, tb, slot) | builds (pair, tile block, first channel pair, buffer) | next reads | memory requests per group
         // Memory requests, at most one instruction group per matrix-instruction group and wave (the four waves run in lockstep and share
@@ -394,26 +411,26 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
         //   (all of DMA(s+2) has been requested two stages before stage (3,0)'s wait for everything)
         auto none = [](auto) {};
         typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 5> I5; typedef std::integral_constant<int, 6> I6;
-        dma_begin(s1, (int)(nxt != 0));                                               // (chunks 2-6 of DMA(s+1))
+        dma_begin(more1 ? s1 : s, (int)(nxt != 0));                                    // (chunks 2-6 of DMA(s+1))
         stage(PY{}, I0{}, I0{}, I0{}, I1{}, I0{}, I0{}, cur, I2{}, I0{}, cur, true, [&](auto g) {
             if (decltype(g)::value == 0) load_piece(s, I3{}, I0{});
-            if (decltype(g)::value == 1) dma_chunk(I2{});
-            if (decltype(g)::value == 2) dma_chunk(I3{});
-            if (decltype(g)::value == 3) dma_chunk(I4{}); }); XSTAMP(1);
+            if (decltype(g)::value == 1) dma_chunk(I2{}, m1);
+            if (decltype(g)::value == 2) dma_chunk(I3{}, m1);
+            if (decltype(g)::value == 3) dma_chunk(I4{}, m1); }); XSTAMP(1);
         stage(PY{}, I1{}, I0{}, I0{}, I1{}, I0{}, I2{}, cur, I0{}, I1{}, cur, true, [&](auto g) {
-            if (decltype(g)::value == 0) dma_chunk(I5{});
-            if (decltype(g)::value == 1) dma_chunk(I6{}); }); XSTAMP(2);
+            if (decltype(g)::value == 0) dma_chunk(I5{}, m1);
+            if (decltype(g)::value == 1) dma_chunk(I6{}, m1); }); XSTAMP(2);
         stage(PY{}, I2{}, I0{}, I1{}, I0{}, I1{}, I0{}, cur, I2{}, I1{}, cur, true, none); XSTAMP(3);
         stage(PY{}, I3{}, I0{}, I1{}, I0{}, I1{}, I2{}, cur, I0{}, I1{}, cur, true, none); XSTAMP(4);
         stage(PY{}, I0{}, I1{}, I0{}, I1{}, I1{}, I0{}, cur, I2{}, I1{}, cur, true, [&](auto g) {
-            if (decltype(g)::value == 1) load_piece(s1, I0{}, I2{});
-            if (decltype(g)::value == 3) load_piece(s1, I0{}, I1{}); }); XSTAMP(5);
+            if (decltype(g)::value == 1) load_piece_if(m1, s1, I0{}, I2{});
+            if (decltype(g)::value == 3) load_piece_if(m1, s1, I0{}, I1{}); }); XSTAMP(5);
         stage(PY{}, I1{}, I1{}, I0{}, I1{}, I1{}, I2{}, cur, I0{}, I0{}, cur, false, [&](auto g) {
-            if (decltype(g)::value == 0) load_piece(s1, I0{}, I0{});
-            if (decltype(g)::value == 1) load_piece(s1, I1{}, I2{});
-            if (decltype(g)::value == 3) load_piece(s1, I1{}, I1{}); }); XSTAMP(6);
-        fix_raw(s1, (int)(nxt != 0));
-        dma_begin(s2, (int)(cur != 0));                                               // (chunks 0, 1 of DMA(s+2))
+            if (decltype(g)::value == 0) load_piece_if(m1, s1, I0{}, I0{});
+            if (decltype(g)::value == 1) load_piece_if(m1, s1, I1{}, I2{});
+            if (decltype(g)::value == 3) load_piece_if(m1, s1, I1{}, I1{}); }); XSTAMP(6);
+        if (more1) fix_raw(s1, (int)(nxt != 0));
+        dma_begin(more2 ? s2 : s, (int)(cur != 0));                                    // (chunks 0, 1 of DMA(s+2))
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         XSTAMP(7);
         __builtin_amdgcn_s_barrier();
@@ -431,15 +448,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
         __builtin_amdgcn_sched_barrier(0);
         XSTAMP(9);
         stage(PY{}, I2{}, I1{}, I1{}, I0{}, I0{}, I0{}, nxt, I2{}, I0{}, nxt, true, [&](auto g) {
-            if (decltype(g)::value == 0) load_piece(s1, I1{}, I0{});
-            if (decltype(g)::value == 1) load_piece(s1, I2{}, I2{});
-            if (decltype(g)::value == 2) dma_chunk(I0{});
-            if (decltype(g)::value == 3) load_piece(s1, I2{}, I1{}); }); XSTAMP(10);
+            if (decltype(g)::value == 0) load_piece_if(m1, s1, I1{}, I0{});
+            if (decltype(g)::value == 1) load_piece_if(m1, s1, I2{}, I2{});
+            if (decltype(g)::value == 2) dma_chunk(I0{}, m2);
+            if (decltype(g)::value == 3) load_piece_if(m1, s1, I2{}, I1{}); }); XSTAMP(10);
         stage(PY{}, I3{}, I1{}, I1{}, I0{}, I0{}, I2{}, nxt, I0{}, I0{}, nxt, true, [&](auto g) {
-            if (decltype(g)::value == 0) load_piece(s1, I2{}, I0{});
-            if (decltype(g)::value == 1) load_piece(s1, I3{}, I2{});
-            if (decltype(g)::value == 2) dma_chunk(I1{});
-            if (decltype(g)::value == 3) load_piece(s1, I3{}, I1{}); }); XSTAMP(11);
+            if (decltype(g)::value == 0) load_piece_if(m1, s1, I2{}, I0{});
+            if (decltype(g)::value == 1) load_piece_if(m1, s1, I3{}, I2{});
+            if (decltype(g)::value == 2) dma_chunk(I1{}, m2);
+            if (decltype(g)::value == 3) load_piece_if(m1, s1, I3{}, I1{}); }); XSTAMP(11);
         cur = nxt;
     }
 #ifdef X3_TIMING
@@ -480,18 +497,31 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     float* ob = P.out + (size_t)bz * P.obs;
     float* ob2 = P.out2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
     const float* rsb = (HAS_AFFINE && P.res) ? P.res + (size_t)bz * P.rbs : nullptr;
+    // the per-channel constants of all 4 NCB iterations are requested here, ahead of the barrier (loaded inside the loop each iteration
+    // waited a memory round trip: the final pass took 6.6 k cycles of a 64-step workgroup's 121 k)
+    float bi_[4 * NCB], sc_[4 * NCB];
+#pragma unroll
+    for (int it = 0; it < 4 * NCB; ++it) {
+        const int co = co0 + fcol + 8 * it, cc = co < P.cout ? co : P.cout - 1;
+        bi_[it] = P.bias ? P.bias[cc] : 0.0f;
+        sc_[it] = (HAS_AFFINE && P.scale) ? P.scale[cc] : 1.0f;
+    }
+#ifdef X3_TIMING
+    const unsigned long long Tz = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef X3_TIMING
+    const unsigned long long Tb = __builtin_readcyclecounter();
+#endif
     // ---- epilogue 2: Y[i][j] = sum_xi A^T[i][xi] Z[xi][j] for (channel, tile row, two x-neighbouring tiles): two 16-byte rows
     const unsigned long long grp = __ballot(pix_ok);
     const float nvalid = 8.0f * (float)__popcll(grp & (0xFFull << (lane & 56)));     // pixels of this lane's 16 x 4 region inside the map
     const float inv_nvalid = nvalid > 0.0f ? 1.0f / nvalid : 0.0f;
-#pragma unroll 2
+#pragma unroll
     for (int it = 0; it < 4 * NCB; ++it) {
         const int col = fcol + 8 * it, co = co0 + col;
         const bool cok = co < P.cout;
-        const int cc = cok ? co : P.cout - 1;
-        const float bi = P.bias ? P.bias[cc] : 0.0f;
-        const float sc = (HAS_AFFINE && P.scale) ? P.scale[cc] : 1.0f;
+        const float bi = bi_[it], sc = sc_[it];
         const float* zr = &smem[col * 64 + 8 * fty + 2 * m4];
         float2 z[4][2];
 #pragma unroll
@@ -545,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     if (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && blockIdx.y == gridDim.y / 2 && tid == 0) {
         for (int i = 0; i < 12; ++i) g_x3_timing[i] = Tacc[i];
         g_x3_timing[12] = Tstart - Tk0; g_x3_timing[13] = Tloop - Tstart; g_x3_timing[14] = __builtin_readcyclecounter() - Tloop; g_x3_timing[15] = nsteps;
+        g_x3_timing[16] = Tz - Tloop; g_x3_timing[17] = Tb - Tz; g_x3_timing[18] = Tp1 - Tk0; g_x3_timing[19] = Tp2 - Tp1; g_x3_timing[20] = Tp3 - Tp2; g_x3_timing[21] = Tstart - Tp3;
     }
 #endif
 }

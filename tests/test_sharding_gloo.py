@@ -265,3 +265,34 @@ def test_sequence_tracker_eight_ranks_chunked():
         assert built == 1 and torch.equal(ok, ok_s) and float((rel - rel_s).abs().max()) <= 1e-6
         assert float((poses - serial).abs().max()) <= 1e-3 * max(1.0, float(serial.abs().max()))
         assert torch.equal(poses, out[0][0])
+
+
+def _worker_bench_pass(rank, world, port, n_frames, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    import rpe_amd.sharding as sh
+    track = lambda: sh.track_sharded(n_frames, _run_block, _chain, rank, world, scale=250.0)
+    sp = bench.sequence_pass(track, n_frames, rank, steps=2, warmup=1, dev='cpu', dist=dist)
+    out[rank] = (sp['poses'], sp['ok'], sp['same'], sp['frames_per_s'], sp['checksum'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_sequence_pass_on_two_ranks():
+    """bench.py's sequence pass (what ``--mode sequence`` times and what ``--gpus N`` adds to the batch line as sequence_frames_per_s when
+    N > 1): K timed walks, the trajectory checksum compared across ranks with MIN / MAX all-reduces.  Driven here on the CPU oracle
+    under gloo, world size 2: both ranks report the serial trajectory, the same checksum, and a positive rate."""
+    import rpe_amd.sharding as sh
+    world, n_frames = 2, 14
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_bench_pass, args=(world, _free_port(), n_frames, out), nprocs=world, join=True)
+    serial, _, ok_s = sh.track_sharded(n_frames, _run_block, _chain, 0, 1, scale=250.0)
+    for r in range(world):
+        poses, ok, same, fps, chk = out[r]
+        assert same and fps > 0.0
+        assert torch.equal(poses, serial) and torch.equal(ok, ok_s)
+    assert out[0][4] == out[1][4]

@@ -51,11 +51,13 @@ with torch.no_grad():
             name, ci, co, t1, t2, t1 / t2, flop / t2 / 1e6, e1.abs().max().item(), e1.pow(2).mean().sqrt().item(), e2.abs().max().item(), e2.pow(2).mean().sqrt().item()), flush=True)
         if hasattr(rpe_amd._lib.lib(), 'rpe_debug_x3_timing'):               # -DX3_TIMING variant builds only
             import ctypes
-            buf = (ctypes.c_ulonglong * 16)()
+            buf = (ctypes.c_ulonglong * 24)()
             rpe_amd._lib.lib().rpe_debug_x3_timing(buf)
             n = max(buf[15], 1)
             print('        cycles per step, wave 0 of a mid-grid workgroup (%d steps): ' % buf[15] + ' '.join('%d:%.0f' % (i, buf[i] / n) for i in range(12)))
             print('        prologue %d  loop %d  epilogue %d cycles' % (buf[12], buf[13], buf[14]))
+            print('        prologue: set-up %d | requests + wait for the first patch %d | patch-up + barrier %d | first fragments %d ;  epilogue: Z to LDS %d | barrier %d | final pass %d' % (
+                buf[18], buf[19], buf[20], buf[21], buf[16], buf[17], buf[14] - buf[16] - buf[17]))
     if not only:
         print('--- encoder layers (bias + instance-norm moments; 48 images)')
         for name, c, hh, ww in (('layer1', 64, 256, 320), ('layer2', 96, 128, 160), ('layer3', 128, 64, 80)):
