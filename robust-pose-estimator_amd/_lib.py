@@ -95,6 +95,9 @@ SIGNATURES = {
     'rpe_conv_wino1d_packed_floats': (_sz, [_i, _i]),
     'rpe_conv_wino1d_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino1d': (_i, [_c.POINTER(ConvDesc), _vp]),
+    'rpe_conv_wino1d_x3_packed_bytes': (_sz, [_i, _i]),
+    'rpe_conv_wino1d_x3_pack': (_i, [_vp, _i, _i, _vp, _vp]),
+    'rpe_conv_wino1d_x3': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_stats_tiles': (_i, [_i, _i, _i, _i]),
     'rpe_conv_stats_tiles_batch': (_i, [_i, _i, _i, _i, _i]),
     'rpe_instnorm_apply': (_i, [_vp, _vp, _i, _i, _i, _i, _c.c_float, _i, _vp, _vp, _vp]),

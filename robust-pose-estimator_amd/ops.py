@@ -618,7 +618,27 @@ def conv_wino1d(x, pw, mode, out, **kw):
     """rpe_conv_wino1d: conv_fused's operation (all four epilogue modes incl. the GRU gates) for 1x5 / 5x1 stride-1 convolutions
     by Winograd F(4,5) along the filter axis: 2.5x fewer matrix FLOPs.  Same keyword arguments as conv_fused (no scale /
     residual / stats / pre_norm)."""
-    return conv_fused(x, pw, mode, out, entry='rpe_conv_wino1d', **kw)
+    return conv_fused(x, pw, mode, out, entry='rpe_conv_wino1d_x3' if getattr(pw, 'x3', False) else 'rpe_conv_wino1d', **kw)
+
+
+class PackedWino1dX3:
+    """Weights of a 1x5 / 5x1 stride-1 convolution transformed and split three ways into bf16 for rpe_conv_wino1d_x3 (the labelled
+    bf16x3 variant of rpe_conv_wino1d; conv_wino1d dispatches on the packing)."""
+    x3 = True
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        n = lib().rpe_conv_wino1d_x3_packed_bytes(self.cout, self.cin) if (self.kh, self.kw) in ((1, 5), (5, 1)) else 0
+        if n == 0:
+            raise _lib.RpeError('PackedWino1dX3: needs a (cout, cin % 32 == 0, 1, 5) or (.., 5, 1) weight')
+        self.packed = torch.empty(n // 4, dtype=torch.float32, device=w.device)
+        check(lib().rpe_conv_wino1d_x3_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv_wino1d_x3_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(weight, ww):
+        return tuple(weight.shape[2:]) in ((1, 5), (5, 1)) and weight.shape[1] % 32 == 0 and ww % 4 == 0
 
 
 class PackedWino:

@@ -485,7 +485,9 @@ class BasicUpdateBlock(nn.Module):
             for n in ('zr1', 'q1', 'zr2', 'q2'):
                 # the loop-varying 256 channels: Winograd F(4,5) along the filter axis (rpe_conv_wino1d: 2.5x fewer matrix FLOPs), else the
                 # direct implicit GEMM; bias is part of the context term (context_terms)
-                P[n] = ops.PackedWino1d(W[n][0]) if WINOGRAD else ops.PackedConv(W[n][0])
+                # (under CONV_BF16X3: the labelled variant's packing -- rpe_conv_wino1d_x3; packed_convs only runs for widths it accepts)
+                P[n] = (ops.PackedWino1dX3 if CONV_BF16X3 and ops.PackedWino1dX3.supported(W[n][0], 4) else ops.PackedWino1d)(W[n][0]) if WINOGRAD \
+                    else ops.PackedConv(W[n][0])
                 P['ctx_' + n] = (ops.PackedWino1d if WINOGRAD else ops.PackedConv)(W[n][1], W[n][2])
             scratch = {}
 
@@ -521,7 +523,7 @@ class BasicUpdateBlock(nn.Module):
             calls = cache.get(key)
             if calls is None:
                 seq = []
-                gconv = ops.conv_wino1d if isinstance(P['zr1'], ops.PackedWino1d) else ops.conv_fused
+                gconv = ops.conv_wino1d if isinstance(P['zr1'], (ops.PackedWino1d, ops.PackedWino1dX3)) else ops.conv_fused
                 for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
                     seq.append(gconv(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
                                      prepare=True))

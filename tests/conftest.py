@@ -29,8 +29,18 @@ def _usable_cores():
 torch.set_num_threads(_usable_cores())            # the CPU oracle is ~100x slower when oversubscribed
 
 
+def pytest_addoption(parser):
+    parser.addoption('--conv-bf16x3', action='store_true', default=False,
+                     help='run the suite with raft.CONV_BF16X3 = True (the labelled bf16x3 variant of the >= 128-channel 3x3 layers, the GRU '
+                          'convolutions and the correlation build): every parity test must pass unchanged under the switch')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    if config.getoption('--conv-bf16x3'):
+        import rpe_amd  # noqa: F401
+        from rpe_amd import raft
+        raft.CONV_BF16X3 = True
 
 
 def pytest_collection_modifyitems(config, items):
