@@ -367,7 +367,7 @@ int rpe_conv_wino1d(const rpe_conv_desc *desc, void *stream);
 /* LABELLED VARIANT of rpe_conv_wino1d (never in a headline number; bench.py --conv-bf16x3): the same convolution, descriptor fields
  * and epilogue modes incl. the GRU gates, with every f32 product of the Winograd domain evaluated as six bf16 products of an exact
  * three-way split on the 16-bit matrix cores, f32 accumulation (csrc/conv_wino1d_x3.hip; error held to the f32 kernels' by
- * tests/test_gpu_conv_x3.py).  Needs cin % 32 == 0, w % 4 == 0, 16-byte aligned tensors; anything else -> RPE_E_UNSUPPORTED (the
+ * tests/test_gpu_conv_x3.py).  Needs cin % 16 == 0, w % 4 == 0, 16-byte aligned tensors; anything else -> RPE_E_UNSUPPORTED (the
  * caller uses rpe_conv_wino1d).  desc->packed must come from rpe_conv_wino1d_x3_pack (rpe_conv_wino1d_x3_packed_bytes bytes, 0 =
  * unsupported shape; 16-byte aligned).  Same reference layers as rpe_conv_wino1d (SepConvGRU, core/RAFT/core/update.py; call sites
  * core/pose/pose_net.py:47,65,129). */

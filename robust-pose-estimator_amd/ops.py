@@ -631,14 +631,14 @@ class PackedWino1dX3:
         self.cout, self.cin, self.kh, self.kw = w.shape
         n = lib().rpe_conv_wino1d_x3_packed_bytes(self.cout, self.cin) if (self.kh, self.kw) in ((1, 5), (5, 1)) else 0
         if n == 0:
-            raise _lib.RpeError('PackedWino1dX3: needs a (cout, cin % 32 == 0, 1, 5) or (.., 5, 1) weight')
+            raise _lib.RpeError('PackedWino1dX3: needs a (cout, cin % 16 == 0, 1, 5) or (.., 5, 1) weight')
         self.packed = torch.empty(n // 4, dtype=torch.float32, device=w.device)
         check(lib().rpe_conv_wino1d_x3_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv_wino1d_x3_pack')
         self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
 
     @staticmethod
     def supported(weight, ww):
-        return tuple(weight.shape[2:]) in ((1, 5), (5, 1)) and weight.shape[1] % 32 == 0 and ww % 4 == 0
+        return tuple(weight.shape[2:]) in ((1, 5), (5, 1)) and weight.shape[1] % 16 == 0 and ww % 4 == 0
 
 
 class PackedWino:

@@ -39,7 +39,7 @@ def reference(x, w, pad, add, hid, z, c, mode):
 dev = torch.device('cuda:0'); torch.manual_seed(0)
 N = int(os.environ.get('CONV_N', 32))
 with torch.no_grad():
-    for (nb, ci, H, W) in ((2, 32, 16, 16), (1, 64, 20, 28), (2, 256, 64, 80), (N, 256, 64, 80)):
+    for (nb, ci, H, W) in ((2, 16, 16, 16), (1, 48, 20, 28), (2, 256, 64, 80), (N, 256, 64, 80)):
         c = 128
         for vert in (False, True):
             for mode, co in ((ops.CONV_LINEAR, 128), (ops.CONV_RELU, 256), (ops.CONV_GATE_ZR, 256), (ops.CONV_GATE_H, 128)):
@@ -77,5 +77,5 @@ with torch.no_grad():
                     buf = (ctypes.c_ulonglong * 16)()
                     rpe_amd._lib.lib().rpe_debug_y3_timing(buf)
                     n = max(buf[11], 1)
-                    print('        cycles per step (wave 0, mid-grid workgroup, %d steps): wait A %d | stage 0 %d | stage 1 %d | wait DMA %d | barrier %d | stage 2 %d | stage 3 %d ;  prologue %d loop %d epilogue %d (exchange %d, barrier %d)' % (
-                        n, *[buf[i] // n for i in range(7)], buf[8], buf[9], buf[10], buf[12], buf[13]))
+                    print('        cycles per step (wave 0, mid-grid workgroup, %d steps): stage 0 %d | stage 1 %d | barrier %d | stage 2 %d | stage 3 %d ;  prologue %d loop %d epilogue %d (first half: wait + fetch %d, exchange %d, barrier %d, first 4 quads %d, other 12 %d)' % (
+                        n, *[buf[i] // n for i in range(1, 6)], buf[8], buf[9], buf[10], buf[12], buf[13], buf[14], buf[15], buf[7]))
