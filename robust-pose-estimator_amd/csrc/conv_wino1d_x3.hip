@@ -227,27 +227,37 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino1d_x3(W1X3P P) {
         asm volatile("" : "+v"(tt[0][0]), "+v"(tt[0][1]), "+v"(tt[1][0]), "+v"(tt[1][1]));
     };
     auto transform = [&]() { t_even(std::integral_constant<int, 0>{}); t_odd(std::integral_constant<int, 0>{}); t_even(std::integral_constant<int, 1>{}); t_odd(std::integral_constant<int, 1>{}); t_fin(); };
-    // position i of channel pair q: split (f_split, per channel), pack (f_pack) -> element q of the three fragments B[slot][i][plane]
-    float r1[2], r2[2];
-    auto f_split = [&](auto ic, auto ec) {
-        constexpr int i = decltype(ic)::value, e = decltype(ec)::value;
-        const float h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tt[e][i]) & 0xFFFF0000u);
-        r1[e] = tt[e][i] - h;
-        const float m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1[e]) & 0xFFFF0000u);
-        r2[e] = r1[e] - m;
-        asm volatile("" : "+v"(r1[e]), "+v"(r2[e]));
+    // position i of channel pair q -> element q of the three fragments B[slot][i][plane].  The split rounds to nearest (v_cvt_pk_bf16_f32
+    // packs the two channels' bf16 parts in one instruction; the residual x - bf16(x) is exact in f32): x = hi + mid + lo to 2^-27
+    // where truncation gives 2^-24, unbiased, for the same 11 instructions per pair as mask / subtract / permute.
+    // (The residual as ONE v_dot2_f32_bf16 with the constant (-1, 0) -- exact, tools/probes/valu_rate.hip, and 7 instructions per pair --
+    // was tried: the dot instructions run on the matrix pipe, cost 8.5 issue cycles beside matrix instructions instead of 6, need wait
+    // states the compiler does not insert around inline asm (wrong results), and the stage got 15% longer.)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    auto pack2 = [](float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_)); };
+    float r1a = 0.0f, r1b = 0.0f, r2a = 0.0f, r2b = 0.0f;
+    unsigned pk_h = 0, pk_m = 0;
+    auto f_hi = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        pk_h = pack2(tt[0][i], tt[1][i]);
+        r1a = tt[0][i] - __builtin_bit_cast(float, pk_h << 16);
+        r1b = tt[1][i] - __builtin_bit_cast(float, pk_h & 0xFFFF0000u);
+        asm volatile("" : "+v"(pk_h), "+v"(r1a), "+v"(r1b));
     };
-    auto f_pack = [&](auto qc, auto slc, auto ic) {
+    auto f_mid = [&]() {
+        pk_m = pack2(r1a, r1b);
+        r2a = r1a - __builtin_bit_cast(float, pk_m << 16);
+        r2b = r1b - __builtin_bit_cast(float, pk_m & 0xFFFF0000u);
+        asm volatile("" : "+v"(pk_m), "+v"(r2a), "+v"(r2b));
+    };
+    auto f_lo = [&](auto qc, auto slc, auto ic) {
         constexpr int q = decltype(qc)::value, sl = decltype(slc)::value, i = decltype(ic)::value;
-        unsigned ph = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, tt[1][i]), __builtin_bit_cast(unsigned, tt[0][i]), 0x07060302u);
-        unsigned pm = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r1[1]), __builtin_bit_cast(unsigned, r1[0]), 0x07060302u);
-        unsigned pl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2[1]), __builtin_bit_cast(unsigned, r2[0]), 0x07060302u);
-        asm volatile("" : "+v"(ph), "+v"(pm), "+v"(pl));
-        B[sl][i][0][q] = ph; B[sl][i][1][q] = pm; B[sl][i][2][q] = pl;
+        unsigned pl = pack2(r2a, r2b);
+        asm volatile("" : "+v"(pl));
+        B[sl][i][0][q] = pk_h; B[sl][i][1][q] = pk_m; B[sl][i][2][q] = pl;
     };
-    auto finish = [&](auto qc, auto slc, auto ic) {
-        f_split(ic, std::integral_constant<int, 0>{}); f_split(ic, std::integral_constant<int, 1>{}); f_pack(qc, slc, ic);
-    };
+    auto finish = [&](auto qc, auto slc, auto ic) { f_hi(ic); f_mid(); f_lo(qc, slc, ic); };
 
     f32x16 acc[2][NCB][2];                            // [position][channel block][tile block]
 #pragma unroll
@@ -287,23 +297,23 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino1d_x3(W1X3P P) {
         Y_SLOT(2, t_even(I1{}));
         Y_SLOT(3, t_odd(I1{}));
         Y_SLOT(4, (t_fin(), issue_reads(Q1{}, SP{}, bufp)));
-        Y_SLOT(5, f_split(I0{}, I0{}));
-        Y_SLOT(6, f_split(I0{}, I1{}));
-        Y_SLOT(7, f_pack(Q0{}, SP{}, I0{}));
-        Y_SLOT(8, f_split(I1{}, I0{}));
-        Y_SLOT(9, f_split(I1{}, I1{}));
-        Y_SLOT(10, f_pack(Q0{}, SP{}, I1{}));
+        Y_SLOT(5, f_hi(I0{}));
+        Y_SLOT(6, f_mid());
+        Y_SLOT(7, f_lo(Q0{}, SP{}, I0{}));
+        Y_SLOT(8, f_hi(I1{}));
+        Y_SLOT(9, f_mid());
+        Y_SLOT(10, f_lo(Q0{}, SP{}, I1{}));
         Y_SLOT(11, (wait_reads(), t_even(I0{})));
         Y_SLOT(12, t_odd(I0{}));
         Y_SLOT(13, t_even(I1{}));
         Y_SLOT(14, t_odd(I1{}));
         Y_SLOT(15, (t_fin(), chain ? issue_reads(qnc, tbnc, bufn) : (void)0));
-        Y_SLOT(16, f_split(I0{}, I0{}));
-        Y_SLOT(17, f_split(I0{}, I1{}));
-        Y_SLOT(18, f_pack(Q1{}, SP{}, I0{}));
-        Y_SLOT(19, f_split(I1{}, I0{}));
-        Y_SLOT(20, f_split(I1{}, I1{}));
-        Y_SLOT(21, f_pack(Q1{}, SP{}, I1{}));
+        Y_SLOT(16, f_hi(I0{}));
+        Y_SLOT(17, f_mid());
+        Y_SLOT(18, f_lo(Q1{}, SP{}, I0{}));
+        Y_SLOT(19, f_hi(I1{}));
+        Y_SLOT(20, f_mid());
+        Y_SLOT(21, f_lo(Q1{}, SP{}, I1{}));
         Y_SLOT(22, (void)0);
         Y_SLOT(23, (void)0);
     };
@@ -580,13 +590,15 @@ __global__ void k_wino1d_pack_x3(const float* __restrict__ w, unsigned short* __
 #pragma unroll
         for (int k = 0; k < 5; ++k) v += G[pos][k] * (double)g[k];
     }
+    // round-to-nearest-even bf16 parts (finite values): hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid), the residuals exact in f32
+    auto bf16_rne = [](float f) { unsigned b = __builtin_bit_cast(unsigned, f); b += 0x7FFFu + ((b >> 16) & 1u); return b & 0xFFFF0000u; };
     const float vf = (float)v;
-    const unsigned u = __builtin_bit_cast(unsigned, vf) & 0xFFFF0000u;
+    const unsigned u = bf16_rne(vf);
     const float r1 = vf - __builtin_bit_cast(float, u);
-    const unsigned u1 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    const unsigned u1 = bf16_rne(r1);
     const float r2 = r1 - __builtin_bit_cast(float, u1);
     unsigned short* d = wp + (e >> 9) * (3 * 512) + co32 * 16 + ci16;
-    d[0] = (unsigned short)(u >> 16); d[512] = (unsigned short)(u1 >> 16); d[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    d[0] = (unsigned short)(u >> 16); d[512] = (unsigned short)(u1 >> 16); d[1024] = (unsigned short)(bf16_rne(r2) >> 16);
 }
 
 static inline int y_cop(int cout) { return (cout + Y_CO - 1) / Y_CO * Y_CO; }

@@ -41,6 +41,9 @@ CONV_BF16X3 = False      # LABELLED VARIANT (bench.py --conv-bf16x3; never the h
 #                          NOT cover (measured no faster: short K loops) stay on the f32 matrix cores: the encoders, convf2, the GRU's
 #                          1x5 / 5x1 layers, convc1 and the other 1x1 layers, the stems.
 X3_MIN_CIN = 128         # rpe_conv_wino_x3 pays from 8 K steps of 16 channels on
+X3_GRU = False           # under CONV_BF16X3, also the SepConvGRU's 1x5 / 5x1 layers on rpe_conv_wino1d_x3.  Off: in the bench step its launches
+#                          take 449 / 410 us (z|r, 1x5 / 5x1) and 251 / 237 us (q) against rpe_conv_wino1d's 407 / 395 and 240 / 224 -- one
+#                          workgroup per CU has nothing to run beside its memory-bound gate pass (csrc/conv_wino1d_x3.hip); kept, tested, opt-in.
 # The motion encoder's flow branch (convf1 -> convf2) on a side stream beside lookup -> convc1 -> convc2.  Measured (MI355X, 640x512):
 # batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
 # launch fills the chip on its own), so it is used for small passes only.
@@ -470,7 +473,7 @@ class BasicUpdateBlock(nn.Module):
         keymods = mods + (e.convf1,)
         # (the convolutions' own weight / bias attributes: walking module.parameters() costs ~100 us a call, and this runs 26 times a frame)
         ps = [t for m in keymods for t in (m.weight, m.bias) if t is not None]
-        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (id(self.gate_weights()), CONV_BF16X3)
+        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (id(self.gate_weights()), CONV_BF16X3, X3_GRU)
         if getattr(self, '_packed', None) is None or self._packed[0] != key:
             W = self.gate_weights()
             P = {n: ops.PackedConv(m.weight, m.bias) for n, m in zip(('convc1', 'convc2', 'convf2', 'conv', 'fh1'), mods)}
@@ -485,8 +488,8 @@ class BasicUpdateBlock(nn.Module):
             for n in ('zr1', 'q1', 'zr2', 'q2'):
                 # the loop-varying 256 channels: Winograd F(4,5) along the filter axis (rpe_conv_wino1d: 2.5x fewer matrix FLOPs), else the
                 # direct implicit GEMM; bias is part of the context term (context_terms)
-                # (under CONV_BF16X3: the labelled variant's packing -- rpe_conv_wino1d_x3; packed_convs only runs for widths it accepts)
-                P[n] = (ops.PackedWino1dX3 if CONV_BF16X3 and ops.PackedWino1dX3.supported(W[n][0], 4) else ops.PackedWino1d)(W[n][0]) if WINOGRAD \
+                # (under CONV_BF16X3 with X3_GRU: the labelled variant's packing -- rpe_conv_wino1d_x3; packed_convs only runs for widths it accepts)
+                P[n] = (ops.PackedWino1dX3 if CONV_BF16X3 and X3_GRU and ops.PackedWino1dX3.supported(W[n][0], 4) else ops.PackedWino1d)(W[n][0]) if WINOGRAD \
                     else ops.PackedConv(W[n][0])
                 P['ctx_' + n] = (ops.PackedWino1d if WINOGRAD else ops.PackedConv)(W[n][1], W[n][2])
             scratch = {}

@@ -6,7 +6,8 @@ it shares the f32 Winograd transforms bit for bit; only the products differ.  So
 THAT kernel's on the same data -- RMS at most 1.25x (measured 0.85-0.88x: the split drops terms below 2^-24 of a product and
 accumulates in the matrix core's f32 adder tree instead of a serial fma chain) -- and, like rpe_conv_wino itself, with the direct f32
 kernel's (RMS <= 3x, max <= 4x: the Winograd transforms' cost, test_gpu_conv.py).  The f64 bars of test_gpu_conv.py's Winograd tests are
-kept unchanged for every epilogue."""
+kept unchanged for every epilogue.  The second half of the file holds rpe_conv_wino1d_x3 (the GRU's F(4,5) layers, csrc/conv_wino1d_x3.hip)
+to the same bars against rpe_conv_wino1d."""
 import numpy as np
 import pytest
 import torch
@@ -156,3 +157,149 @@ def test_x3_special_values(rpe):
     ref = F.conv2d(xs.cpu().double(), wt.double(), None, padding=1)
     gs = ops.conv_wino(xs, px, ops.CONV_LINEAR, torch.empty(1, 32, 16, 16, device='cuda')).cpu().double()
     assert (gs - ref).abs().max() < 1e-5 * ref.abs().max()
+
+
+# ---- rpe_conv_wino1d_x3: the GRU's 1x5 / 5x1 convolutions (csrc/conv_wino1d_x3.hip), the variant of rpe_conv_wino1d ---------------------
+
+from test_gpu_conv import _ref_conv
+
+
+@pytest.mark.parametrize('kh,kw,h,w', [(1, 5, 64, 80), (5, 1, 64, 80), (1, 5, 44, 48), (5, 1, 44, 48), (1, 5, 30, 40), (5, 1, 30, 40)])
+def test_x3_gru_half_step_matches_f64(rpe, kh, kw, h, w):
+    """test_gpu_conv.test_gru_half_step_matches_f64 on the variant, same reference and bars: z, r*h and the blended hidden state of one
+    SepConvGRU half fused into the two convolutions (the branch-free gate passes: addend, no bias), in place on the hidden state."""
+    from rpe_amd import ops
+    c, b = 128, 2
+    rng = np.random.default_rng(kh * 10 + kw + h)
+    hx = _rand(rng, b, 2 * c, h, w, s=0.5)
+    wzr, azr = _rand(rng, 2 * c, 2 * c, kh, kw, s=0.03), _rand(rng, b, 2 * c, h, w, s=0.3)
+    wq, aq = _rand(rng, c, 2 * c, kh, kw, s=0.03), _rand(rng, b, c, h, w, s=0.3)
+    hid = hx[:, :c].double()
+    zr = torch.sigmoid(_ref_conv(hx, wzr, None, azr))
+    z, r = zr[:, :c], zr[:, c:]
+    rhx = torch.cat((r * hid, hx[:, c:].double()), 1)
+    q = torch.tanh(_ref_conv(rhx.float(), wq, None, aq))
+    hnew = (1 - z) * hid + z * q
+    g_hx, g_rhx = hx.cuda(), hx.cuda().clone()
+    g_z = torch.empty(b, c, h, w, device='cuda')
+    pzr, pq = ops.PackedWino1dX3(wzr.cuda()), ops.PackedWino1dX3(wq.cuda())
+    ops.conv_wino1d(g_hx, pzr, ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
+    tz = _tol(hx, wzr) * 0.25 + 2e-7
+    assert (g_z.cpu().double() - z).abs().max() < tz
+    assert (g_rhx[:, :c].cpu().double() - r * hid).abs().max() < tz * float(hx.abs().max())
+    assert torch.equal(g_rhx[:, c:], g_hx[:, c:])
+    ops.conv_wino1d(g_rhx, pq, ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)   # in place on h
+    assert (g_hx[:, :c].cpu().double() - hnew).abs().max() < _tol(hx, wq) + tz * 2
+    assert torch.equal(g_hx[:, c:].cpu(), hx[:, c:])
+    # with a bias (the gate passes with runtime operands) and through the prepared launcher: same values
+    bzr = _rand(rng, 2 * c, s=0.1)
+    z2 = torch.sigmoid(_ref_conv(hx, wzr, bzr, azr))[:, :c]
+    g_z2, g_r2 = torch.empty(b, c, h, w, device='cuda'), torch.empty(b, c, h, w, device='cuda')
+    ops.conv_wino1d(hx.cuda(), ops.PackedWino1dX3(wzr.cuda(), bzr.cuda()), ops.CONV_GATE_ZR, g_z2, out2=g_r2, add=azr.cuda(), hidden=hx.cuda()[:, :c],
+                    gate_channels=c, prepare=True)()
+    assert (g_z2.cpu().double() - z2).abs().max() < tz
+
+
+@pytest.mark.parametrize('cin,cout,kh,kw,h,w,b', [
+    (256, 256, 1, 5, 64, 80, 2),      # convz1|convr1 at bench geometry
+    (256, 128, 5, 1, 64, 80, 2),      # convq2
+    (64, 96, 1, 5, 20, 24, 1),        # ragged output channels, map smaller than two patches
+    (64, 200, 5, 1, 7, 36, 2),        # 7 rows: the last 4-pixel tile is cut, 36 columns: the last patch is cut; a second, ragged channel tile
+    (16, 16, 1, 5, 33, 4, 1),         # one quad wide, one K step
+    (16, 16, 5, 1, 3, 4, 1),          # shorter than the filter
+    (48, 70, 1, 5, 18, 20, 3),        # three K steps; 70 channels: the upper 64-channel half of the tile holds six
+])
+@pytest.mark.parametrize('relu', [False, True])
+def test_x3_winograd_1d_matches_f64(rpe, cin, cout, kh, kw, h, w, b, relu):
+    """test_gpu_conv.test_winograd_1d_matches_f64 on the variant: the plain epilogues with bias, addend and a second output, on channel
+    slices of wider buffers; same bar."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + kh * 7 + kw + h)
+    x, wt, bias, add = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, kh, kw, s=0.05), _rand(rng, cout, s=0.1), _rand(rng, b, cout, h, w, s=0.3)
+    ref = _ref_conv(x, wt, bias, add)
+    if relu:
+        ref = ref.clamp_min(0)
+    xbuf = torch.full((b, cin + 8, h, w), float('nan'), device='cuda'); xbuf[:, 4:4 + cin] = x.cuda()
+    obuf = torch.full((b, cout + 8, h, w), -7.0, device='cuda'); o2buf = torch.full((b, cout + 4, h, w), -7.0, device='cuda')
+    assert ops.PackedWino1dX3.supported(wt, w)
+    pw = ops.PackedWino1dX3(wt.cuda(), bias.cuda())
+    ops.conv_wino1d(xbuf[:, 4:4 + cin], pw, ops.CONV_RELU if relu else ops.CONV_LINEAR, obuf[:, 4:4 + cout], out2=o2buf[:, 4:], add=add.cuda())
+    got = obuf[:, 4:4 + cout].cpu().double()
+    assert (got - ref).abs().max() < _tol(x, wt) * 2
+    assert torch.equal(obuf[:, 4:4 + cout], o2buf[:, 4:])
+    assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all() and (o2buf[:, :4] == -7.0).all()
+    # no addend, no bias; deterministic
+    plain = ops.conv_wino1d(x.cuda(), ops.PackedWino1dX3(wt.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    assert (plain.cpu().double() - _ref_conv(x, wt, None, None)).abs().max() < _tol(x, wt) * 2
+    assert torch.equal(ops.conv_wino1d(x.cuda(), ops.PackedWino1dX3(wt.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda')), plain)
+
+
+def test_x3_winograd_1d_rejects_what_it_cannot_do(rpe):
+    from rpe_amd import ops
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWino1dX3(torch.zeros(8, 24, 1, 5, device='cuda'))            # cin % 16
+    with pytest.raises(rpe.RpeError):
+        ops.PackedWino1dX3(torch.zeros(8, 16, 3, 3, device='cuda'))
+    pw = ops.PackedWino1dX3(torch.zeros(8, 16, 1, 5, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):                      # width not a multiple of 4
+        ops.conv_wino1d(torch.zeros(1, 16, 8, 10, device='cuda'), pw, ops.CONV_LINEAR, torch.empty(1, 8, 8, 10, device='cuda'))
+    shifted = torch.zeros(16 * 8 * 12 + 1, device='cuda')[1:].view(1, 16, 8, 12)         # an input that is not 16-byte aligned
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):
+        ops.conv_wino1d(shifted, pw, ops.CONV_LINEAR, torch.empty(1, 8, 8, 12, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):                      # plain and gate epilogues only
+        ops.conv_wino1d(torch.zeros(1, 16, 8, 12, device='cuda'), pw, ops.CONV_LINEAR, torch.empty(1, 8, 8, 12, device='cuda'), scale=torch.ones(8, device='cuda'))
+    assert not ops.PackedWino1dX3.supported(torch.zeros(8, 16, 1, 5), 10) and not ops.PackedWino1dX3.supported(torch.zeros(8, 24, 5, 1), 12)
+    assert ops.PackedWino1dX3.supported(torch.zeros(8, 16, 5, 1), 12)
+
+
+@pytest.mark.parametrize('kind,cin,cout,h,w', [('1x5', 256, 256, 64, 80), ('5x1', 256, 128, 64, 80), ('1x5', 256, 128, 44, 48)])
+@pytest.mark.parametrize('flow_channels', [False, True])
+def test_x3_winograd_1d_error_relative_to_the_f32_kernels_on_trained_like_statistics(rpe, kind, cin, cout, h, w, flow_channels):
+    """The f32-equivalence bar of the 3x3 variant, for F(4,5): on trained-like statistics (a saturated hidden state, +-50 px flow
+    channels, heavy-tailed weights) the error against the f64 convolution is at most 1.25x (RMS) the f32 Winograd kernel's
+    (rpe_conv_wino1d, measured 0.85x), its maximum at most 1.25x the larger of the two f32 kernels' maxima, and within the bars
+    rpe_conv_wino1d itself is held to against the direct kernel (3x RMS, 4x max)."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin * 1000 + cout * 7 + h + 3 * len(kind) + ord(kind[0]) + int(flow_channels))
+    kh, kw = {'1x5': (1, 5), '5x1': (5, 1)}[kind]
+    b = 2
+    x, wt, bias = _trained_like(rng, b, cin, cout, kh, kw, h, w, flow_channels)
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=(kh // 2, kw // 2))
+    direct = ops.conv_fused(x.cuda(), ops.PackedConv(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    wino = ops.conv_wino1d(x.cuda(), ops.PackedWino1d(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    x3 = ops.conv_wino1d(x.cuda(), ops.PackedWino1dX3(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(b, cout, h, w, device='cuda'))
+    dmax, drms = _errs(direct, ref)
+    wmax, wrms = _errs(wino, ref)
+    xmax, xrms = _errs(x3, ref)
+    print(f'{kind} {cin}->{cout} flow_channels={flow_channels}: |out| {float(ref.abs().max()):.1f}; direct max {dmax:.2e} rms {drms:.2e}; f32 winograd max {wmax:.2e} '
+          f'rms {wrms:.2e}; bf16x3 winograd max {xmax:.2e} rms {xrms:.2e}; x3 / f32-winograd {xmax / wmax:.2f} / {xrms / wrms:.2f}; x3 / direct {xmax / dmax:.2f} / {xrms / drms:.2f}')
+    assert xrms <= 1.25 * wrms and xmax <= 1.25 * max(wmax, dmax)
+    assert xrms <= 3.0 * drms and xmax <= 4.0 * dmax
+
+
+def test_x3_gru_gates_on_saturated_state_and_large_flow(rpe):
+    """test_gpu_conv.test_gru_gates_on_saturated_state_and_large_flow on the variant (winograd bars): hidden state at +-1, flow channels at
+    +-50, pre-activations over +-30 -- saturated gates are 0 or 1 to rounding, nothing is NaN, the blend stays inside [-1, 1]."""
+    from rpe_amd import ops
+    c, b, h, w = 128, 2, 64, 80
+    rng = np.random.default_rng(77)
+    hx, wzr, _ = _trained_like(rng, b, 2 * c, 2 * c, 1, 5, h, w)
+    hx[:, :c] = torch.sign(hx[:, :c] - 1.0) * (1 - 1e-4 * torch.rand(b, c, h, w))
+    _, wq, _ = _trained_like(rng, b, 2 * c, c, 1, 5, h, w)
+    azr = torch.from_numpy(rng.normal(0, 10.0, size=(b, 2 * c, h, w)).astype(np.float32))
+    aq = torch.from_numpy(rng.normal(0, 10.0, size=(b, c, h, w)).astype(np.float32))
+    hid = hx[:, :c].double()
+    pre = _ref_conv(hx, wzr, None, azr)
+    z = torch.sigmoid(pre)[:, :c]
+    g_hx, g_rhx = hx.cuda(), hx.cuda().clone()
+    g_z = torch.empty(b, c, h, w, device='cuda')
+    ops.conv_wino1d(g_hx, ops.PackedWino1dX3(wzr.cuda()), ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
+    assert bool(torch.isfinite(g_z).all()) and float(g_z.min()) >= 0.0 and float(g_z.max()) <= 1.0
+    assert float((g_z.cpu().double() - z).abs().max()) < 0.25 * 2 * _tol(hx, wzr) + 2e-6
+    assert float(pre.abs().max()) > 25 and float((z < 1e-9).float().mean()) > 0.001 and float((z > 1 - 1e-9).float().mean()) > 0.001
+    rh = g_rhx[:, :c].cpu()
+    q = torch.tanh(_ref_conv(torch.cat((rh, hx[:, c:]), 1), wq, None, aq))
+    ops.conv_wino1d(g_rhx, ops.PackedWino1dX3(wq.cuda()), ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)
+    hnew = (1 - g_z.cpu().double()) * hid + g_z.cpu().double() * q
+    assert bool(torch.isfinite(g_hx).all()) and float(g_hx[:, :c].abs().max()) <= 1.0 + 1e-6
+    assert float((g_hx[:, :c].cpu().double() - hnew).abs().max()) < _tol(hx, wq) * 2 + 4e-6

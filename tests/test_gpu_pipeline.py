@@ -62,9 +62,11 @@ def test_raft_matches_oracle(models):
     assert low[-1].shape == (2, 2, H // 8, W // 8) and float((low[-1].cpu() - olow[-1]).abs().max()) < 5e-3
 
 
-def test_raft_matches_oracle_with_the_bf16x3_variant(models, monkeypatch):
+@pytest.mark.parametrize('gru', [False, True])
+def test_raft_matches_oracle_with_the_bf16x3_variant(models, monkeypatch, gru):
     """raft.CONV_BF16X3 (bench.py --conv-bf16x3): convc2 / conv / FlowHead.conv1 / the mask head's 3x3 through rpe_conv_wino_x3 and the
-    correlation through k_corr_build_x3.  Same pair, same oracle, same bars as test_raft_matches_oracle: the variant is f32-equivalent."""
+    correlation through k_corr_build_x3; with raft.X3_GRU also the SepConvGRU's 1x5 / 5x1 layers through rpe_conv_wino1d_x3 (opt-in: not
+    faster in the bench step).  Same pair, same oracle, same bars as test_raft_matches_oracle: the variant is f32-equivalent."""
     model, om, synth = models
     from rpe_amd import ops, raft
     fr = synth.stereo_frames(3, 1, H, W)
@@ -77,20 +79,28 @@ def test_raft_matches_oracle_with_the_bf16x3_variant(models, monkeypatch):
     def spy(x, pw, *a, **k):
         ran.append(type(pw).__name__)
         return real(x, pw, *a, **k)
+    real1d = ops.conv_wino1d
+
+    def spy1d(x, pw, *a, **k):
+        ran.append(type(pw).__name__)
+        return real1d(x, pw, *a, **k)
     monkeypatch.setattr(raft, 'CONV_BF16X3', True)
+    monkeypatch.setattr(raft, 'X3_GRU', gru)
     monkeypatch.setattr(ops, 'conv_wino', spy)
+    monkeypatch.setattr(ops, 'conv_wino1d', spy1d)
     try:
         flows, hid, ctx = model.flow(i1.cuda(), i2.cuda(), all_flows=True)
     finally:
         monkeypatch.undo()
         model.flow(i1.cuda(), i2.cuda())                     # back on the f32 packings for the tests that follow
     assert ran.count('PackedWinoX3') >= 4                    # convc2, conv, FlowHead.conv1 (prepared once), the mask head
+    assert (ran.count('PackedWino1dX3') >= 4) == gru         # the four GRU launches (prepared once)
     with torch.no_grad():
         oflows, ohid, octx = om.flow(i1, i2)
     d0 = float((flows[0].cpu() - oflows[0]).abs().max())
     d11 = float((flows[-1].cpu() - oflows[-1]).abs().max())
     dv = float((flows[-1] - base[-1]).abs().max())
-    print(f'bf16x3 variant: flow diff vs oracle iter0 {d0:.2e} px, iter11 {d11:.2e} px; vs the f32 route {dv:.2e} px')
+    print(f'bf16x3 variant (GRU {gru}): flow diff vs oracle iter0 {d0:.2e} px, iter11 {d11:.2e} px; vs the f32 route {dv:.2e} px')
     assert d0 < 1e-4 and d11 < 1e-3
     assert float((hid.cpu() - ohid).abs().max()) < 5e-3 and float((ctx.cpu() - octx).abs().max()) < 1e-3
 
