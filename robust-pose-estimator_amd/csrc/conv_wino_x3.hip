@@ -4,7 +4,8 @@
 // Replaces the same reference layers as conv_wino.hip (the reference's RAFT submodule, call sites core/pose/pose_net.py:47,65,129:
 // core/RAFT/core/update.py BasicMotionEncoder.convc2 / convf2 / conv, FlowHead.conv1; core/RAFT/core/extractor.py residual blocks).
 //
-// Arithmetic.  x = hi + mid + lo EXACTLY (truncation split of the 24-bit significand into three bf16 pieces of 8 bits), and
+// Arithmetic.  x = hi + mid + lo to 2^-27 |x| (three round-to-nearest bf16 parts, hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid),
+// the residuals exact in f32; the first version truncated: exact to 2^-24 but biased, maximum error up to 1.3x the f32 kernel's), and
 //     u v ~= uh vh + (uh vm + um vh) + (uh vl + ul vh + um vm),        f32 accumulation in the matrix core;
 // the dropped terms (um vl, ul vm, ul vl) are below 2^-24 |u v|, the rounding of the f32 product itself (k_corr_build_x3 measured this
 // scheme at 1.0-1.08x the f32 pipe's RMS error).  U = G g G^T is transformed in f32 and split ONCE at pack time; V = B^T d B
@@ -271,19 +272,20 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     // position nu (slot `sl`, index i = nu & 1 of its pair) of channel pair q: column pass, split, pack
     auto finish_nu = [&](auto qc, auto slc, auto nuc) {
         constexpr int q = decltype(qc)::value, sl = decltype(slc)::value, nu = decltype(nuc)::value, i = nu & 1;
-        float v[2], r1[2], r2[2];
+        float v[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 2; ++e)
             v[e] = nu == 0 ? tt[e][0] - tt[e][2] : nu == 1 ? tt[e][1] + tt[e][2] : nu == 2 ? tt[e][2] - tt[e][1] : tt[e][1] - tt[e][3];
-            const float h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[e]) & 0xFFFF0000u);
-            r1[e] = v[e] - h;                                                                  // exact
-            const float m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1[e]) & 0xFFFF0000u);
-            r2[e] = r1[e] - m;                                                                 // exact, at most 8 significant bits
-        }
-        // v_perm_b32: the high halves of (odd channel, even channel) -> [even | odd << 16]
-        unsigned ph = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[0]), 0x07060302u);
-        unsigned pm = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r1[1]), __builtin_bit_cast(unsigned, r1[0]), 0x07060302u);
-        unsigned pl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2[1]), __builtin_bit_cast(unsigned, r2[0]), 0x07060302u);
+        // round-to-nearest split: v_cvt_pk_bf16_f32 packs the channel pair's bf16 parts [even | odd << 16] in one instruction, the residual
+        // x - bf16(x) is exact in f32: x = hi + mid + lo to 2^-27 (truncation: 2^-24, biased), the same 11 instructions per pair
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        auto pack2 = [](float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_)); };
+        unsigned ph = pack2(v[0], v[1]);
+        const float r10 = v[0] - __builtin_bit_cast(float, ph << 16), r11 = v[1] - __builtin_bit_cast(float, ph & 0xFFFF0000u);
+        unsigned pm = pack2(r10, r11);
+        const float r20 = r10 - __builtin_bit_cast(float, pm << 16), r21 = r11 - __builtin_bit_cast(float, pm & 0xFFFF0000u);
+        unsigned pl = pack2(r20, r21);
         asm volatile("" : "+v"(ph), "+v"(pm), "+v"(pl));
         B[sl][i][0][q] = ph; B[sl][i][1][q] = pm; B[sl][i][2][q] = pl;
     };
@@ -601,12 +603,14 @@ __global__ void k_wino_pack_x3(const float* __restrict__ w, unsigned short* __re
         }
         v = nu == 0 ? col[0] : nu == 1 ? 0.5f * ((col[0] + col[1]) + col[2]) : nu == 2 ? 0.5f * ((col[0] - col[1]) + col[2]) : col[2];
     }
-    const unsigned u = __builtin_bit_cast(unsigned, v) & 0xFFFF0000u;
+    // round-to-nearest-even bf16 parts: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid), the residuals exact in f32
+    auto bf16_rne = [](float f) { unsigned b = __builtin_bit_cast(unsigned, f); b += 0x7FFFu + ((b >> 16) & 1u); return b & 0xFFFF0000u; };
+    const unsigned u = bf16_rne(v);
     const float r1 = v - __builtin_bit_cast(float, u);
-    const unsigned u1 = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    const unsigned u1 = bf16_rne(r1);
     const float r2 = r1 - __builtin_bit_cast(float, u1);
     unsigned short* d = wp + (e >> 9) * (3 * 512) + co32 * 16 + ci16;
-    d[0] = (unsigned short)(u >> 16); d[512] = (unsigned short)(u1 >> 16); d[1024] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    d[0] = (unsigned short)(u >> 16); d[512] = (unsigned short)(u1 >> 16); d[1024] = (unsigned short)(bf16_rne(r2) >> 16);
 }
 
 static inline int x3_cop(int cout) { return (cout + X_CO - 1) / X_CO * X_CO; }

@@ -203,7 +203,7 @@ class PoseEstimator(torch.nn.Module):
         if self.last_frame is None:
             rel = SE3.IdentityLike(self.last_pose)
             depth, stereo_flow, valid, cache = self.model.flow2depth(self.frame.img, self.frame.rimg,
-                                                                     self.baseline * self.scale, ret_cache=True, enc=enc)
+                                                                     self.baseline * self.scale, ret_cache=True, **({'enc': enc} if enc is not None else {}))
             self._enc_cache = cache if self.reuse_features else None
             self.frame.depth = depth / self.scale
             self.frame.flow = stereo_flow
@@ -212,7 +212,7 @@ class PoseEstimator(torch.nn.Module):
             self.last_frame.img, self.frame.img, self.intrinsics, self.baseline * self.scale,
             depth1=self.last_frame.depth * self.scale, image2r=self.frame.rimg, mask1=self.last_frame.mask,
             mask2=self.frame.mask, stereo_flow1=self.last_frame.flow, ret_details=True,
-            cache1=self._enc_cache, ret_cache=True, enc2=enc if self._enc_cache is not None else None)
+            cache1=self._enc_cache, ret_cache=True, **({'enc2': enc} if enc is not None and self._enc_cache is not None else {}))
         self._enc_cache = cache if self.reuse_features else None
         rel = SE3(rel.data.reshape(1, 7))
         self.frame.depth = depth2 / self.scale
