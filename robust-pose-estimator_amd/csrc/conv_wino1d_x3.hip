@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino1d_x3(W1X3P P) {
                 const int coc = co < P.cout ? co : P.cout - 1, oyc = oy < H ? oy : H - 1;
                 const size_t px = (size_t)oyc * W + e_oxc;
                 o[r].a = *(const f32x4*)(addb + (size_t)coc * hw + px);
-                if (EPI == 1) { o[r].h = o[r].a; if (co0 + 64 * hf >= cgt) o[r].h = *(const f32x4*)(hb + (size_t)(coc >= cgt ? coc - cgt : coc) * hw + px); o[r].z = o[r].a; }
+                if (EPI == 1) { o[r].h = o[r].a; if (co0 + 64 * hf + 63 >= cgt) o[r].h = *(const f32x4*)(hb + (size_t)(coc >= cgt ? coc - cgt : coc) * hw + px); o[r].z = o[r].a; }
                 else { o[r].z = *(const f32x4*)(zgb + (size_t)coc * hw + px); o[r].h = *(const f32x4*)(hb + (size_t)coc * hw + px); }
                 continue;
             }

@@ -303,3 +303,29 @@ def test_x3_gru_gates_on_saturated_state_and_large_flow(rpe):
     hnew = (1 - g_z.cpu().double()) * hid + g_z.cpu().double() * q
     assert bool(torch.isfinite(g_hx).all()) and float(g_hx[:, :c].abs().max()) <= 1.0 + 1e-6
     assert float((g_hx[:, :c].cpu().double() - hnew).abs().max()) < _tol(hx, wq) * 2 + 4e-6
+
+
+@pytest.mark.parametrize('kh,kw', [(1, 5), (5, 1)])
+def test_x3_gates_with_the_gate_boundary_inside_a_channel_half(rpe, kh, kw):
+    """48 hidden channels: z | r = 96 output channels, the boundary between z and r * h falls inside the kernel's first 64-channel half
+    (the hidden state must be fetched for a half that holds both kinds) and the tile's second half holds 32 channels."""
+    from rpe_amd import ops
+    c, b, h, w = 48, 2, 20, 24
+    rng = np.random.default_rng(kh + 3)
+    hx = _rand(rng, b, 2 * c, h, w, s=0.5)
+    wzr, azr = _rand(rng, 2 * c, 2 * c, kh, kw, s=0.05), _rand(rng, b, 2 * c, h, w, s=0.3)
+    wq, aq = _rand(rng, c, 2 * c, kh, kw, s=0.05), _rand(rng, b, c, h, w, s=0.3)
+    hid = hx[:, :c].double()
+    zr = torch.sigmoid(_ref_conv(hx, wzr, None, azr))
+    z, r = zr[:, :c], zr[:, c:]
+    g_hx, g_rhx = hx.cuda(), hx.cuda().clone()
+    g_z = torch.empty(b, c, h, w, device='cuda')
+    ops.conv_wino1d(g_hx, ops.PackedWino1dX3(wzr.cuda()), ops.CONV_GATE_ZR, g_z, out2=g_rhx[:, :c], add=azr.cuda(), hidden=g_hx[:, :c], gate_channels=c)
+    tz = _tol(hx, wzr) * 0.25 + 2e-7
+    assert (g_z.cpu().double() - z).abs().max() < tz
+    assert (g_rhx[:, :c].cpu().double() - r * hid).abs().max() < tz * float(hx.abs().max())
+    q = torch.tanh(_ref_conv(torch.cat((g_rhx[:, :c].cpu(), hx[:, c:]), 1), wq, None, aq))
+    ops.conv_wino1d(g_rhx, ops.PackedWino1dX3(wq.cuda()), ops.CONV_GATE_H, g_hx[:, :c], add=aq.cuda(), hidden=g_hx[:, :c], zgate=g_z)
+    hnew = (1 - g_z.cpu().double()) * hid + g_z.cpu().double() * q
+    assert (g_hx[:, :c].cpu().double() - hnew).abs().max() < _tol(hx, wq) + tz * 2
+    assert torch.equal(g_hx[:, c:].cpu(), hx[:, c:])

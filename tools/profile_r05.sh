@@ -23,3 +23,5 @@ tools/pmc_kernel.sh gpurun_out/pmc_r05_conv1x1 k_conv1x1 bench_conv1x1_only.py >
 tools/pmc_lookup.sh gpurun_out/pmc_r05_build --only build > /dev/null 2>&1; cp gpurun_out/pmc_r05_build/summary.txt gpurun_out/r05_pmc_corr_build.txt 2>/dev/null
 tools/pmc_bench.sh gpurun_out/pmc_r05_bench > /dev/null 2>&1; cp gpurun_out/pmc_r05_bench/summary.txt gpurun_out/r05_pmc_bench_lookup.txt; cp gpurun_out/pmc_r05_bench/pmc_traffic_bench.json gpurun_out/r05_pmc_traffic_bench.json 2>/dev/null
 ls -la gpurun_out/r05_*
+# only the summaries travel back (gpurun merges at most 64 MiB): drop the raw databases and counter CSVs
+rm -rf gpurun_out/prof_r05_bench gpurun_out/prof_r05_bench_x3 gpurun_out/prof_r05_tracker gpurun_out/prof_r05_conv1d_x3 gpurun_out/pmc_r05_*
