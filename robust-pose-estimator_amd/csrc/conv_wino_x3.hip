@@ -106,10 +106,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
     const int nsteps = P.cin / XK;
 
     // ---- DMA role: wave w brings channels 4w .. 4w+3 of the step: logical quad lq = 64 k + lane (< 432) -> (channel, row, quad column);
-    // out-of-map quads read a clamped in-map quad and are overwritten after landing (fix_raw).  Lanes past 432 repeat the last quad into
-    // the wave's 16 slack slots.  The seven per-lane offsets live in LDS (ROFF_AT; two 16-byte reads per step): the loop has no
+    // out-of-map quads are never requested (the lanes are masked out of the DMA instruction, their slots zeroed once) -- with the
+    // loader-side norm (PRE) they read a clamped in-map quad and are overwritten after landing with the rest of the patch-up (fix_raw).
+    // Lanes past 432 repeat the last quad into the wave's 16 slack slots.  The seven per-lane offsets live in LDS (ROFF_AT; two 16-byte reads per step): the loop has no
     // vector register to spare.
     unsigned oob = 0;
+    unsigned long long msk[7];                   // lanes of chunk k whose quad lies inside the map (the DMA request runs under this mask)
     {
         unsigned roff[8];
 #pragma unroll
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
             const int lq0 = 64 * k + lane, lq = lq0 < 432 ? lq0 : 431;
             const int cl = lq / X_QCH, rem = lq - cl * X_QCH, r = rem / 6, qc = rem - r * 6;
             int yy = y0 - 1 + r, xx = x0 - 4 + 4 * qc;
-            if (lq0 < 432 && (yy < 0 || yy >= H || xx < 0 || xx >= W)) oob |= 1u << k;
+            const bool out = lq0 < 432 && (yy < 0 || yy >= H || xx < 0 || xx >= W);
+            if (out) oob |= 1u << k;
+            msk[k] = __ballot(!out);
             yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy); xx = xx < 0 ? 0 : (xx >= W ? W - 4 : xx);
             roff[k] = (unsigned)((4 * wv + cl) * hw + yy * W + xx) * 4u + 3072u - 1024u * (k & 3);
         }
@@ -126,6 +130,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
         *(u32x4*)&smem[ROFF_AT + 8 * tid + 4] = (u32x4){roff[4], roff[5], roff[6], roff[7]};
     }
     const bool border = (y0 < 1) | (y0 + 16 >= H) | (x0 < 4) | (x0 + 16 >= W);              // workgroup-uniform
+    if (!PRE && border) {                                 // the wave's own slots of both buffers: zeros for the quads no request ever writes
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) *(f32x4*)&smem[b * X_RBUF + (wv * X_WQ + 64 * k + lane) * 4] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
     const unsigned smem_lds = lds_addr_of(&smem[0]);
     const unsigned rs_base = smem_lds + (unsigned)wv * (X_WQ * 16u) + 4u;                  // (+4: patch column 0 lands on an 8-byte boundary)
     const size_t rstep = (size_t)XK * hw;
@@ -150,16 +160,17 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
         dma_src = wave_uniform(xb + (size_t)step * rstep - 768);
         dma_lds = rs_base + (unsigned)buf * (X_RBUF * 4u);
     };
-    auto dma_chunk = [&rr_, &dma_src, &dma_lds](auto kc, unsigned long long lanes) {
+    auto dma_chunk = [&rr_, &dma_src, &dma_lds, &msk](auto kc, unsigned long long lanes) {
         constexpr int k = decltype(kc)::value;
         unsigned keep;
+        if (!PRE) lanes &= msk[k];                                       // (out-of-map quads are never written: their slots keep the zeros of the prologue)
         const unsigned la = dma_lds + (k >= 4 ? 4096u : 0u);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %5\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(rr_[k]), "s"(dma_src), "s"(la), "n"((k & 3) * 1024), "s"(lanes) : "memory");
     };
     // after landing: the lane patches ITS quads (no barrier needed in front): padding, and with PRE relu((x - mean) / std) in place
     auto fix_raw = [&](int step, int buf) {
-        if (!PRE && !border) return;
+        if (!PRE) return;                                                // (without the loader-side norm nothing is patched: masked requests, zeroed slots)
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int lq0 = 64 * k + lane;
@@ -354,7 +365,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_x3(WinoX3P P) {
 #ifdef X3_TIMING
     const unsigned long long Tp1 = __builtin_readcyclecounter();
 #endif
-    dma_raw(0, 0);
+    if (PRE) dma_raw(0, 0);
+    else {
+        typedef std::integral_constant<int, 4> J4; typedef std::integral_constant<int, 5> J5; typedef std::integral_constant<int, 6> J6;
+        dma_begin(0, 0);
+        dma_chunk(I0{}, all_lanes); dma_chunk(I1{}, all_lanes); dma_chunk(I2{}, all_lanes); dma_chunk(I3{}, all_lanes);
+        dma_chunk(J4{}, all_lanes); dma_chunk(J5{}, all_lanes); dma_chunk(J6{}, all_lanes);
+    }
     load_a(0, I0{}); load_a(0, I1{}); load_a(0, I2{}); load_piece(0, I3{}, I2{}); load_piece(0, I3{}, I1{});
     if (nsteps > 1) { dma_begin(1, 1); dma_chunk(I0{}, all_lanes); dma_chunk(I1{}, all_lanes); }          // (chunks 2-6 of DMA(1): the loop's first two stages)
     if (PRE) {
