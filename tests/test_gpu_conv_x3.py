@@ -329,3 +329,47 @@ def test_x3_gates_with_the_gate_boundary_inside_a_channel_half(rpe, kh, kw):
     hnew = (1 - g_z.cpu().double()) * hid + g_z.cpu().double() * q
     assert (g_hx[:, :c].cpu().double() - hnew).abs().max() < _tol(hx, wq) + tz * 2
     assert torch.equal(g_hx[:, c:].cpu(), hx[:, c:])
+
+
+def test_x3_kernels_agree_with_the_f32_kernels_on_random_shapes(rpe):
+    """Sixty random shapes per kernel (channel counts around the 32 / 64 / 128 tile edges, maps from one tile to several ragged patches,
+    every epilogue mode of the 1-D kernel): the variant against the f32 Winograd kernel on the same data, tolerance = twice the f64 bar of
+    either (both are within it of the exact result).  Destinations are pre-filled: nothing outside them may change."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(2025)
+    for it in range(60):
+        cin = 16 * int(rng.integers(1, 11)); cout = int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 130, 191, 256]))
+        h, w = int(rng.integers(1, 41)), 4 * int(rng.integers(1, 14)); b = int(rng.integers(1, 4))
+        kh, kw = ((1, 5), (5, 1))[it & 1]
+        mode = (ops.CONV_LINEAR, ops.CONV_RELU, ops.CONV_GATE_ZR, ops.CONV_GATE_H)[(it >> 1) & 3]
+        if mode == ops.CONV_GATE_ZR:
+            cout = 2 * max(1, cout // 2)
+        c = cout // 2 if mode == ops.CONV_GATE_ZR else cout
+        x, wt = _rand(rng, b, cin, h, w).cuda(), _rand(rng, cout, cin, kh, kw, s=0.05).cuda()
+        add, hid, z = _rand(rng, b, cout, h, w, s=0.3).cuda(), _rand(rng, b, c, h, w, s=0.5).cuda(), torch.rand(b, c, h, w).cuda()
+        outs = []
+        for P in (ops.PackedWino1d, ops.PackedWino1dX3):
+            o = torch.full((b, c + 2, h, w), -7.0, device='cuda'); o2 = torch.full((b, c + 2, h, w), -7.0, device='cuda')
+            kw_ = dict(add=add)
+            if mode == ops.CONV_GATE_ZR:
+                kw_.update(out2=o2[:, 1:1 + c], hidden=hid, gate_channels=c)
+            elif mode == ops.CONV_GATE_H:
+                kw_.update(hidden=hid, zgate=z)
+            ops.conv_wino1d(x, P(wt), mode, o[:, 1:1 + c], **kw_)
+            assert bool((o[:, 0] == -7.0).all()) and bool((o[:, 1 + c] == -7.0).all()), (it, cin, cout, h, w, kh, mode)
+            outs.append((o, o2))
+        tol = 4 * _tol(x.cpu(), wt.cpu())
+        assert float((outs[0][0] - outs[1][0]).abs().max()) < tol, (it, cin, cout, h, w, kh, mode)
+        if mode == ops.CONV_GATE_ZR:
+            assert float((outs[0][1] - outs[1][1]).abs().max()) < tol, (it, cin, cout, h, w, kh, mode)
+    for it in range(60):
+        cin = 16 * int(rng.integers(1, 11)); cout = int(rng.choice([1, 7, 31, 32, 33, 63, 64, 65, 96, 126, 128, 129, 192, 256]))
+        h, w = 2 * int(rng.integers(1, 21)), 4 * int(rng.integers(1, 14)); b = int(rng.integers(1, 4))
+        x, wt, bias = _rand(rng, b, cin, h, w).cuda(), _rand(rng, cout, cin, 3, 3, s=0.05).cuda(), _rand(rng, cout, s=0.5).cuda()
+        outs = []
+        for P in (ops.PackedWino, ops.PackedWinoX3):
+            o = torch.full((b, cout + 2, h, w), -7.0, device='cuda')
+            ops.conv_wino(x, P(wt, bias), ops.CONV_RELU if it & 1 else ops.CONV_LINEAR, o[:, 1:1 + cout])
+            assert bool((o[:, 0] == -7.0).all()) and bool((o[:, 1 + cout] == -7.0).all()), (it, cin, cout, h, w)
+            outs.append(o)
+        assert float((outs[0] - outs[1]).abs().max()) < 6 * _tol(x.cpu(), wt.cpu()), (it, cin, cout, h, w)
