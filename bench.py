@@ -104,13 +104,14 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-X3_DTYPE = ('f32 (RAFT / geometry; LABELLED VARIANT: f32 products of the update block\'s 3x3 layers with >= 128 input channels and of the correlation build '
+X3_DTYPE = ('f32 (RAFT / geometry; LABELLED VARIANT: f32 products of the update block\'s 3x3 layers with >= 128 input channels, of the 1x1 layers and of the correlation build '
             'as six bf16 products of an exact 3-way split, f32 accumulation) + f64 (SE(3) solve)')
-X3_FAMILIES = {'split (bf16x3)': ['k_conv_wino_x3: BasicMotionEncoder.convc2, .conv, FlowHead.conv1, mask head 3x3', 'k_corr_build_x3: correlation pyramid'],
+X3_FAMILIES = {'split (bf16x3)': ['k_conv_wino_x3: BasicMotionEncoder.convc2, .conv, FlowHead.conv1, mask head 3x3', 'k_conv1x1_x3: BasicMotionEncoder.convc1, the 1x1 output layers (fnet, cnet ReLU half, mask head)',
+                                  'k_corr_build_x3: correlation pyramid'],
                'f32 matrix cores (not split: measured no faster)': ['k_conv_wino: encoders\' 3x3 layers, convf2',
                                                                     'k_conv_wino1d: SepConvGRU 1x5 / 5x1 (k_conv_wino1d_x3 exists, raft.X3_GRU: 449 / 410 / 251 / 237 us per launch in this step '
                                                                     'against 407 / 395 / 240 / 224)',
-                                                                    'k_conv1x1 / k_conv_igemm: convc1, 1x1 layers, stride-2 layers', 'k_stem7x7: stems']}
+                                                                    'k_conv1x1 / k_conv_igemm: cnet tanh half, stride-2 layers', 'k_stem7x7: stems']}
 
 
 def free_port():

@@ -381,6 +381,14 @@ int rpe_conv_wino1d_x3(const rpe_conv_desc *desc, void *stream);
 size_t rpe_conv1x1_packed_floats(int cout, int cin);
 int rpe_conv1x1_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_conv1x1(const rpe_conv_desc *desc, void *stream);
+/* LABELLED VARIANT of rpe_conv1x1 (never in a headline number; bench.py --conv-bf16x3): the same GEMM with every f32 product as six bf16
+ * products of a three-way split on the 16-bit matrix cores, f32 accumulation (csrc/conv1x1_x3.hip; BasicMotionEncoder.convc1,
+ * core/RAFT/core/update.py; call sites core/pose/pose_net.py:47,65,129).  Same descriptor; supported: bias, out, out2, mode LINEAR / RELU;
+ * h * w % 4 == 0, 16-byte aligned input slice; anything else -> RPE_E_UNSUPPORTED (use rpe_conv1x1).  desc->packed must come from
+ * rpe_conv1x1_x3_pack (rpe_conv1x1_x3_packed_bytes bytes; 16-byte aligned). */
+size_t rpe_conv1x1_x3_packed_bytes(int cout, int cin);
+int rpe_conv1x1_x3_pack(const float *weight, int cout, int cin, void *packed, void *stream);
+int rpe_conv1x1_x3(const rpe_conv_desc *desc, void *stream);
 /* Generic convolution for every shape the tuned kernels above refuse (odd maps, rows that are not whole 16-byte quads): replaces
  * torch.nn.functional.conv2d(x, weight, bias, stride, padding) as the host code's fallback route, so that every convolution of the
  * reference's RAFT (core/RAFT/core/extractor.py, update.py) runs in this library for any img_size (configuration/infer_f2f.yaml:13).

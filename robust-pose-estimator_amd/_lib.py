@@ -92,6 +92,9 @@ SIGNATURES = {
     'rpe_conv_wino_x3_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino_x3': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv1x1': (_i, [_c.POINTER(ConvDesc), _vp]),
+    'rpe_conv1x1_x3_packed_bytes': (_sz, [_i, _i]),
+    'rpe_conv1x1_x3_pack': (_i, [_vp, _i, _i, _vp, _vp]),
+    'rpe_conv1x1_x3': (_i, [_c.POINTER(ConvDesc), _vp]),
     'rpe_conv_wino1d_packed_floats': (_sz, [_i, _i]),
     'rpe_conv_wino1d_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_conv_wino1d': (_i, [_c.POINTER(ConvDesc), _vp]),

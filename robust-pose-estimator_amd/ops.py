@@ -473,9 +473,25 @@ class PackedConv1x1:
         return (h * w) % 4 == 0 and h * w >= 4
 
 
+class PackedConv1x1X3:
+    """Weights of a 1x1 stride-1 convolution split three ways into bf16 for rpe_conv1x1_x3 (the labelled bf16x3 variant of rpe_conv1x1;
+    conv1x1 dispatches on the packing).  LINEAR / RELU only."""
+    x3 = True
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        if (self.kh, self.kw) != (1, 1):
+            raise _lib.RpeError('PackedConv1x1X3: weight must be (cout, cin, 1, 1)')
+        self.packed = torch.empty(lib().rpe_conv1x1_x3_packed_bytes(self.cout, self.cin) // 4, dtype=torch.float32, device=w.device)
+        check(lib().rpe_conv1x1_x3_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_conv1x1_x3_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+
 def conv1x1(x, pc, mode, out, out2=None, prepare=False):
-    """rpe_conv1x1: out = act(W x + bias) for a PackedConv1x1 (LINEAR / RELU / TANH), channel-slice destinations like conv_fused."""
-    return conv_fused(x, pc, mode, out, out2=out2, prepare=prepare, entry='rpe_conv1x1')
+    """rpe_conv1x1: out = act(W x + bias) for a PackedConv1x1 (LINEAR / RELU / TANH), channel-slice destinations like conv_fused
+    (a PackedConv1x1X3 runs rpe_conv1x1_x3)."""
+    return conv_fused(x, pc, mode, out, out2=out2, prepare=prepare, entry='rpe_conv1x1_x3' if getattr(pc, 'x3', False) else 'rpe_conv1x1')
 
 
 class Conv1x1:
@@ -487,7 +503,7 @@ class Conv1x1:
         self._w = _nchw(weight.detach().contiguous(), 'weight')
         self._b = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
         self.cout, self.cin = self._w.shape[0], self._w.shape[1]
-        self._fused = self._gemm = None
+        self._fused = self._gemm = self._gemm_x3 = None
 
     @property
     def fused(self):
@@ -501,11 +517,19 @@ class Conv1x1:
             self._gemm = PackedConv1x1(self._w, self._b)
         return self._gemm
 
-    def __call__(self, x, mode, out, out2=None, prepare=False):
+    @property
+    def gemm_x3(self):
+        if self._gemm_x3 is None:
+            self._gemm_x3 = PackedConv1x1X3(self._w, self._b)
+        return self._gemm_x3
+
+    def __call__(self, x, mode, out, out2=None, prepare=False, x3=False):
         b, _, hh, ww = x.shape
         # rpe_conv1x1's own preconditions (16-byte DMA pieces): plane size, base and batch stride of the input slice
         aligned = PackedConv1x1.supported(hh, ww) and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
         big = b * -(-(hh * ww) // 128) * -(-self.cout // 128) >= 512 and aligned
+        if big and x3 and mode in (CONV_LINEAR, CONV_RELU):        # the labelled bf16x3 variant (raft.CONV_BF16X3)
+            return conv1x1(x, self.gemm_x3, mode, out, out2=out2, prepare=prepare)
         if big:
             return conv1x1(x, self.gemm, mode, out, out2=out2, prepare=prepare)
         return conv_fused(x, self.fused, mode, out, out2=out2, prepare=prepare)

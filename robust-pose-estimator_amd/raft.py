@@ -299,9 +299,9 @@ class BasicEncoder(nn.Module):
                                                ops.Conv1x1(w[half:].contiguous(), bv[half:].contiguous()))
             out = torch.empty(b, m.out_channels, hh, ww, device=x.device)
             if not split_act:
-                return cached[1](x, ops.CONV_LINEAR, out)
+                return cached[1](x, ops.CONV_LINEAR, out, x3=CONV_BF16X3)
             cached[2](x, ops.CONV_TANH, out[:, :half])
-            cached[3](x, ops.CONV_RELU, out[:, half:])
+            cached[3](x, ops.CONV_RELU, out[:, half:], x3=CONV_BF16X3)
             return out
         y = ops.conv_direct(x, m.weight, m.bias, 1, 0)           # (maps whose rows are not whole 16-byte quads)
         if split_act:
@@ -379,7 +379,7 @@ class BasicMotionEncoder(nn.Module):
                     return ops.conv_wino(x, wino[name], ops.CONV_RELU, out, out2=out2, prepare=True)
                 return ops.conv_fused(x, packed[name], ops.CONV_RELU, out, out2=out2, prepare=True)
             calls = (key, cor, flo,
-                     packed['convc1_1x1'](corr, ops.CONV_RELU, cor, prepare=True),
+                     packed['convc1_1x1'](corr, ops.CONV_RELU, cor, prepare=True, x3=CONV_BF16X3),
                      c3('convc2', cor, cat_buf[:, :192]), c3('convf2', flo, cat_buf[:, 192:]),
                      c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
             _bounded_put(cache, key, calls, keep=4)
@@ -583,7 +583,7 @@ class BasicUpdateBlock(nn.Module):
         else:
             t = ops.conv_direct(net, c1.weight, c1.bias, 1, 1, relu=True)
         if p2 is not None and ww % 4 == 0 and not torch.is_grad_enabled():
-            return p2(t, ops.CONV_LINEAR, torch.empty(net.shape[0], c2.out_channels, hh, ww, device=net.device))
+            return p2(t, ops.CONV_LINEAR, torch.empty(net.shape[0], c2.out_channels, hh, ww, device=net.device), x3=CONV_BF16X3)
         return ops.conv_direct(t, w2, b2, 1, 0)
 
 

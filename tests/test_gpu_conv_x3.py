@@ -373,3 +373,54 @@ def test_x3_kernels_agree_with_the_f32_kernels_on_random_shapes(rpe):
             assert bool((o[:, 0] == -7.0).all()) and bool((o[:, 1 + cout] == -7.0).all()), (it, cin, cout, h, w)
             outs.append(o)
         assert float((outs[0] - outs[1]).abs().max()) < 6 * _tol(x.cpu(), wt.cpu()), (it, cin, cout, h, w)
+
+
+# ---- rpe_conv1x1_x3: 1x1 layers as bf16x3 GEMMs (csrc/conv1x1_x3.hip), the variant of rpe_conv1x1 ------------------------------------------
+
+@pytest.mark.parametrize('cin,cout,h,w,b,relu', [(324, 256, 64, 80, 2, True), (128, 256, 64, 80, 3, False), (256, 576, 32, 40, 1, False),
+                                                 (16, 128, 16, 16, 2, True), (40, 96, 20, 28, 1, False), (324, 130, 6, 10, 3, True), (8, 5, 2, 2, 1, False)])
+def test_x3_conv1x1_matches_f64(rpe, cin, cout, h, w, b, relu):
+    """convc1's shape (324 input channels: the last step is ragged), the encoders' and the mask head's output layers, channel counts that are
+    not multiples of the 128-channel tile, maps that are not whole 256-pixel runs (down to one quad): against f64 at the f32 kernel's bar,
+    on channel slices, with the second destination, through the prepared launcher; neighbours untouched."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(cin + cout + h)
+    x, wt, bias = _rand(rng, b, cin, h, w), _rand(rng, cout, cin, 1, 1, s=0.05), _rand(rng, cout, s=0.5)
+    ref = F.conv2d(x.double(), wt.double(), bias.double())
+    ref = ref.clamp_min(0) if relu else ref
+    mode = ops.CONV_RELU if relu else ops.CONV_LINEAR
+    xbuf = torch.full((b, cin + 8, h, w), float('nan'), device='cuda'); xbuf[:, 4:4 + cin] = x.cuda()
+    obuf = torch.full((b, cout + 8, h, w), -7.0, device='cuda'); o2buf = torch.full((b, cout + 4, h, w), -7.0, device='cuda')
+    px = ops.PackedConv1x1X3(wt.cuda(), bias.cuda())
+    ops.conv1x1(xbuf[:, 4:4 + cin], px, mode, obuf[:, 4:4 + cout], out2=o2buf[:, 4:])
+    assert (obuf[:, 4:4 + cout].cpu().double() - ref).abs().max() < _tol(x, wt)
+    assert torch.equal(obuf[:, 4:4 + cout], o2buf[:, 4:])
+    assert (obuf[:, :4] == -7.0).all() and (obuf[:, 4 + cout:] == -7.0).all() and (o2buf[:, :4] == -7.0).all()
+    again = torch.empty(b, cout, h, w, device='cuda')
+    ops.conv1x1(x.cuda(), px, mode, again, prepare=True)()
+    assert torch.equal(again, obuf[:, 4:4 + cout])
+    # against the f32 kernel on the same data
+    f32 = ops.conv1x1(x.cuda(), ops.PackedConv1x1(wt.cuda(), bias.cuda()), mode, torch.empty(b, cout, h, w, device='cuda'))
+    assert (f32 - again).abs().max() < 2 * _tol(x, wt)
+
+
+def test_x3_conv1x1_rejects_what_it_cannot_do_and_error_bars(rpe):
+    from rpe_amd import ops
+    px = ops.PackedConv1x1X3(torch.zeros(8, 16, 1, 1, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):                      # tanh stays on rpe_conv1x1
+        ops.conv1x1(torch.zeros(1, 16, 4, 4, device='cuda'), px, ops.CONV_TANH, torch.empty(1, 8, 4, 4, device='cuda'))
+    with pytest.raises(rpe.RpeError, match='UNSUPPORTED'):                      # planes that are not whole 16-byte quads
+        ops.conv1x1(torch.zeros(1, 16, 3, 5, device='cuda'), px, ops.CONV_LINEAR, torch.empty(1, 8, 3, 5, device='cuda'))
+    with pytest.raises(rpe.RpeError):
+        ops.PackedConv1x1X3(torch.zeros(8, 16, 3, 3, device='cuda'))
+    # trained-like statistics (heavy-tailed weights, post-ReLU activations): error against f64 at most 1.25x the f32 kernel's (RMS and max)
+    rng = np.random.default_rng(11)
+    for cin, cout in ((324, 256), (128, 256)):
+        x, wt, bias = _trained_like(rng, 2, cin, cout, 1, 1, 64, 80)
+        ref = F.conv2d(x.double(), wt.double(), bias.double())
+        f32 = ops.conv1x1(x.cuda(), ops.PackedConv1x1(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(2, cout, 64, 80, device='cuda'))
+        x3 = ops.conv1x1(x.cuda(), ops.PackedConv1x1X3(wt.cuda(), bias.cuda()), ops.CONV_LINEAR, torch.empty(2, cout, 64, 80, device='cuda'))
+        fmax, frms = _errs(f32, ref)
+        xmax, xrms = _errs(x3, ref)
+        print(f'1x1 {cin}->{cout}: f32 max {fmax:.2e} rms {frms:.2e}; bf16x3 max {xmax:.2e} rms {xrms:.2e}; ratios {xmax / fmax:.2f} / {xrms / frms:.2f}')
+        assert xrms <= 1.25 * frms and xmax <= 1.25 * fmax
