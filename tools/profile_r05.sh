@@ -19,7 +19,7 @@ tail -1 gpurun_out/prof_r05_bench.log | cut -c1-200; tail -1 gpurun_out/prof_r05
 CONV_ONLY=convc2 tools/pmc_kernel.sh gpurun_out/pmc_r05_wino k_conv_wino bench_conv_x3.py > /dev/null 2>&1; cp gpurun_out/pmc_r05_wino/summary.txt gpurun_out/r05_pmc_conv_wino_and_x3.txt
 CONV_ONLY=gru tools/pmc_kernel.sh gpurun_out/pmc_r05_wino1d k_conv_wino1d bench_conv_wino.py > /dev/null 2>&1; cp gpurun_out/pmc_r05_wino1d/summary.txt gpurun_out/r05_pmc_conv_wino1d.txt
 CONV_N=32 tools/pmc_kernel.sh gpurun_out/pmc_r05_wino1d_x3 k_conv_wino1d bench_conv1d_x3.py > /dev/null 2>&1; cp gpurun_out/pmc_r05_wino1d_x3/summary.txt gpurun_out/r05_pmc_conv_wino1d_and_x3.txt
-tools/pmc_kernel.sh gpurun_out/pmc_r05_conv1x1 k_conv1x1 bench_conv1x1_only.py > /dev/null 2>&1; cp gpurun_out/pmc_r05_conv1x1/summary.txt gpurun_out/r05_pmc_conv1x1.txt
+tools/pmc_kernel.sh gpurun_out/pmc_r05_conv1x1 k_conv1x1 bench_conv1x1_x3.py > /dev/null 2>&1; cp gpurun_out/pmc_r05_conv1x1/summary.txt gpurun_out/r05_pmc_conv1x1.txt
 tools/pmc_lookup.sh gpurun_out/pmc_r05_build --only build > /dev/null 2>&1; cp gpurun_out/pmc_r05_build/summary.txt gpurun_out/r05_pmc_corr_build.txt 2>/dev/null
 tools/pmc_bench.sh gpurun_out/pmc_r05_bench > /dev/null 2>&1; cp gpurun_out/pmc_r05_bench/summary.txt gpurun_out/r05_pmc_bench_lookup.txt; cp gpurun_out/pmc_r05_bench/pmc_traffic_bench.json gpurun_out/r05_pmc_traffic_bench.json 2>/dev/null
 ls -la gpurun_out/r05_*
