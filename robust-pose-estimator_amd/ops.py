@@ -528,7 +528,8 @@ class Conv1x1:
         # rpe_conv1x1's own preconditions (16-byte DMA pieces): plane size, base and batch stride of the input slice
         aligned = PackedConv1x1.supported(hh, ww) and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
         big = b * -(-(hh * ww) // 128) * -(-self.cout // 128) >= 512 and aligned
-        if big and x3 and mode in (CONV_LINEAR, CONV_RELU):        # the labelled bf16x3 variant (raft.CONV_BF16X3)
+        if aligned and x3 and mode in (CONV_LINEAR, CONV_RELU):     # the labelled bf16x3 variant (raft.CONV_BF16X3): at EVERY launch size, so that a
+            #                                                            row's bits do not depend on the batch it is launched in
             return conv1x1(x, self.gemm_x3, mode, out, out2=out2, prepare=prepare)
         if big:
             return conv1x1(x, self.gemm, mode, out, out2=out2, prepare=prepare)
