@@ -325,8 +325,10 @@ def run_batch(args, rank, world, dev, dist):
 
     last_lookup = {}
 
-    def timed_lookup(self, coords, out=None):
-        last_lookup['pyr'], last_lookup['coords'], last_lookup['out'] = self, coords, out
+    def timed_lookup(self, coords, out=None, prepare=False):
+        last_lookup['pyr'], last_lookup['coords'], last_lookup['out'] = self, coords, out      # (the loop's persistent buffers: coords1 / corr of the workspace)
+        if prepare:
+            return real_lookup(self, coords, out, prepare=True)
         if not timing['on']:
             return real_lookup(self, coords, out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -337,6 +339,19 @@ def run_batch(args, rank, world, dev, dist):
         return r
 
     rpe_amd.ops.CorrPyramid.lookup = timed_lookup
+    # The product enqueues the update loop as ONE launch list (raft.LOOP_OPLIST -> rpe_run_ops), so the lookup is not a Python call any
+    # more: the list itself records raw HIP events around each iteration's lookup when raft.LOOKUP_EVENT_SINK hands it some.  One pair per
+    # lookup launch of the timed region, created up front (no event is created, and no extra record issued, inside the timed region).
+    from rpe_amd import _lib as _rpe_lib
+    raw_ev = _rpe_lib.RawEvents(2 * args.raft_iters * max(1, args.steps))
+    raw_used = [0]
+
+    def lookup_sink(iters):
+        k = raw_used[0]
+        if k + 2 * iters > len(raw_ev.handles):          # (more passes than planned: those run untimed)
+            return [None] * (2 * iters)
+        raw_used[0] = k + 2 * iters
+        return raw_ev.handles[k:k + 2 * iters]
 
     solve_events = []
     real_solve = rpe_amd.ops.pose_solve
@@ -377,6 +392,7 @@ def run_batch(args, rank, world, dev, dist):
                 else:
                     conv_events.append((e0, e1, flop))
                 return r
+            timed_launch.op, timed_launch.keep = launch.op, launch.keep      # (a launch list takes the real argument block: no Python in between)
             return timed_launch
         if not timing['conv']:
             return real_conv(x, pc, *a, **k)
@@ -421,6 +437,7 @@ def run_batch(args, rank, world, dev, dist):
             e1.record()
             wino_events.append((e0, e1, direct * 4.0 / 9.0, direct))
             return r
+        timed_launch.op, timed_launch.keep = launch.op, launch.keep
         return timed_launch
 
     rpe_amd.ops.conv_wino = timed_wino
@@ -431,10 +448,12 @@ def run_batch(args, rank, world, dev, dist):
 
     def timed_step():
         timing['on'] = True
+        raft_mod.LOOKUP_EVENT_SINK = lookup_sink
         try:
             return step()
         finally:
             timing['on'] = False
+            raft_mod.LOOKUP_EVENT_SINK = None
 
     step()                                         # set-up pass (untimed, not a warm-up step): weights are packed and the
     torch.cuda.synchronize()                       # persistent workspaces / launch descriptors built on first use
@@ -464,6 +483,7 @@ def run_batch(args, rank, world, dev, dist):
     conv_steps = 2                                 # diagnostic pass: the same step with every convolution launch bracketed by HIP events
     timing['conv'] = True
     enc_streams, raft_mod.ENC_STREAMS = raft_mod.ENC_STREAMS, False     # one stream: a launch's duration is its own, not two overlapping launches'
+    loop_oplist, raft_mod.LOOP_OPLIST = raft_mod.LOOP_OPLIST, False     # launch by launch from Python: the wrappers above bracket each launch with events
     try:
         for _ in range(conv_steps):
             step()
@@ -471,8 +491,9 @@ def run_batch(args, rank, world, dev, dist):
     finally:
         timing['conv'] = False
         raft_mod.ENC_STREAMS = enc_streams
+        raft_mod.LOOP_OPLIST = loop_oplist
     info = model.pose_head.problem.last_info.cpu()
-    lk_ms = sorted(a.elapsed_time(b) for a, b in lookup_events)
+    lk_ms = sorted([a.elapsed_time(b) for a, b in lookup_events] + [raw_ev.elapsed_ms(i, i + 1) for i in range(0, raw_used[0], 2)])
     lk_avg_s = sum(lk_ms) / max(1, len(lk_ms)) / 1e3
 
     def pct(q):
@@ -706,6 +727,7 @@ def deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_
     finally:
         model.pose_head.problem.lbgfs_iters = keep
     out['tracker_fps'] = F / dt
+    out.update(tracker_split(model, seq, slam, frames, W, H, dev))
     # the same walk with the next frame's encoders prefetched on a side stream (PoseEstimator.submit / result; poses bit-identical)
     model.pose_head.problem.lbgfs_iters = 20
     try:
@@ -778,6 +800,76 @@ def deployment_numbers(args, model, cfg, frames, gpu_in, mask2_init, dev, solve_
         finally:
             prob.solver = 'lbfgs'
     return out
+
+
+def tracker_split(model, seq, slam, frames, W, H, dev):
+    """Is the sequential tracker host-bound or GPU-bound on THIS box?  The same frames as ``tracker_fps``, per steady-state frame (medians
+    over frames 2..F): ``tracker_gpu_ms_per_frame`` = HIP events around PoseEstimator.forward; ``tracker_host_enqueue_ms_per_frame`` =
+    perf_counter from the call to the moment the last launch has been handed to the runtime (PoseEstimator.t_enqueued, taken right
+    before the success-flag synchronisation); ``tracker_wall_ms_per_frame``; the launch counts of one frame; and the same walk with
+    the update loop launched call by call from Python (raft.LOOP_OPLIST = False) for the A/B on one box."""
+    import statistics
+    import warnings
+    from rpe_amd import _lib as rl
+    from rpe_amd import pose_estimator
+    from rpe_amd import raft as raft_mod
+    F = len(seq)
+    res = {}
+
+    def walk(est, rec=None):
+        for i, (l, r, m) in enumerate(seq):
+            mm = m.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            est(l, r, mm)
+            e1.record()
+            t1 = time.perf_counter()
+            if rec is not None and i >= 2:
+                rec.append((est.t_enqueued - t0, t1 - t0, e0, e1))
+    keep = model.pose_head.problem.lbgfs_iters
+    model.pose_head.problem.lbgfs_iters = 20
+    keep_list, keep_frame = raft_mod.LOOP_OPLIST, raft_mod.FRAME_OPLISTS
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for oplist in (False, True):
+                raft_mod.LOOP_OPLIST = raft_mod.FRAME_OPLISTS = oplist
+                for rep in range(2):
+                    rec = []
+                    est = pose_estimator.PoseEstimator(slam, frames['K'][0], 7.2 * 250.0, model, (W, H)).to(dev)
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    walk(est, rec)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t
+                med = lambda v: statistics.median(v)
+                if oplist:
+                    res['tracker_gpu_ms_per_frame'] = med([a.elapsed_time(b) for _, _, a, b in rec])
+                    res['tracker_host_enqueue_ms_per_frame'] = 1e3 * med([h for h, _, _, _ in rec])
+                    res['tracker_wall_ms_per_frame'] = 1e3 * med([w for _, w, _, _ in rec])
+                    res['tracker_fps_with_events'] = F / dt
+                else:
+                    res['tracker_launch_by_launch'] = {'fps': F / dt, 'host_enqueue_ms_per_frame': 1e3 * med([h for h, _, _, _ in rec]),
+                                                       'gpu_ms_per_frame': med([a.elapsed_time(b) for _, _, a, b in rec]),
+                                                       'config': 'raft.LOOP_OPLIST = raft.FRAME_OPLISTS = False: every launch dispatched from Python (rounds 1-5)'}
+            # launch counts of one steady-state frame
+            raft_mod.LOOP_OPLIST = raft_mod.FRAME_OPLISTS = True
+            est = pose_estimator.PoseEstimator(slam, frames['K'][0], 7.2 * 250.0, model, (W, H)).to(dev)
+            for l, r, m in seq[:3]:
+                est(l, r, m.clone())
+            l, r, m = seq[3]
+            with rl.CountingLib() as counter:
+                est(l, r, m.clone())
+            torch.cuda.synchronize()
+            res['tracker_launches_per_frame'] = {'entry_point_calls_from_python': counter.calls, 'ops_enqueued_by_launch_lists': counter.list_ops,
+                                                 'note': 'an entry point is one kernel launch except rpe_pose_solve_ex (2 per evaluation), rpe_unet_heads (15) and '
+                                                         'rpe_corr_build_ex; kernel counts per frame: profiles/r06_tracker_kernel_stats_last_frame.txt'}
+    finally:
+        model.pose_head.problem.lbgfs_iters = keep
+        raft_mod.LOOP_OPLIST, raft_mod.FRAME_OPLISTS = keep_list, keep_frame
+    res['tracker_bound'] = 'gpu' if res['tracker_host_enqueue_ms_per_frame'] <= 0.5 * res['tracker_gpu_ms_per_frame'] else 'host (enqueue > half of the GPU time)'
+    return res
 
 
 def pose_roofline(events, frames, h, w, iters):

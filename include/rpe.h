@@ -425,6 +425,62 @@ int rpe_instnorm_apply_ex(const float *x, const float *partials, int tiles, int 
  * next rpe_conv_fused, which then normalises its input on the fly (no separate pass for norm1 + ReLU of a ResidualBlock). */
 int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw, float eps, float *mean_inv, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Prepared launch lists -- replace the HOST loop around the kernels above: RAFT.forward's `for itr in range(iters)` over lookup ->
+ * motion encoder -> SepConvGRU -> flow head (core/RAFT/core/raft.py; call sites core/pose/pose_net.py:47,65,129) and the encoders'
+ * layer-by-layer walk (core/RAFT/core/extractor.py), which the reference runs as hundreds of Python-dispatched launches per frame
+ * (scripts/infer_trajectory.py:57,71-77 tracks one frame at a time: ~330 launches of 10-50 us each, i.e. the host decides the frame rate).
+ * A list is an array of rpe_op in caller-owned host memory: each op names an entry point of this header (`kind`), the argument block that
+ * entry point would be called with (`args`: the rpe_conv_desc of the convolutions, one of the rpe_*_args structs below for the others --
+ * the same values in the same order as the function's parameters) and the stream it goes to (`stream` = index into the `streams` array of
+ * the call).  rpe_run_ops walks the list once, calling the SAME entry points -- same checks, same kernels, same bits as calling them one
+ * by one -- and stops at the first op that fails (its index goes to *failed_op, its status is returned).  The list and everything it
+ * points to must stay alive and unchanged for the duration of the call only (launches are asynchronous; the argument blocks are consumed
+ * at enqueue time); the caller may patch pointers inside the argument blocks between calls (new input / output buffers).
+ * Fork / join between the streams of a list: RPE_OP_EVENT_RECORD records, RPE_OP_STREAM_WAIT makes streams[op.stream] wait for, the
+ * hipEvent_t whose handle is stored at `args` (args = address of a void* cell holding the handle; a NULL handle makes the op a no-op, so a
+ * caller can keep timing events in a list and arm them only when it measures).  No state is kept between calls. */
+#define RPE_OP_CONV_FUSED 1        /* args: const rpe_conv_desc *  -> rpe_conv_fused       */
+#define RPE_OP_CONV_WINO 2         /*       const rpe_conv_desc *  -> rpe_conv_wino        */
+#define RPE_OP_CONV_WINO1D 3       /*       const rpe_conv_desc *  -> rpe_conv_wino1d      */
+#define RPE_OP_CONV1X1 4           /*       const rpe_conv_desc *  -> rpe_conv1x1          */
+#define RPE_OP_CONV_WINO_X3 5      /*       const rpe_conv_desc *  -> rpe_conv_wino_x3     */
+#define RPE_OP_CONV_WINO1D_X3 6    /*       const rpe_conv_desc *  -> rpe_conv_wino1d_x3   */
+#define RPE_OP_CONV1X1_X3 7        /*       const rpe_conv_desc *  -> rpe_conv1x1_x3       */
+#define RPE_OP_CORR_LOOKUP 8       /*       const rpe_corr_lookup_args *                   */
+#define RPE_OP_STEM_CONV 9         /*       const rpe_stem_conv_args *                     */
+#define RPE_OP_FLOW_UPDATE 10      /*       const rpe_flow_update_args * -> rpe_conv3x3_to2_flow */
+#define RPE_OP_COPY_PLANES 11      /*       const rpe_copy_planes_args *                   */
+#define RPE_OP_INSTNORM_FINALIZE 12 /*      const rpe_instnorm_finalize_args *             */
+#define RPE_OP_INSTNORM_APPLY 13   /*       const rpe_instnorm_apply_args * -> rpe_instnorm_apply_ex */
+#define RPE_OP_UPSAMPLE_CONVEX 14  /*       const rpe_upsample_convex_args *               */
+#define RPE_OP_CORR_BUILD 15       /*       const rpe_corr_build_args * -> rpe_corr_build_ex */
+#define RPE_OP_EVENT_RECORD 32     /*       void *const * (address of a hipEvent_t handle; NULL handle = no-op) */
+#define RPE_OP_STREAM_WAIT 33      /*       void *const * (the same)                       */
+typedef struct rpe_op {
+    int kind;                      /* RPE_OP_*                                             */
+    int stream;                    /* index into rpe_run_ops' streams[]                    */
+    const void *args;
+} rpe_op;
+typedef struct rpe_corr_lookup_args { const void *pyramid; const float *coords; int b, h8, w8, levels, radius; float *out; } rpe_corr_lookup_args;
+typedef struct rpe_corr_build_args { const float *fmap1, *fmap2; int b, c, h8, w8, levels, feature_dtype; void *pyramid; } rpe_corr_build_args;
+typedef struct rpe_stem_conv_args {
+    const float *image; int b, cin, h, w, stride; float div, mul, sub; const float *packed; int cout; const float *bias, *scale; int relu;
+    float *out, *stats;
+} rpe_stem_conv_args;
+typedef struct rpe_flow_update_args {
+    const float *x, *weight, *bias; int b, c, h, w; const float *coords; float *coords_out, *flow_out, *dst1; long long dst1_batch_stride;
+    float *dst2; long long dst2_batch_stride;
+} rpe_flow_update_args;
+typedef struct rpe_copy_planes_args { const float *src; long long src_batch_stride; float *dst; long long dst_batch_stride; int b, c, hw; } rpe_copy_planes_args;
+typedef struct rpe_instnorm_finalize_args { const float *partials; int tiles, b, c, hw; float eps; float *mean_inv; } rpe_instnorm_finalize_args;
+typedef struct rpe_instnorm_apply_args {
+    const float *x, *partials; int tiles, b, c, hw; float eps; int relu; const float *residual, *residual_mean_inv; float *out;
+} rpe_instnorm_apply_args;
+typedef struct rpe_upsample_convex_args { const float *flow, *mask; int b, h8, w8; float *out; } rpe_upsample_convex_args;
+/* streams: n_streams hipStream_t handles (NULL = the default stream).  failed_op may be NULL. */
+int rpe_run_ops(const rpe_op *ops, int n_ops, void *const *streams, int n_streams, int *failed_op);
+
 /* ---- The two weight heads of PoseNet (core/pose/pose_net.py:109-115: torch.cat of the 1/8 stacks with the GRU hidden
  * state and the context -> TinyUNet(264) / TinyUNet(272), core/unet/unet.py:7-82 -> bilinear resize to (H, W) -> Sigmoid)
  * as one chain of 15 launches for both heads and all frames (csrc/unet.hip), inference-mode batch norm folded.

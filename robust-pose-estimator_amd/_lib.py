@@ -31,6 +31,56 @@ class ConvDesc(_c.Structure):
                 ('gate_channels', _i), ('stride', _i), ('stats_tiles', _i)]
 
 
+class Op(_c.Structure):
+    """struct rpe_op (include/rpe.h, prepared launch lists)."""
+    _fields_ = [('kind', _i), ('stream', _i), ('args', _vp)]
+
+
+_fl = _c.c_float
+
+
+class CorrLookupArgs(_c.Structure):
+    _fields_ = [('pyramid', _vp), ('coords', _vp), ('b', _i), ('h8', _i), ('w8', _i), ('levels', _i), ('radius', _i), ('out', _vp)]
+
+
+class CorrBuildArgs(_c.Structure):
+    _fields_ = [('fmap1', _vp), ('fmap2', _vp), ('b', _i), ('c', _i), ('h8', _i), ('w8', _i), ('levels', _i), ('feature_dtype', _i), ('pyramid', _vp)]
+
+
+class StemConvArgs(_c.Structure):
+    _fields_ = [('image', _vp), ('b', _i), ('cin', _i), ('h', _i), ('w', _i), ('stride', _i), ('div', _fl), ('mul', _fl), ('sub', _fl), ('packed', _vp),
+                ('cout', _i), ('bias', _vp), ('scale', _vp), ('relu', _i), ('out', _vp), ('stats', _vp)]
+
+
+class FlowUpdateArgs(_c.Structure):
+    _fields_ = [('x', _vp), ('weight', _vp), ('bias', _vp), ('b', _i), ('c', _i), ('h', _i), ('w', _i), ('coords', _vp), ('coords_out', _vp),
+                ('flow_out', _vp), ('dst1', _vp), ('dst1_batch_stride', _ll), ('dst2', _vp), ('dst2_batch_stride', _ll)]
+
+
+class CopyPlanesArgs(_c.Structure):
+    _fields_ = [('src', _vp), ('src_batch_stride', _ll), ('dst', _vp), ('dst_batch_stride', _ll), ('b', _i), ('c', _i), ('hw', _i)]
+
+
+class InstnormFinalizeArgs(_c.Structure):
+    _fields_ = [('partials', _vp), ('tiles', _i), ('b', _i), ('c', _i), ('hw', _i), ('eps', _fl), ('mean_inv', _vp)]
+
+
+class InstnormApplyArgs(_c.Structure):
+    _fields_ = [('x', _vp), ('partials', _vp), ('tiles', _i), ('b', _i), ('c', _i), ('hw', _i), ('eps', _fl), ('relu', _i), ('residual', _vp),
+                ('residual_mean_inv', _vp), ('out', _vp)]
+
+
+class UpsampleConvexArgs(_c.Structure):
+    _fields_ = [('flow', _vp), ('mask', _vp), ('b', _i), ('h8', _i), ('w8', _i), ('out', _vp)]
+
+
+# RPE_OP_* of include/rpe.h
+OP_CONV_FUSED, OP_CONV_WINO, OP_CONV_WINO1D, OP_CONV1X1, OP_CONV_WINO_X3, OP_CONV_WINO1D_X3, OP_CONV1X1_X3 = 1, 2, 3, 4, 5, 6, 7
+OP_CORR_LOOKUP, OP_STEM_CONV, OP_FLOW_UPDATE, OP_COPY_PLANES, OP_INSTNORM_FINALIZE, OP_INSTNORM_APPLY, OP_UPSAMPLE_CONVEX, OP_CORR_BUILD = 8, 9, 10, 11, 12, 13, 14, 15
+OP_EVENT_RECORD, OP_STREAM_WAIT = 32, 33
+OP_OF_ENTRY = {'rpe_conv_fused': OP_CONV_FUSED, 'rpe_conv_wino': OP_CONV_WINO, 'rpe_conv_wino1d': OP_CONV_WINO1D, 'rpe_conv1x1': OP_CONV1X1,
+               'rpe_conv_wino_x3': OP_CONV_WINO_X3, 'rpe_conv_wino1d_x3': OP_CONV_WINO1D_X3, 'rpe_conv1x1_x3': OP_CONV1X1_X3}
+
 ABI_VERSION = 5            # RPE_ABI_VERSION of include/rpe.h these struct mirrors were written against
 
 
@@ -113,6 +163,7 @@ SIGNATURES = {
     'rpe_stem_packed_floats': (_sz, [_i, _i]),
     'rpe_stem_pack': (_i, [_vp, _i, _i, _vp, _vp]),
     'rpe_stem_conv': (_i, [_vp, _i, _i, _i, _i, _i, _c.c_float, _c.c_float, _c.c_float, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    'rpe_run_ops': (_i, [_c.POINTER(Op), _i, _c.POINTER(_vp), _i, _c.POINTER(_i)]),
     'rpe_mask_specularities': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_resize_crop_mask': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -156,6 +207,39 @@ def lib():
     return _lib
 
 
+class CountingLib:
+    """Stands in for the loaded library (``with CountingLib() as c:``): counts the entry-point calls Python makes (``calls``; size queries
+    are not launches) and the ops launch lists enqueue on top (``list_ops`` = rpe_run_ops' n_ops).  ops.Recorder uses it to prove that it
+    logged every launch of the pass it recorded; bench.py reports the counts of a tracker frame."""
+
+    def __init__(self):
+        self._real, self.calls, self.list_ops, self.names = None, 0, 0, []
+
+    def __enter__(self):
+        global _lib
+        self._real = lib()
+        _lib = self
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._real
+        return False
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not name.startswith('rpe_') or any(k in name for k in ('_bytes', '_floats', '_tiles', 'version')):        # (size queries launch nothing)
+            return fn
+
+        def counted(*a):
+            self.calls += 1
+            self.names.append(name)
+            if name == 'rpe_run_ops':
+                self.list_ops += a[1]
+            return fn(*a)
+        return counted
+
+
 _ERR = {-1: 'RPE_E_BADARG', -2: 'RPE_E_LAUNCH', -3: 'RPE_E_UNSUPPORTED'}
 
 
@@ -177,3 +261,39 @@ def stream_ptr():
 
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class RawEvents:
+    """n raw hipEvent_t handles (timing enabled) from the HIP runtime this process already uses -- what a launch list's event cells take
+    (ops.OpList; torch.cuda.Event creates its handle lazily and cannot be handed over before its first record).  Measurement plumbing
+    for bench.py and the tests: ``handles`` (ints), ``elapsed_ms(i, j)``; the events are destroyed with the object."""
+
+    def __init__(self, n):
+        self._hip = None
+        for line in open('/proc/self/maps'):
+            if 'libamdhip64' in line:
+                self._hip = ctypes.CDLL(line.split()[-1])           # the copy torch loaded (a second runtime could not share streams)
+                break
+        if self._hip is None:
+            raise RpeError('RawEvents: no HIP runtime is loaded in this process')
+        self._hip.hipEventCreate.argtypes = [_c.POINTER(_vp)]
+        self._hip.hipEventElapsedTime.argtypes = [_c.POINTER(_c.c_float), _vp, _vp]
+        self._hip.hipEventDestroy.argtypes = [_vp]
+        self.handles = []
+        for _ in range(n):
+            h = _vp()
+            if self._hip.hipEventCreate(_c.byref(h)) != 0:
+                raise RpeError('hipEventCreate failed')
+            self.handles.append(h.value)
+
+    def elapsed_ms(self, i, j):
+        ms = _c.c_float()
+        st = self._hip.hipEventElapsedTime(_c.byref(ms), self.handles[i], self.handles[j])
+        if st != 0:
+            raise RpeError(f'hipEventElapsedTime failed with {st} (events not recorded / not complete?)')
+        return ms.value
+
+    def __del__(self):
+        for h in getattr(self, 'handles', []):
+            self._hip.hipEventDestroy(h)
+        self.handles = []

@@ -10,9 +10,12 @@
 //                   f32 planes + two u8 planes, does all arithmetic in f64 (as the reference), keeps 8 (+21
 //                   with the Hessian) f64 accumulators, then 64-lane butterfly -> LDS -> one partial row
 //                   per block.  No atomics: the result is bit-reproducible run to run.
-//   k_pose_update : grid (n), 256 threads.  Fixed-order sum of the block partials, gradient clipping, one
-//                   L-BFGS (or GN) iteration in R^6, left retraction T <- exp(t d) T.  State lives in the
-//                   caller's workspace, so the whole N-iteration solve is 2N launches and zero host syncs.
+//   its tail      : the LAST workgroup of a row to finish (an atomic ticket per row decides who that is -- nothing else: the
+//                   partials are summed in a fixed order whoever runs the tail) sums the block partials, clips the gradient, runs
+//                   one L-BFGS (or GN) iteration in R^6, the left retraction T <- exp(t d) T and the stopping tests, and writes
+//                   the row's outputs once it has stopped.  State lives in the caller's workspace, so the whole N-iteration
+//                   solve is N + 1 launches (k_pose_init + N x k_pose_reduce) and zero host syncs.  (Rounds 1-5: a second
+//                   one-workgroup-per-row kernel, k_pose_update, behind every reduction, and k_pose_finalize: 2N + 2 launches.)
 #include "rpe_common.h"
 #include <cstddef>
 #include <cstdlib>
@@ -67,7 +70,7 @@ extern "C" size_t rpe_pose_workspace_bytes(int n, int h, int w) {
     size_t st = align_up(sizeof(RowState) * (size_t)n, 256) + align_up(sizeof(RowUniform) * (size_t)n, 256);
     size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(1, h, w) * n, 256);   // room for any partition_rows (n = 1 has the most blocks per
                                                                                           // row; the Hessian launch never has more)
-    return st + pa + 256;
+    return st + pa + align_up(sizeof(int) * (size_t)n, 256) + 256;                        // + one ticket counter per row
 }
 
 struct PoseArgs {
@@ -173,15 +176,25 @@ __device__ __forceinline__ void pixel_terms(double* acc, double px, double py, d
     }
 }
 
-template <bool HESS, int VEC>
-__global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseArgs A, const RowUniform* __restrict__ uni,
-                                                             const RowState* __restrict__ states,
-                                                             double* __restrict__ partials) {
+struct SolveOpts { double tol_grad, tol_change; int history; };
+// what the tail of a solve's reduction needs (rpe_pose_reduce's stand-alone launches have no tail)
+struct TailArgs {
+    int* tickets;                 // one counter per row, zero between launches
+    int mode, max_iter;
+    SolveOpts opt;
+    double* T_out; float* vec7; float* log6; int32_t* info;
+};
+template <bool TAIL>
+__device__ void reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z);
+
+template <bool HESS, int VEC, bool TAIL>
+__global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseArgs A, RowUniform* uni, RowState* states,
+                                                                             double* __restrict__ partials, TailArgs Z) {
     constexpr int NACC = HESS ? 29 : 8;
     const int row = blockIdx.y;
     const int nblk = gridDim.x;
     double* prow = partials + ((size_t)row * nblk + blockIdx.x) * NPART;
-    if (states && states[row].stop != 0) return;          // finished rows cost nothing
+    if (states && states[row].stop != 0) return;          // finished rows cost nothing (every workgroup of the row sees the same flag: no ticket is drawn)
     const int64_t hw = (int64_t)A.h * A.w;
     const RowUniform& U = uni[row];
     double R[9], t[3], K[9];
@@ -245,6 +258,18 @@ __global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseA
         if (threadIdx.x < NACC) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
         prow[threadIdx.x] = s;
     }
+    if constexpr (TAIL) {
+        // the row's last workgroup to get here runs the update: partial row visible device-wide (fence), then one ticket per workgroup
+        __shared__ int is_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) is_last = atomicAdd(&Z.tickets[row], 1) == nblk - 1;
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();                                   // (acquire side: the other workgroups' partial rows)
+        if (threadIdx.x == 0) Z.tickets[row] = 0;          // for the next evaluation's launch
+        reduce_tail<TAIL>(A, uni, states, partials, row, nblk, Z);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- update
@@ -295,15 +320,25 @@ __device__ void apply_step(RowState& S, RowUniform& U, const double* dir, double
 // blocks p, p+8, ... with four loads in flight (one lane walking the 160 rows of a 640x512 frame serially cost 24 us of
 // dependent L2 round trips per launch), then the parts are added in the order 0..7.  Ends with a barrier.
 #define UPD_THREADS 256
+// COHERENT: the partial rows were written by other workgroups of the SAME launch (the reduction's tail): device-scope loads, which no
+// cache of this CU can answer with a stale line.
+template <bool COHERENT>
+__device__ __forceinline__ double ld_partial(const double* p) {
+    if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COHERENT>
 __device__ __forceinline__ void sum_partials(const double* partials, int row, int nblk, int tid, double* vals, double (*red)[NPART]) {
     const int j = tid & 31, part = tid >> 5;
     const double* p = partials + (size_t)row * nblk * NPART + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = part;
     for (; b + 24 < nblk; b += 32) {
-        s0 += p[(size_t)b * NPART]; s1 += p[(size_t)(b + 8) * NPART]; s2 += p[(size_t)(b + 16) * NPART]; s3 += p[(size_t)(b + 24) * NPART];
+        const double v0 = ld_partial<COHERENT>(p + (size_t)b * NPART), v1 = ld_partial<COHERENT>(p + (size_t)(b + 8) * NPART);
+        const double v2 = ld_partial<COHERENT>(p + (size_t)(b + 16) * NPART), v3 = ld_partial<COHERENT>(p + (size_t)(b + 24) * NPART);
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    for (; b < nblk; b += 8) s0 += p[(size_t)b * NPART];
+    for (; b < nblk; b += 8) s0 += ld_partial<COHERENT>(p + (size_t)b * NPART);
     red[part][j] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (tid < NPART) {
@@ -314,45 +349,59 @@ __device__ __forceinline__ void sum_partials(const double* partials, int row, in
     __syncthreads();
 }
 
-struct SolveOpts { double tol_grad, tol_change; int history; };
-
 // One lane runs the iteration logic; every access it makes to the row's state used to be a dependent L2 round trip (28 us per
-// launch at batch 1).  The wave stages the state's head (poses, gradients, counters: 31 doubles), the (y, s, rho) history
-// and the row's rotation in LDS, lane 0 works there, and the wave writes back what changed.
-__device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, int* wb, const double* vals, const float* lw, int row,
+// launch at batch 1).  The workgroup stages the state's head (poses, gradients, counters: 31 doubles), the (y, s, rho) history
+// and the row's rotation in LDS, lane 0 works there, and the workgroup writes back what changed.
+__device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, double (*Lc)[6], int* wb, const double* vals, const float* lw, int row,
                                 int h, int w, int mode, int max_iter, SolveOpts opt);
 
-__global__ __launch_bounds__(UPD_THREADS) void k_pose_update(RowState* states, RowUniform* uni, const double* partials, int nblk,
-                                                             const float* lw, int h, int w, int mode, int max_iter, SolveOpts opt) {
-    const int row = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void finalize_row(const RowState& S, int row, double* T_out, float* vec7, float* log6, int32_t* info) {
+    for (int i = 0; i < 7; ++i) {
+        T_out[row * 7 + i] = S.T[i];
+        if (vec7) vec7[row * 7 + i] = (float)S.T[i];       // out.group.vec().float()
+    }
+    if (log6) {                                           // out.log().float()
+        V3<double> tau, phi;
+        se3_log(pose_load(S.T), tau, phi);
+        float* o = log6 + row * 6;
+        o[0] = (float)tau.x; o[1] = (float)tau.y; o[2] = (float)tau.z;
+        o[3] = (float)phi.x; o[4] = (float)phi.y; o[5] = (float)phi.z;
+    }
+    if (info) { info[row * 4 + 0] = S.n_iter; info[row * 4 + 1] = S.evals; info[row * 4 + 2] = S.stop; info[row * 4 + 3] = 0; }
+}
+
+template <bool TAIL>
+__device__ void reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z) {
+    const int lane = threadIdx.x;
     RowState& G = states[row];
-    if (G.stop != 0) return;
     constexpr int HEAD = 31;                                  // doubles in front of old_dirs (T, g, prev_g, d, t, loss, prev_loss, H_diag, 4 ints)
     static_assert(offsetof(RowState, old_dirs) == HEAD * sizeof(double), "RowState head");
     __shared__ double vals[NPART], red[UPD_THREADS / 32][NPART];
     __shared__ RowState S;
     __shared__ RowUniform U;
-    __shared__ double h_al[HIST];
+    __shared__ double h_al[HIST], Lc[6][6];
     __shared__ int wb[2];                                     // history entries [wb[0], wb[1]) changed
-    sum_partials(partials, row, nblk, lane, vals, red);
+    // the state's loads go out first, the partial rows' right behind them: one round trip for both
     if (lane < HEAD) ((double*)&S)[lane] = ((const double*)&G)[lane];
     if (lane < (int)(sizeof(RowUniform) / sizeof(double))) ((double*)&U)[lane] = ((const double*)&uni[row])[lane];
-    if (mode != RPE_SOLVER_GN) {
+    if (Z.mode != RPE_SOLVER_GN) {
         const int nold = G.num_old;
         for (int e = lane; e < nold * 6; e += UPD_THREADS) { (&S.old_dirs[0][0])[e] = (&G.old_dirs[0][0])[e]; (&S.old_stps[0][0])[e] = (&G.old_stps[0][0])[e]; }
         for (int e = lane; e < nold; e += UPD_THREADS) S.ro[e] = G.ro[e];
     }
     if (lane == 0) { wb[0] = 0; wb[1] = 0; }
-    __syncthreads();
-    if (lane == 0) pose_update_row(S, U, h_al, wb, vals, lw, row, h, w, mode, max_iter, opt);
+    sum_partials<true>(partials, row, nblk, lane, vals, red);             // (ends with a barrier)
+    if (lane == 0) pose_update_row(S, U, h_al, Lc, wb, vals, A.lw, row, A.h, A.w, Z.mode, Z.max_iter, Z.opt);
     __syncthreads();
     if (lane < HEAD) ((double*)&G)[lane] = ((const double*)&S)[lane];
     if (lane < 12) ((double*)&uni[row])[lane] = ((const double*)&U)[lane];          // R, t (write_rt)
     for (int e = wb[0] * 6 + lane; e < wb[1] * 6; e += UPD_THREADS) { (&G.old_dirs[0][0])[e] = (&S.old_dirs[0][0])[e]; (&G.old_stps[0][0])[e] = (&S.old_stps[0][0])[e]; }
     for (int e = wb[0] + lane; e < wb[1]; e += UPD_THREADS) G.ro[e] = S.ro[e];
+    // a row that has stopped is never touched again: its outputs are written here, once (DeclarativeFunctionLie.forward's vec7 / log6)
+    if (lane == 64 && S.stop != 0) finalize_row(S, row, Z.T_out, Z.vec7, Z.log6, Z.info);
 }
 
-__device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, int* wb, const double* vals, const float* lw, int row,
+__device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, double (*L)[6], int* wb, const double* vals, const float* lw, int row,
                                 int h, int w, int mode, int max_iter, SolveOpts opt) {
     const double hwd = (double)h * (double)w;
     const double loss2d = vals[0] / hwd / hwd, loss3d = vals[1] / hwd;
@@ -365,8 +414,7 @@ __device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, int* w
     if (mode == RPE_SOLVER_GN) {
         S.n_iter += 1; S.evals += 1; S.loss = loss;
         for (int i = 0; i < 6; ++i) S.g[i] = g[i];
-        // Cholesky H = L L^T on the 6x6 upper triangle
-        double L[6][6];
+        // Cholesky H = L L^T on the 6x6 upper triangle (L in LDS: indexed by loop variables, it would otherwise live in scratch memory)
         bool ok = true;
         for (int i = 0; i < 6; ++i) ok = ok && isfinite(g[i]);
         for (int i = 0; i < 6 && ok; ++i) {
@@ -469,9 +517,10 @@ __device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, int* w
     if (S.n_iter == max_iter) S.stop = RPE_STOP_MAX_ITER;
 }
 
-__global__ void k_pose_init(RowState* states, RowUniform* uni, const float* K, const float* lw, int n, int h, int w) {
+__global__ void k_pose_init(RowState* states, RowUniform* uni, int* tickets, const float* K, const float* lw, int n, int h, int w) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
+    tickets[row] = 0;
     RowState& S = states[row];
     for (int i = 0; i < 6; ++i) { S.T[i] = 0.0; S.g[i] = 0.0; S.prev_g[i] = 0.0; S.d[i] = 0.0; }
     S.T[6] = 1.0;
@@ -481,30 +530,20 @@ __global__ void k_pose_init(RowState* states, RowUniform* uni, const float* K, c
     write_consts(uni[row], K, lw, row, h, w);
 }
 
+// only for a solve without a single evaluation (Gauss-Newton with iters = 0): rows otherwise write their outputs in the tail that stops them
 __global__ void k_pose_finalize(RowState* states, int n, double* T_out, float* vec7, float* log6, int32_t* info) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     RowState& S = states[row];
     if (S.stop == 0) S.stop = RPE_STOP_MAX_ITER;
-    for (int i = 0; i < 7; ++i) {
-        T_out[row * 7 + i] = S.T[i];
-        if (vec7) vec7[row * 7 + i] = (float)S.T[i];       // out.group.vec().float()
-    }
-    if (log6) {                                           // out.log().float()
-        V3<double> tau, phi;
-        se3_log(pose_load(S.T), tau, phi);
-        float* o = log6 + row * 6;
-        o[0] = (float)tau.x; o[1] = (float)tau.y; o[2] = (float)tau.z;
-        o[3] = (float)phi.x; o[4] = (float)phi.y; o[5] = (float)phi.z;
-    }
-    if (info) { info[row * 4 + 0] = S.n_iter; info[row * 4 + 1] = S.evals; info[row * 4 + 2] = S.stop; info[row * 4 + 3] = 0; }
+    finalize_row(S, row, T_out, vec7, log6, info);
 }
 
 // Packs the reduced sums of one row into the rpe_pose_reduce output layout.
 __global__ __launch_bounds__(UPD_THREADS) void k_pose_pack(const double* partials, int nblk, const float* lw, int h, int w, double* out) {
     const int row = blockIdx.x, lane = threadIdx.x;
     __shared__ double vals[NPART], red[UPD_THREADS / 32][NPART];
-    sum_partials(partials, row, nblk, lane, vals, red);
+    sum_partials<false>(partials, row, nblk, lane, vals, red);
     if (lane >= 32) return;
     const double hwd = (double)h * (double)w;
     double* o = out + (size_t)row * 32;
@@ -517,23 +556,23 @@ __global__ __launch_bounds__(UPD_THREADS) void k_pose_pack(const double* partial
     else o[lane] = 0.0;
 }
 
-static void launch_reduce(const PoseArgs& A, const RowUniform* T, const RowState* st, double* partials, int nblk,
-                          bool hess, hipStream_t s) {
+template <bool TAIL>
+static void launch_reduce(const PoseArgs& A, RowUniform* T, RowState* st, double* partials, int nblk, bool hess, hipStream_t s, const TailArgs& Z) {
     dim3 grid(nblk, A.n), block(RED_THREADS);
     bool vec = ((int64_t)A.h * A.w) % 4 == 0 && A.w % 4 == 0;
     const void* ptrs[] = {A.flow, A.pcl1, A.pcl2, A.w1, A.w2};
     for (const void* p : ptrs) vec = vec && ((uintptr_t)p % 16 == 0);
     vec = vec && ((uintptr_t)A.m1 % 4 == 0) && ((uintptr_t)A.m2 % 4 == 0);
     if (hess) {
-        if (vec) hipLaunchKernelGGL((k_pose_reduce<true, 4>), grid, block, 0, s, A, T, st, partials);
-        else hipLaunchKernelGGL((k_pose_reduce<true, 1>), grid, block, 0, s, A, T, st, partials);
+        if (vec) hipLaunchKernelGGL((k_pose_reduce<true, 4, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
+        else hipLaunchKernelGGL((k_pose_reduce<true, 1, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
     } else {
-        if (vec) hipLaunchKernelGGL((k_pose_reduce<false, 4>), grid, block, 0, s, A, T, st, partials);
-        else hipLaunchKernelGGL((k_pose_reduce<false, 1>), grid, block, 0, s, A, T, st, partials);
+        if (vec) hipLaunchKernelGGL((k_pose_reduce<false, 4, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
+        else hipLaunchKernelGGL((k_pose_reduce<false, 1, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
     }
 }
 
-static bool carve(void* ws, int n, int h, int w, RowState** st, RowUniform** uni, double** partials) {
+static bool carve(void* ws, int n, int h, int w, RowState** st, RowUniform** uni, double** partials, int** tickets = nullptr) {
     if (!ws) return false;
     uintptr_t p = ((uintptr_t)ws + 255) / 256 * 256;
     *st = (RowState*)p;
@@ -541,6 +580,8 @@ static bool carve(void* ws, int n, int h, int w, RowState** st, RowUniform** uni
     *uni = (RowUniform*)p;
     p += align_up(sizeof(RowUniform) * (size_t)n, 256);
     *partials = (double*)p;
+    p += align_up(sizeof(double) * NPART * (size_t)pose_nblk(1, h, w) * n, 256);
+    if (tickets) *tickets = (int*)p;
     return true;
 }
 
@@ -556,7 +597,7 @@ extern "C" int rpe_pose_reduce(const float* flow, const float* pcl1, const float
     hipStream_t s = (hipStream_t)stream;
     int nblk = pose_nblk(n, h, w, need_hessian != 0);
     hipLaunchKernelGGL(k_pose_prep, dim3(ceil_div(n, 64)), dim3(64), 0, s, uni, T, K, loss_weight, n, h, w);
-    launch_reduce(A, uni, nullptr, partials, nblk, need_hessian != 0, s);
+    launch_reduce<false>(A, uni, nullptr, partials, nblk, need_hessian != 0, s, TailArgs{});
     hipLaunchKernelGGL(k_pose_pack, dim3(n), dim3(UPD_THREADS), 0, s, (const double*)partials, nblk, loss_weight, h, w, out);
     return rpe_check_launch();
 }
@@ -606,22 +647,22 @@ extern "C" int rpe_pose_solve_ex(const float* flow, const float* pcl1, const flo
     if (!flow || !pcl1 || !pcl2 || !w1 || !w2 || !mask1 || !mask2 || !K || !loss_weight || !T_out || n <= 0 || h <= 0 || w <= 0 || iters < 0)
         return RPE_E_BADARG;
     if (mode != RPE_SOLVER_LBFGS && mode != RPE_SOLVER_GN) return RPE_E_BADARG;
-    RowState* st; RowUniform* uni; double* partials;
-    if (!carve(workspace, n, h, w, &st, &uni, &partials)) return RPE_E_BADARG;
+    RowState* st; RowUniform* uni; double* partials; int* tickets;
+    if (!carve(workspace, n, h, w, &st, &uni, &partials, &tickets)) return RPE_E_BADARG;
     PoseArgs A{flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, n, h, w};
     hipStream_t s = (hipStream_t)stream;
     // The reduction's block partition fixes the order of the f64 sums.  By default it follows the batch (one resident round of
     // workgroups chip-wide); with partition_rows = p it is the one a p-row batch would get, so with p = 1 a row's iterates are
     // bit-identical to solving it alone (rpe_pose_workspace_bytes covers every partition: n = 1 has the most blocks per row)
     int nblk = pose_nblk(opts->partition_rows > 0 && opts->partition_rows < n ? opts->partition_rows : n, h, w, mode == RPE_SOLVER_GN);
-    hipLaunchKernelGGL(k_pose_init, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, uni, K, loss_weight, n, h, w);
+    hipLaunchKernelGGL(k_pose_init, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, uni, tickets, K, loss_weight, n, h, w);
     // LBFGS with max_iter = N costs N evaluations (the last iteration moves without re-evaluating);
     // torch evaluates the closure once even for max_iter = 0.
     int evals = mode == RPE_SOLVER_LBFGS && iters == 0 ? 1 : iters;
-    for (int it = 0; it < evals; ++it) {
-        launch_reduce(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s);
-        hipLaunchKernelGGL(k_pose_update, dim3(n), dim3(UPD_THREADS), 0, s, st, uni, (const double*)partials, nblk, loss_weight, h, w, mode, iters, opt);
-    }
-    hipLaunchKernelGGL(k_pose_finalize, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, n, T_out, vec7, log6, info);
+    // every evaluation is ONE launch: the reduction, and in its tail (the row's last workgroup) the update, the stopping tests and -- for a
+    // row that stops -- its outputs.  The last evaluation always stops a row (n_iter == max_iter at the latest).
+    const TailArgs Z{tickets, mode, iters, opt, T_out, vec7, log6, info};
+    for (int it = 0; it < evals; ++it) launch_reduce<true>(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s, Z);
+    if (evals == 0) hipLaunchKernelGGL(k_pose_finalize, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, n, T_out, vec7, log6, info);
     return rpe_check_launch();
 }

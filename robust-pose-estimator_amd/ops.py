@@ -8,6 +8,138 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 SOLVER_LBFGS, SOLVER_GN = 0, 1
+
+
+class OpList:
+    """A prepared launch list for rpe_run_ops (include/rpe.h): the launches of a host loop -- RAFT.forward's update iterations, core/RAFT/
+    core/raft.py -- enqueued by ONE call into the library instead of one Python-dispatched call each.  Built from the ``prepare=True``
+    launchers of this module (their ``.op`` = (RPE_OP_* kind, argument struct)); every op runs through the same public entry point with
+    the same arguments as the launcher would, so results are bit-identical to launching them one by one.  ``stream`` indexes the
+    stream tuple given to run().  Event cells: cell(i) is a void* slot holding a raw hipEvent_t handle (0 = the op is skipped)."""
+
+    def __init__(self, n_cells=0):
+        import ctypes
+        self._items, self._keep, self._arr = [], [], None
+        self.cells = (ctypes.c_void_p * max(1, n_cells))()
+        self._streams = (ctypes.c_void_p * 4)()
+        self._failed = ctypes.c_int(-1)
+
+    def __len__(self):
+        return len(self._items)
+
+    def add(self, launcher, stream=0):
+        kind, args = launcher.op
+        import ctypes
+        self._items.append((kind, stream, ctypes.addressof(args)))
+        self._keep.append(launcher)                       # (the launcher keeps the struct and every tensor it points to alive)
+        self._arr = None
+        return self
+
+    def _cell_op(self, kind, cell, stream):
+        import ctypes
+        self._items.append((kind, stream, ctypes.addressof(self.cells) + ctypes.sizeof(ctypes.c_void_p) * cell))
+        self._arr = None
+        return self
+
+    def record(self, cell, stream=0):
+        return self._cell_op(_lib.OP_EVENT_RECORD, cell, stream)
+
+    def wait(self, cell, stream=0):
+        return self._cell_op(_lib.OP_STREAM_WAIT, cell, stream)
+
+    def mark(self):
+        """Index of the next op: run(start, stop) takes such marks (a caller that needs the state between iterations runs slices)."""
+        return len(self._items)
+
+    def run(self, streams, start=0, stop=None):
+        """Enqueue ops [start, stop) on ``streams`` (raw hipStream_t handles as ints, index = the ops' ``stream``)."""
+        import ctypes
+        if self._arr is None:
+            self._arr = (_lib.Op * max(1, len(self._items)))(*[_lib.Op(k, s, a) for k, s, a in self._items])
+        stop = len(self._items) if stop is None else stop
+        if stop <= start:
+            return
+        for i, h in enumerate(streams):
+            self._streams[i] = h
+        st = lib().rpe_run_ops(ctypes.cast(ctypes.byref(self._arr, ctypes.sizeof(_lib.Op) * start), ctypes.POINTER(_lib.Op)), stop - start, self._streams,
+                               len(streams), ctypes.byref(self._failed))
+        if st != 0:
+            check(st, f'rpe_run_ops (op {start + self._failed.value} of the list, kind {self._items[start + self._failed.value][0]})')
+
+
+_REC = None          # the active Recorder (one host thread drives one GPU)
+
+
+class Recorder(OpList):
+    """An OpList filled by RUNNING a piece of host code once: inside ``with recorder:`` every wrapper of this module that a launch list
+    can carry (the convolutions, stems, instance-norm passes, plane copies, the correlation build, the convex up-sampling) launches as
+    usual AND logs its argument block -- so the recording pass is an ordinary pass with an ordinary result.  Every tensor a logged
+    launch touches is kept alive by the recorder: the intermediates of the pass become the list's private workspace, at fixed addresses.
+    ``bind(name, tensor)`` then marks a tensor of the pass as an external input / output: replay({name: new_tensor, ...}) rewrites every
+    pointer of the list that points into it (base + the same offset: channel / batch slices stay slices) and enqueues the whole list
+    with one rpe_run_ops call on the current stream.  The caller guarantees what the list cannot see: same shapes and dtypes, same
+    weights, replays on the stream it was recorded on (the workspace is reused without synchronisation)."""
+
+    def __init__(self):
+        super().__init__()
+        self._structs, self._bound, self._claimed = [], {}, set()
+        self.complete = False         # set when the pass has ended and every library launch of it was logged
+
+    def __enter__(self):
+        global _REC
+        if _REC is not None:
+            raise _lib.RpeError('Recorder: recordings do not nest')
+        self._count = _lib.CountingLib().__enter__()
+        _REC = self
+        return self
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        self._count.__exit__(*exc)
+        # a launch that went to the library without being logged (a wrapper this class does not know, a fallback route) would be
+        # missing from every replay: such a recording is not usable, and the caller keeps launching the pass call by call
+        self.complete = exc[0] is None and self._count.calls == len(self._items)
+        self.unlogged = [] if self.complete else sorted(set(self._count.names))
+        del self._count
+        return False
+
+    def log(self, kind, args, keep):
+        import ctypes
+        self._items.append((kind, 0, ctypes.addressof(args)))
+        self._keep.append((args, keep))
+        self._structs.append(args)
+        self._arr = None
+
+    def bind(self, name, t):
+        """Every pointer field of the logged argument blocks that points into ``t``'s memory -> (struct, field, offset)."""
+        import ctypes
+        lo, hi = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+        sites = []
+        for i, st in enumerate(self._structs):
+            for fname, ftype in st._fields_:
+                if ftype is ctypes.c_void_p and (i, fname) not in self._claimed:
+                    v = getattr(st, fname)
+                    if v is not None and lo <= v < hi:
+                        sites.append((st, fname, v - lo))
+                        self._claimed.add((i, fname))
+        self._bound[name] = (sites, tuple(t.shape), t.dtype)
+        return len(sites)
+
+    def replay(self, tensors):
+        for name, t in tensors.items():
+            sites, shape, dtype = self._bound[name]
+            if tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous():
+                raise _lib.RpeError(f'Recorder.replay: {name} must be a contiguous {dtype} tensor of shape {shape}')
+            base = t.data_ptr()
+            for st, fname, off in sites:
+                setattr(st, fname, base + off)
+        self.run((raw_stream(),))
+
+
+def raw_stream(stream=None):
+    """The raw hipStream_t handle (int) of a torch stream (default: the current stream of the current device)."""
+    return _lib.stream_ptr().value or 0 if stream is None else stream.cuda_stream
 _DT = {torch.float32: 0, torch.float64: 1}
 
 
@@ -244,17 +376,34 @@ class CorrPyramid:
             raise _lib.RpeError('corr build: shape mismatch')
         if self.buf.numel() < lib().rpe_corr_pyramid_bytes_ex(b, h8, w8, self.levels, 2 if fp16_features else 3 if bf16x3 else 0):
             raise _lib.RpeError('corr build: this pyramid was not sized for the requested feature mode (CorrPyramid(..., bf16x3=True))')
+        if _REC is not None:
+            _REC.log(_lib.OP_CORR_BUILD, _lib.CorrBuildArgs(f1.data_ptr(), f2.data_ptr(), b, c, h8, w8, self.levels, 2 if fp16_features else 3 if bf16x3 else 0,
+                                                            self.buf.data_ptr()), (f1, f2, self))
         check(lib().rpe_corr_build_ex(ptr(f1), ptr(f2), b, c, h8, w8, self.levels, 2 if fp16_features else 3 if bf16x3 else 0, ptr(self.buf),
                                       stream_ptr()), 'rpe_corr_build_ex')
         return self
 
-    def lookup(self, coords, out=None):
+    def lookup(self, coords, out=None, prepare=False):
+        """``prepare=True`` (needs ``out``): a zero-argument launcher on these buffers, with ``.op`` for an OpList."""
         co = _dev(coords, torch.float32, 'coords')
         if tuple(co.shape) != (self.b, 2, self.h8, self.w8):
             raise _lib.RpeError('corr lookup: coords shape mismatch')
         ch = self.levels * (2 * self.radius + 1) ** 2
         if out is None:
             out = torch.empty(self.b, ch, self.h8, self.w8, dtype=torch.float32, device=co.device)
+        if prepare:
+            if co is not coords or tuple(_nchw(out, 'out').shape) != (self.b, ch, self.h8, self.w8):
+                raise _lib.RpeError('corr lookup: a prepared launch needs contiguous coords and a (b, levels*(2r+1)^2, h8, w8) out buffer')
+            a = _lib.CorrLookupArgs(self.buf.data_ptr(), co.data_ptr(), self.b, self.h8, self.w8, self.levels, self.radius, out.data_ptr())
+            fn, keep = lib().rpe_corr_lookup, (self, co, out)
+
+            def launch():
+                if _REC is not None:
+                    _REC.log(_lib.OP_CORR_LOOKUP, a, keep)
+                check(fn(a.pyramid, a.coords, a.b, a.h8, a.w8, a.levels, a.radius, a.out, stream_ptr()), 'rpe_corr_lookup')
+                return keep[2]
+            launch.keep, launch.op = keep, (_lib.OP_CORR_LOOKUP, a)
+            return launch
         check(lib().rpe_corr_lookup(ptr(self.buf), ptr(co), self.b, self.h8, self.w8, self.levels, self.radius, ptr(out),
                                     stream_ptr()), 'rpe_corr_lookup')
         return out
@@ -389,13 +538,16 @@ def flow_update(x, weight, bias, coords, coords_out, flow_out=None, dst1=None, d
     fn = lib().rpe_conv3x3_to2_flow
     if prepare:
         keep = (x, weight, bias, coords, coords_out, flow_out, dst1, dst2)
+        a = _lib.FlowUpdateArgs(*[v.value if hasattr(v, 'value') else v for v in args])
 
         def launch():
+            if _REC is not None:
+                _REC.log(_lib.OP_FLOW_UPDATE, a, keep)
             st = fn(*args, stream_ptr())
             if st != 0:
                 check(st, 'rpe_conv3x3_to2_flow')
             return keep[4]
-        launch.keep = keep
+        launch.keep, launch.op = keep, (_lib.OP_FLOW_UPDATE, a)
         return launch
     check(fn(*args, stream_ptr()), 'rpe_conv3x3_to2_flow')
     return coords_out
@@ -408,6 +560,8 @@ def copy_planes(src, dst):
     b, c, hh, ww = src.shape
     if tuple(dst.shape) != (b, c, hh, ww):
         raise _lib.RpeError('copy_planes: shape mismatch')
+    if _REC is not None:
+        _REC.log(_lib.OP_COPY_PLANES, _lib.CopyPlanesArgs(sp.value, sbs, dp.value, dbs, b, c, hh * ww), (src, dst))
     check(lib().rpe_copy_planes(sp, sbs, dp, dbs, b, c, hh * ww, stream_ptr()), 'rpe_copy_planes')
     return dst
 
@@ -418,6 +572,8 @@ def upsample_convex(flow, mask):
     if tuple(mk.shape) != (b, 576, h8, w8):
         raise _lib.RpeError('upsample_convex: mask must be (b,576,h/8,w/8)')
     out = torch.empty(b, 2, 8 * h8, 8 * w8, dtype=torch.float32, device=fl.device)
+    if _REC is not None:
+        _REC.log(_lib.OP_UPSAMPLE_CONVEX, _lib.UpsampleConvexArgs(fl.data_ptr(), mk.data_ptr(), b, h8, w8, out.data_ptr()), (fl, mk, out))
     check(lib().rpe_upsample_convex(ptr(fl), ptr(mk), b, h8, w8, ptr(out), stream_ptr()), 'rpe_upsample_convex')
     return out
 
@@ -581,15 +737,19 @@ def conv_fused(x, pc, mode, out, out2=None, add=None, hidden=None, zgate=None, g
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.gate_channels = b, cin, pc.cout, hh, ww, pc.kh, pc.kw, mode, gate_channels
     d.stride = stride
     import ctypes
+    if _REC is not None and not prepare:
+        _REC.log(_lib.OP_OF_ENTRY[entry], d, (x, pc, out, out2, add, hidden, zgate, scale, bias, residual, stats, pre_norm))
     if prepare:                                    # the checked descriptor, to be launched again and again on the same buffers
         fn, ref, keep = getattr(lib(), entry), ctypes.byref(d), (d, x, pc, out, out2, add, hidden, zgate, scale, bias, residual, stats, pre_norm)
 
         def launch():
+            if _REC is not None:
+                _REC.log(_lib.OP_OF_ENTRY[entry], d, keep)
             st = fn(ref, stream_ptr())
             if st != 0:
                 check(st, entry)
             return keep[3]
-        launch.keep = keep
+        launch.keep, launch.op = keep, (_lib.OP_OF_ENTRY[entry], d)
         return launch
     check(getattr(lib(), entry)(ctypes.byref(d), stream_ptr()), entry)
     return out
@@ -740,15 +900,19 @@ def conv_wino(x, pw, mode, out, out2=None, scale=None, bias='packed', residual=N
         raise _lib.RpeError(f'conv_wino: pre_norm must be a contiguous float32 ({b},{cin},2) GPU tensor')
     d.stats, d.pre_norm = ptr(stats), ptr(pre_norm)
     d.b, d.cin, d.cout, d.h, d.w, d.kh, d.kw, d.mode, d.stride = b, cin, pw.cout, hh, ww, 3, 3, mode, 1
+    if _REC is not None and not prepare:
+        _REC.log(_lib.OP_CONV_WINO_X3 if getattr(pw, 'x3', False) else _lib.OP_CONV_WINO, d, (x, pw, out, out2, scale, bias, residual, stats, pre_norm))
     if prepare:
         fn, ref, keep = (lib().rpe_conv_wino_x3 if getattr(pw, 'x3', False) else lib().rpe_conv_wino), ctypes.byref(d), (d, x, pw, out, out2, scale, bias, residual, stats, pre_norm)
 
         def launch():
+            if _REC is not None:
+                _REC.log(_lib.OP_CONV_WINO_X3 if getattr(pw, 'x3', False) else _lib.OP_CONV_WINO, d, keep)
             st = fn(ref, stream_ptr())
             if st != 0:
                 check(st, 'rpe_conv_wino')
             return keep[3]
-        launch.keep = keep
+        launch.keep, launch.op = keep, (_lib.OP_CONV_WINO_X3 if getattr(pw, 'x3', False) else _lib.OP_CONV_WINO, d)
         return launch
     if getattr(pw, 'x3', False):
         check(lib().rpe_conv_wino_x3(ctypes.byref(d), stream_ptr()), 'rpe_conv_wino_x3')
@@ -805,6 +969,8 @@ def instnorm_finalize(stats, hw, eps=1e-5, channels=None):
         raise _lib.RpeError(f'instnorm_finalize: records hold {c} channels, expected {channels}')
     t, tiles = _stats_layout(stats, b, c, 'instnorm_finalize')
     mi = torch.empty(b, c, 2, dtype=torch.float32, device=t.device)
+    if _REC is not None:
+        _REC.log(_lib.OP_INSTNORM_FINALIZE, _lib.InstnormFinalizeArgs(t.data_ptr(), tiles, b, c, hw, float(eps), mi.data_ptr()), (t, mi))
     check(lib().rpe_instnorm_finalize(ptr(t), tiles, b, c, hw, float(eps), ptr(mi), stream_ptr()), 'rpe_instnorm_finalize')
     return mi
 
@@ -830,6 +996,10 @@ def instnorm_apply(x, stats, eps=1e-5, relu=True, residual=None, out=None, resid
         raise _lib.RpeError(f'instnorm_apply: residual_norm must be a contiguous float32 ({b},{c},2) GPU tensor next to a residual')
     out = x if out is None else _nchw(out, 'out')
     flags = int(bool(relu)) | (0 if residual_relu or residual_norm is None else 2)
+    if _REC is not None:
+        dp = lambda v: v.data_ptr() if v is not None else None
+        _REC.log(_lib.OP_INSTNORM_APPLY, _lib.InstnormApplyArgs(x.data_ptr(), t.data_ptr(), tiles, b, c, hh * ww, float(eps), flags, dp(residual),
+                                                                dp(residual_norm), out.data_ptr()), (x, t, residual, residual_norm, out))
     check(lib().rpe_instnorm_apply_ex(ptr(x), ptr(t), tiles, b, c, hh * ww, float(eps), flags, ptr(residual), ptr(residual_norm),
                                       ptr(out), stream_ptr()), 'rpe_instnorm_apply_ex')
     return out
@@ -848,9 +1018,9 @@ class PackedStem:
         check(lib().rpe_stem_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_stem_pack')
 
 
-def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.0, mul=2.0, sub=1.0, out=None):
+def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.0, mul=2.0, sub=1.0, out=None, prepare=False):
     """conv7x7(mul * (image / div) - sub) * scale + bias [ReLU]; stride and channel counts come from ``ps``.
-    Returns out, or (out, stats)."""
+    Returns out, or (out, stats).  ``prepare=True`` (needs ``out``; stats = a caller-owned buffer or False): a launcher with ``.op``."""
     _nchw(image, 'image')
     b, c, hh, ww = image.shape
     if c != ps.cin:
@@ -867,6 +1037,23 @@ def stem_conv(image, ps, bias=None, scale=None, relu=True, stats=False, div=255.
         stats = True
     else:
         st = torch.empty(b, ps.cout, lib().rpe_stem_tiles(hh, ww, st_), 3, dtype=torch.float32, device=image.device) if stats else None
+    if prepare or _REC is not None:
+        dp = lambda t: t.data_ptr() if t is not None else None
+        a = _lib.StemConvArgs(dp(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), dp(ps.packed), ps.cout, dp(bias), dp(scale), int(bool(relu)),
+                              dp(out), dp(st))
+        fn, keep = lib().rpe_stem_conv, (image, ps, bias, scale, out, st)
+        if not prepare:
+            _REC.log(_lib.OP_STEM_CONV, a, keep)
+
+    if prepare:
+        def launch():
+            if _REC is not None:
+                _REC.log(_lib.OP_STEM_CONV, a, keep)
+            check(fn(a.image, a.b, a.cin, a.h, a.w, a.stride, a.div, a.mul, a.sub, a.packed, a.cout, a.bias, a.scale, a.relu, a.out, a.stats, stream_ptr()),
+                  'rpe_stem_conv')
+            return keep[4]
+        launch.keep, launch.op = keep, (_lib.OP_STEM_CONV, a)
+        return launch
     check(lib().rpe_stem_conv(ptr(image), b, c, hh, ww, st_, float(div), float(mul), float(sub), ptr(ps.packed), ps.cout, ptr(bias), ptr(scale),
                               int(bool(relu)), ptr(out), ptr(st), stream_ptr()), 'rpe_stem_conv')
     return (out, st) if stats else out

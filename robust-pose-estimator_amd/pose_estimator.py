@@ -6,6 +6,7 @@ Follows core/pose/pose_estimator.py:26-48 (checkpoint + config overrides, 1/dept
 ``last_pose <- last_pose * rel^-1``) and :98-125 (get_pose_f2f), and core/utils/frame_class.py:5-50 (Frame).
 Frame-to-model tracking (``frame2frame: False``, SurfelMap) is out of scope.
 """
+import time
 import warnings
 from collections import OrderedDict
 
@@ -159,6 +160,7 @@ class PoseEstimator(torch.nn.Module):
         rel, pose, ok = ops.pose_gate_chain(rel_pose.data.reshape(1, 7), self.last_pose.data, self._inv_scale, 1.0e-1)
         if self._pending:
             self._start_encoders(self._pending[0])            # (submit / result) the next frame's encoders, before the host waits for this one
+        self.t_enqueued = time.perf_counter()             # everything of this frame has been handed to the runtime; what follows waits for the GPU
         self.success = bool(ok[0])
         if not self.success:
             warnings.warn('pose estimation not converged, skip.', RuntimeWarning)                 # :82

@@ -48,6 +48,21 @@ X3_GRU = False           # under CONV_BF16X3, also the SepConvGRU's 1x5 / 5x1 la
 # batch 1-2 (sequential tracking) 9.22 -> 9.08 ms per frame pair, 110.2 -> 111.9 frames/s; batch 32: 72.49 vs 72.41 ms per step (every
 # launch fills the chip on its own), so it is used for small passes only.
 SIDE_STREAM = True
+# The update loop as ONE call into the library (ops.OpList -> rpe_run_ops): the 12 iterations' ~130-180 launches and stream fork / joins are
+# enqueued by a C loop over prepared argument blocks instead of one Python-dispatched ctypes call each (bit-identical: the same entry
+# points with the same arguments).  False = launch by launch from Python (bench.py's per-convolution diagnostic pass, A/B runs).
+LOOP_OPLIST = True
+# bench.py's hook for timing the lookup INSIDE the timed region: a callable iters -> 2 * iters raw hipEvent_t handles (ints), recorded in
+# front of and behind each iteration's lookup by the launch list itself; None = the list's timing cells stay empty (no-ops)
+LOOKUP_EVENT_SINK = None
+# Sequential tracking encodes 1-3 images and runs one or two flow pairs per frame: ~75 launches around the update loop whose Python dispatch
+# (argument checks, descriptor construction, output allocation) costs more host time than the loop's list.  For such small passes an
+# encoder pass and the two ends of RAFT.forward are RECORDED once (ops.Recorder: an ordinary pass that also logs its launches and keeps its
+# intermediates as a private workspace) and replayed as launch lists with the input / output pointers rewritten.  Bit-identical (the same
+# entry points with the same arguments); keyed on shapes, stream and the weights' versions.  Larger passes (batch mode) keep the
+# call-by-call route: their host time is hidden behind 60 ms of kernels and their intermediates would pin gigabytes.
+FRAME_OPLISTS = True
+FRAME_OPLISTS_MAX_IMAGES = 4                                      # images per encoder pass / flow pairs per RAFT pass up to which passes are recorded
 ENC_STREAMS = True                                                 # RAFT.encode_both: the context encoder on the side stream beside the feature encoder
 ENC_STREAMS_MIN = 8                                                # ... for at least this many context images (below: the fork / join costs more than it hides)
 SIDE_STREAM_MAX = 8 * 5120                                     # queries per pass (batch * h/8 * w/8) up to which the side stream is used
@@ -222,6 +237,42 @@ def conv_norm_act(conv, norm, x, relu, residual=None):
     raise NotImplementedError(type(norm))
 
 
+def _tensor_key(tensors):
+    """Versions and addresses of a fixed list of parameter / buffer tensors (in-place updates bump the version, .to() / .float() move the data)."""
+    return tuple(t._version for t in tensors) + tuple(t.data_ptr() for t in tensors)
+
+
+def _overlap(tensors):
+    spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in tensors)
+    return any(a[1] > b[0] for a, b in zip(spans, spans[1:]))
+
+
+class _Recorded:
+    """A small cache of recorded passes (ops.Recorder) keyed by the caller; a key whose recording came out incomplete three times (a launch
+    the recorder cannot carry: a fallback route, a weight packing made on first use) is given up on and stays on the call-by-call route."""
+
+    def __init__(self, keep=4):
+        self._progs, self._failed, self._keep = {}, {}, keep
+
+    def get(self, key):
+        return self._progs.get(key)
+
+    def wanted(self, key):
+        return self._failed.get(key, 0) < 3
+
+    def put(self, key, rec):
+        if rec.complete:
+            _bounded_put(self._progs, key, rec, keep=self._keep)
+        else:
+            if len(self._failed) > 64:
+                self._failed.clear()
+            self._failed[key] = self._failed.get(key, 0) + 1
+
+    def clear(self):
+        self._progs.clear()
+        self._failed.clear()
+
+
 class BasicEncoder(nn.Module):
     def __init__(self, output_dim=128, norm_fn='batch', dropout=0.0):
         super().__init__()
@@ -309,9 +360,46 @@ class BasicEncoder(nn.Module):
             ops.bias_act(y[:, half:].contiguous(), None, relu=True, out=y, out_offset=half)
         return y
 
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.__dict__.pop('_key_tensors', None)                # .to() / .float(): the recorded passes point at the old storage
+        if getattr(self, '_recorded', None) is not None:
+            self._recorded.clear()
+        return r
+
     def forward(self, x, raw255=False, split_act=False):
         """``raw255``: x is the raw 0..255 image (RAFT.forward's normalisation is then done inside the first kernel), or a list of
-        such image batches, encoded as one batch.  ``split_act``: see _final."""
+        such image batches, encoded as one batch.  ``split_act``: see _final.
+        Small inference passes (FRAME_OPLISTS) are recorded once per (shapes, stream, weights) and replayed as one launch list."""
+        images = list(x) if isinstance(x, (list, tuple)) else [x]
+        first = images[0]
+        if FRAME_OPLISTS and raw255 and first.is_cuda and not torch.is_grad_enabled() and sum(im.shape[0] for im in images) <= FRAME_OPLISTS_MAX_IMAGES \
+                and all(im.is_contiguous() and im.dtype == torch.float32 and im.device == first.device for im in images) and not _overlap(images):
+            if getattr(self, '_recorded', None) is None:
+                self._recorded = _Recorded()
+            if '_key_tensors' not in self.__dict__:
+                self.__dict__['_key_tensors'] = [t for t in list(self.parameters()) + list(self.buffers()) if t is not None]
+            key = (tuple(tuple(im.shape) for im in images), first.device.index, ops.raw_stream(), split_act, WINOGRAD, CONV_BF16X3,
+                   _tensor_key(self.__dict__['_key_tensors']))
+            rec = self._recorded.get(key)
+            if rec is not None:
+                out = torch.empty(rec.out_shape, device=first.device)
+                rec.replay({**{i: im for i, im in enumerate(images)}, 'out': out})
+                return out
+            if self._recorded.wanted(key):
+                rec = ops.Recorder()
+                with rec:
+                    out = self._forward(x, raw255, split_act)
+                if rec.complete and out.is_contiguous():
+                    for i, im in enumerate(images):
+                        rec.complete = rec.complete and rec.bind(i, im) > 0
+                    rec.complete = rec.complete and rec.bind('out', out) > 0
+                    rec.out_shape = tuple(out.shape)
+                self._recorded.put(key, rec)
+                return out
+        return self._forward(x, raw255, split_act)
+
+    def _forward(self, x, raw255=False, split_act=False):
         many = isinstance(x, (list, tuple))
         first = x[0] if many else x
         hh, ww = first.shape[-2:]
@@ -384,6 +472,17 @@ class BasicMotionEncoder(nn.Module):
                      c3('conv', cat_buf, hx[:, 128:254], rhx[:, 128:254]))
             _bounded_put(cache, key, calls, keep=4)
         return calls
+
+    def flow_branch_launchers(self, flow, corr, cat_buf, hx, rhx, packed):
+        """(convf1, convf2) as prepared launchers on these buffers (``flow`` must be the persistent flow buffer of the workspace)."""
+        _, cor, flo_buf, c1, c2, f2, cv_ = self._calls(corr, cat_buf, hx, rhx, packed)
+        key = (flow.data_ptr(), flo_buf.data_ptr())
+        cache = packed.setdefault('_f1_calls', {})
+        f1 = cache.get(key)
+        if f1 is None:
+            f1 = ops.stem_conv(flow, packed['convf1'], bias=self.convf1.bias.detach(), relu=True, div=1.0, mul=1.0, sub=0.0, out=flo_buf, prepare=True)
+            _bounded_put(cache, key, f1, keep=4)
+        return f1, f2
 
     def flow_branch(self, flow, corr, cat_buf, hx, rhx, packed):
         """convf1 -> convf2 (fused route): depends on the flow only, not on the correlation lookup, so RAFT.forward may run it on a
@@ -505,6 +604,36 @@ class BasicUpdateBlock(nn.Module):
             self._packed = (key, P)
         return self._packed[1]
 
+    def gru_launchers(self, hx, rhx, z_buf, ctx, flow, coords1, in_place, P):
+        """Prepared launchers of the GRU, FlowHead.conv1 and (``in_place``) the flow head's output layer with the coords / flow bookkeeping,
+        on these buffers (descriptors checked once; every iteration of every pass on the same workspace reuses them)."""
+        c = self.hidden_dim
+        fh = self.flow_head
+        # each GRU half = two implicit-GEMM convolutions whose epilogues are the gates:
+        #   z = s(convz hx + ctx), r*h -> rhx ;  h <- (1-z) h + z tanh(convq rhx + ctx)   (in place on hx[:, :c])
+        key = (hx.data_ptr(), rhx.data_ptr(), z_buf.data_ptr(), tuple(ctx[k].data_ptr() for k in ('zr1', 'q1', 'zr2', 'q2')), tuple(hx.shape),
+               (coords1.data_ptr(), flow.data_ptr()) if in_place else None)
+        cache = P.setdefault('_gru_calls', {})
+        calls = cache.get(key)
+        if calls is None:
+            seq = []
+            gconv = ops.conv_wino1d if isinstance(P['zr1'], (ops.PackedWino1d, ops.PackedWino1dX3)) else ops.conv_fused
+            for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
+                seq.append(gconv(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
+                                 prepare=True))
+                seq.append(gconv(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
+            if 'fh1' in P['wino'] and hx.shape[-1] % 2 == 0 and hx.shape[-2] % 2 == 0:
+                pfh = P['wino_x3']['fh1'] if 'fh1' in P.get('wino_x3', {}) and hx.shape[-1] % 4 == 0 else P['wino']['fh1']
+                seq.append(ops.conv_wino(hx[:, :c], pfh, ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+            else:
+                seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
+            if in_place:
+                seq.append(ops.flow_update(P['fh_buf'](hx), fh.conv2.weight, fh.conv2.bias.detach(), coords1, coords1, flow_out=flow,
+                                           dst1=hx[:, 2 * c - 2:], dst2=rhx[:, 2 * c - 2:], prepare=True))
+            calls = (key, seq)
+            _bounded_put(cache, key, calls, keep=4)
+        return calls[1]
+
     def step(self, hx, rhx, z_buf, cat_buf, h_buf, ctx, corr, flow, coords1, in_place=False, flow_branch_done=None):
         """One update.  hx = (h | motion | flow), rhx = (r*h | motion | flow), both (b,256,h,w); ctx = context_terms().
         Returns coords1 + delta_flow; the new hidden state is left in hx[:, :128] (h_buf is written by the generic
@@ -518,29 +647,7 @@ class BasicUpdateBlock(nn.Module):
         self.encoder(flow, corr, cat_buf, hx, rhx, packed=P, flow_in_place=in_place, flow_branch_done=flow_branch_done)
         fh = self.flow_head
         if P is not None:
-            # each GRU half = two implicit-GEMM convolutions whose epilogues are the gates:
-            #   z = s(convz hx + ctx), r*h -> rhx ;  h <- (1-z) h + z tanh(convq rhx + ctx)   (in place on hx[:, :c])
-            key = (hx.data_ptr(), rhx.data_ptr(), z_buf.data_ptr(), tuple(ctx[k].data_ptr() for k in ('zr1', 'q1', 'zr2', 'q2')), tuple(hx.shape),
-                   (coords1.data_ptr(), flow.data_ptr()) if in_place else None)
-            cache = P.setdefault('_gru_calls', {})
-            calls = cache.get(key)
-            if calls is None:
-                seq = []
-                gconv = ops.conv_wino1d if isinstance(P['zr1'], (ops.PackedWino1d, ops.PackedWino1dX3)) else ops.conv_fused
-                for zr, q in (('zr1', 'q1'), ('zr2', 'q2')):
-                    seq.append(gconv(hx, P[zr], ops.CONV_GATE_ZR, z_buf, out2=rhx[:, :c], add=ctx[zr], hidden=hx[:, :c], gate_channels=c,
-                                     prepare=True))
-                    seq.append(gconv(rhx, P[q], ops.CONV_GATE_H, hx[:, :c], add=ctx[q], hidden=hx[:, :c], zgate=z_buf, prepare=True))
-                if 'fh1' in P['wino'] and hx.shape[-1] % 2 == 0 and hx.shape[-2] % 2 == 0:
-                    pfh = P['wino_x3']['fh1'] if 'fh1' in P.get('wino_x3', {}) and hx.shape[-1] % 4 == 0 else P['wino']['fh1']
-                    seq.append(ops.conv_wino(hx[:, :c], pfh, ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
-                else:
-                    seq.append(ops.conv_fused(hx[:, :c], P['fh1'], ops.CONV_RELU, P['fh_buf'](hx), prepare=True))
-                if in_place:
-                    seq.append(ops.flow_update(P['fh_buf'](hx), fh.conv2.weight, fh.conv2.bias.detach(), coords1, coords1, flow_out=flow,
-                                               dst1=hx[:, 2 * c - 2:], dst2=rhx[:, 2 * c - 2:], prepare=True))
-                calls = (key, seq)
-                _bounded_put(cache, key, calls, keep=4)
+            calls = (None, self.gru_launchers(hx, rhx, z_buf, ctx, flow, coords1, in_place, P))
             if in_place:
                 for launch in calls[1]:
                     launch()
@@ -653,6 +760,47 @@ class RAFT(nn.Module):
                                  zero2=torch.zeros(n, 2, h8, w8, device=device))
         return self._ws[key]
 
+    def _loop_program(self, pyr, ws, iters, side):
+        """The update loop on workspace ``ws`` as a launch list (ops.OpList): per iteration [fork: convf1 -> convf2 on the side stream]
+        lookup, convc1, convc2, [join | convf1, convf2], conv, the four GRU convolutions, FlowHead.conv1 and the flow update -- built once
+        per (weights, pyramid, workspace, iters, streams) and replayed by one rpe_run_ops call per pass.  Cells 0 / 1: the fork / join
+        events; cells 2 + 2k, 3 + 2k: timing events around iteration k's lookup (LOOKUP_EVENT_SINK; empty = skipped).
+        Returns (list, marks) with marks[k] = first op of iteration k, marks[iters] = the end."""
+        ub = self.update_block
+        hx, rhx, z_buf, cat_buf, corr, coords1, flow = (ws[k] for k in ('hx', 'rhx', 'z', 'cat', 'corr', 'coords1', 'flow'))
+        P = ub.packed_convs(hx.shape[-1])
+        key = (id(P), pyr.buf.data_ptr(), iters, None if side is None else side[0].cuda_stream)
+        cached = ws.get('_program')
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
+        _, _, _, c1, c2, _, cv_ = ub.encoder._calls(corr, cat_buf, hx, rhx, P)
+        f1, f2 = ub.encoder.flow_branch_launchers(flow, corr, cat_buf, hx, rhx, P)
+        seq = ub.gru_launchers(hx, rhx, z_buf, ws['ctx'], flow, coords1, True, P)
+        lk = pyr.lookup(coords1, out=corr, prepare=True)
+        prog = ops.OpList(n_cells=2 + 2 * iters)
+        if side is not None:
+            for cell, ev in ((0, side[1]), (1, side[2])):
+                ev.record()                                       # (torch creates the hipEvent_t at the first record)
+                prog.cells[cell] = ev.cuda_event
+        marks = []
+        for itr in range(iters):
+            marks.append(prog.mark())
+            if side is not None:                                  # the flow branch needs only the flow: beside lookup -> convc1 -> convc2
+                prog.record(0, 0).wait(0, 1).add(f1, 1).add(f2, 1).record(1, 1)
+            prog.record(2 + 2 * itr, 0).add(lk).record(3 + 2 * itr, 0).add(c1).add(c2)
+            if side is not None:
+                prog.wait(1, 0)
+            else:
+                prog.add(f1).add(f2)
+            prog.add(cv_)
+            for launch in seq:
+                prog.add(launch)
+        marks.append(prog.mark())
+        prog.keep = (P, pyr, side)
+        prog.armed = False
+        ws['_program'] = (key, prog, marks)
+        return prog, marks
+
     @torch.no_grad()
     def encode_features(self, images):
         """fnet on raw 0..255 images (normalised like forward does); one batch or a list of batches encoded as one."""
@@ -688,6 +836,90 @@ class RAFT(nn.Module):
         cn.record_stream(cur)                                 # allocated on the side stream, consumed (and freed) on the caller's
         return f, cn
 
+    def _begin(self, pyr, ws, fmap1, fmap2, cnet, fused):
+        """Everything of a pass in front of the update loop: the correlation pyramid, h <- tanh half of the context encoder's output, the
+        GRU's four loop-invariant context terms, and (fused route) coords1 <- grid, flow <- 0 in the workspace's persistent buffers,
+        which the flow head's output layer then updates in place."""
+        c = self.hidden_dim
+        pyr.build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision, bf16x3=(CORR_BF16X3 or CONV_BF16X3) and not self.mixed_precision)
+        hx, rhx = ws['hx'], ws['rhx']
+        ops.copy_planes(cnet[:, :c], hx[:, :c])
+        ctx = self.update_block.context_terms(cnet[:, c:], out=ws['ctx'] if fused else None)      # (fused: written into the persistent buffers)
+        if fused:
+            ops.copy_planes(ws['coords0'], ws['coords1'])
+            ops.copy_planes(ws['zero2'], ws['flow'])
+            ops.copy_planes(ws['zero2'], hx[:, 2 * c - 2:])
+            ops.copy_planes(ws['zero2'], rhx[:, 2 * c - 2:])
+        return ctx
+
+    def _finish(self, ws, upsample):
+        """Behind the loop of the fused route: the returned prediction (mask head + convex x8 up-sampling, or a copy of the 1/8 flow) and
+        the returned hidden state, both fresh tensors."""
+        c = self.hidden_dim
+        hx, flow = ws['hx'], ws['flow']
+        pred = ops.upsample_convex(flow, self.update_block.up_mask(hx[:, :c])) if upsample else ops.copy_planes(flow, torch.empty_like(flow))
+        h_buf = ops.copy_planes(hx[:, :c], torch.empty(hx.shape[0], c, hx.shape[2], hx.shape[3], device=hx.device))
+        return pred, h_buf
+
+    def _run_loop(self, pyr, ws, iters, side):
+        prog, marks = self._loop_program(pyr, ws, iters, side)
+        if LOOKUP_EVENT_SINK is not None:
+            for i, h in enumerate(LOOKUP_EVENT_SINK(iters)):
+                prog.cells[2 + i] = h
+            prog.armed = True
+        elif prog.armed:
+            for i in range(2 * iters):
+                prog.cells[2 + i] = None
+            prog.armed = False
+        streams = (ops.raw_stream(),) if side is None else (ops.raw_stream(), side[0].cuda_stream)
+        return prog, marks, streams
+
+    def _forward_recorded(self, fmap1, fmap2, cnet, iters, upsample):
+        """forward() for a small pass on given encoder outputs (sequential tracking: one or two flow pairs per frame) as THREE calls into
+        the library: the recorded front (_begin), the loop's launch list, the recorded tail (_finish).  None = this pass cannot be
+        recorded (the caller goes on call by call)."""
+        N, _, h8, w8 = fmap1.shape
+        dev = fmap1.device
+        c = self.hidden_dim
+        ts = (fmap1, fmap2, cnet)
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) or _overlap(ts) or tuple(cnet.shape) != (N, 2 * c, h8, w8):
+            return None
+        if getattr(self, '_recorded', None) is None:
+            self._recorded = _Recorded()
+        if '_key_tensors' not in self.__dict__:
+            self.__dict__['_key_tensors'] = [t for t in self.update_block.parameters()]
+        pyr = self._pyramid(N, h8, w8, dev)
+        ws = self._workspace(N, h8, w8, dev)
+        key = (N, h8, w8, dev.index, ops.raw_stream(), iters, upsample, self.mixed_precision, WINOGRAD, CORR_BF16X3, CONV_BF16X3, X3_GRU, SIDE_STREAM,
+               pyr.buf.data_ptr(), ws['hx'].data_ptr(), _tensor_key(self.__dict__['_key_tensors']))
+        side = self._side_stream(dev) if SIDE_STREAM and N * h8 * w8 <= SIDE_STREAM_MAX else None
+        entry = self._recorded.get(key)
+        if entry is not None:
+            pre, post = entry.pre, entry
+            pre.replay({'f1': fmap1, 'f2': fmap2, 'cnet': cnet})
+            prog, _, streams = self._run_loop(pyr, ws, iters, side)
+            prog.run(streams)
+            pred, h_buf = torch.empty(post.pred_shape, device=dev), torch.empty(N, c, h8, w8, device=dev)
+            post.replay({'pred': pred, 'h': h_buf})
+            return [pred], h_buf, cnet[:, c:]
+        if not self._recorded.wanted(key):
+            return None
+        prog, _, streams = self._run_loop(pyr, ws, iters, side)      # (built outside the recordings: its launchers must hold the real entry points)
+        pre = ops.Recorder()
+        with pre:
+            self._begin(pyr, ws, fmap1, fmap2, cnet, True)
+        prog.run(streams)
+        post = ops.Recorder()
+        with post:
+            pred, h_buf = self._finish(ws, upsample)
+        if pre.complete and post.complete:
+            ok = pre.bind('f1', fmap1) > 0 and pre.bind('f2', fmap2) > 0 and pre.bind('cnet', cnet) > 0 and post.bind('pred', pred) > 0 and post.bind('h', h_buf) > 0
+            pre.complete = post.complete = ok
+        post.complete = post.complete and pre.complete
+        post.pre, post.pred_shape = pre, tuple(pred.shape)
+        self._recorded.put(key, post)
+        return [pred], h_buf, cnet[:, c:]
+
     @torch.no_grad()
     def forward(self, image1, image2, upsample=True, iters=None, all_flows=False, fmaps=None, cnet=None):
         """image1, image2: (N,3,H,W) in 0..255.  Inference only (the reference freezes RAFT, train.yaml:51).
@@ -706,27 +938,39 @@ class RAFT(nn.Module):
             fmap1, fmap2 = f[:N], f[N:]
         else:
             fmap1, fmap2 = fmaps                              # precomputed by encode_features (caller de-duplicates)
-        pyr = self._pyramid(N, h8, w8, dev).build(fmap1.float(), fmap2.float(), fp16_features=self.mixed_precision, bf16x3=(CORR_BF16X3 or CONV_BF16X3) and not self.mixed_precision)
         if cnet is None:
             cnet = self.encode_context(image1)                # (tanh(net) | relu(inp))
         c = self.hidden_dim
+        fused = self.update_block.packed_convs(w8) is not None
+        if fused and FRAME_OPLISTS and LOOP_OPLIST and not all_flows and N <= FRAME_OPLISTS_MAX_IMAGES and LOOKUP_EVENT_SINK is None:
+            r = self._forward_recorded(fmap1, fmap2, cnet, iters, upsample)
+            if r is not None:
+                return r
+        pyr = self._pyramid(N, h8, w8, dev)
         ws = self._workspace(N, h8, w8, dev)
+        ctx = self._begin(pyr, ws, fmap1, fmap2, cnet, fused)
         hx, rhx, z_buf, cat_buf, corr = ws['hx'], ws['rhx'], ws['z'], ws['cat'], ws['corr']   # hx = (h | motion | flow)
         h_buf = torch.empty(N, c, h8, w8, device=dev)         # returned to the caller: fresh
-        ops.copy_planes(cnet[:, :c], hx[:, :c])
         inp = cnet[:, c:]
-        ctx = self.update_block.context_terms(inp, out=ws['ctx'])
         coords0 = ws['coords0']
         flow_predictions = []
-        fused = self.update_block.packed_convs(w8) is not None
         if fused:
-            # coords1 and flow = coords1 - coords0 live in persistent buffers which the flow head's output layer updates in place
-            coords1, flow = ops.copy_planes(coords0, ws['coords1']), ops.copy_planes(ws['zero2'], ws['flow'])
-            ops.copy_planes(ws['zero2'], hx[:, 2 * c - 2:])
-            ops.copy_planes(ws['zero2'], rhx[:, 2 * c - 2:])
+            coords1, flow = ws['coords1'], ws['flow']
         else:
             coords1 = coords0.clone()
         side = self._side_stream(dev) if fused and SIDE_STREAM and N * h8 * w8 <= SIDE_STREAM_MAX else None
+        if fused and LOOP_OPLIST:
+            prog, marks, streams = self._run_loop(pyr, ws, iters, side)
+            if not all_flows:
+                prog.run(streams)
+            for itr in range(iters if all_flows else 0):
+                prog.run(streams, marks[itr], marks[itr + 1])
+                if itr < iters - 1:
+                    flow_predictions.append(ops.upsample_convex(flow, self.update_block.up_mask(hx[:, :c])) if upsample
+                                            else ops.copy_planes(flow, torch.empty_like(flow)))
+            flow_predictions.append(ops.upsample_convex(flow, self.update_block.up_mask(hx[:, :c])) if upsample
+                                    else ops.copy_planes(flow, torch.empty_like(flow)))
+            iters = 0                                             # (the launch-by-launch loop below is the other route)
         for itr in range(iters):
             done = None
             if side is not None:

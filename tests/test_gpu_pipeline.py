@@ -370,6 +370,135 @@ def test_infer_parity_sweep(models):
     assert flips <= 50
 
 
+@pytest.mark.parametrize('batch,side', [(1, True), (2, False), (3, True)])
+def test_update_loop_as_one_launch_list_equals_launch_by_launch(models, monkeypatch, batch, side):
+    """raft.LOOP_OPLIST: the 12 update iterations (and the side stream's fork / joins) enqueued by ONE rpe_run_ops call over prepared
+    argument blocks.  Same entry points, same arguments as the launch-by-launch route: every returned tensor must be bit-identical, for
+    the final prediction, for all twelve (all_flows runs the list in per-iteration slices), without up-sampling, with and without the
+    side stream, and on a second pass (the list is built once per workspace and replayed)."""
+    model, om, synth = models
+    from rpe_amd import raft
+    fr = synth.stereo_frames(11, batch, H, W)
+    i1, i2 = fr['image1l'].cuda(), fr['image2l'].cuda()
+    monkeypatch.setattr(raft, 'SIDE_STREAM', side)
+    monkeypatch.setattr(raft, 'LOOP_OPLIST', False)
+    ref_all, ref_h, ref_c = model.flow(i1, i2, all_flows=True)
+    ref_low, _, _ = model.flow(i1, i2, upsample=False)
+    monkeypatch.setattr(raft, 'LOOP_OPLIST', True)
+    for _ in range(2):
+        last, hid, ctx = model.flow(i1, i2)
+        assert len(last) == 1 and torch.equal(last[0], ref_all[-1]) and torch.equal(hid, ref_h) and torch.equal(ctx, ref_c)
+    every, hid, _ = model.flow(i1, i2, all_flows=True)
+    assert len(every) == 12 and all(torch.equal(a, b) for a, b in zip(every, ref_all)) and torch.equal(hid, ref_h)
+    low, _, _ = model.flow(i1, i2, upsample=False)
+    assert torch.equal(low[-1], ref_low[-1])
+
+
+def test_recorded_passes_equal_call_by_call(models, monkeypatch):
+    """raft.FRAME_OPLISTS: small encoder passes and the two ends of RAFT.forward are recorded once (ops.Recorder) and replayed as launch
+    lists with the input / output pointers rewritten.  Replays on OTHER inputs than the recorded ones must equal the call-by-call route bit
+    for bit (a stale pointer would reproduce the recorded frame), outputs must be fresh tensors, and a recording must really exist."""
+    model, om, synth = models
+    from rpe_amd import raft
+    flow = model.flow
+    fr = synth.stereo_frames(21, 4, H, W)
+    L, R = fr['image2l'].cuda(), fr['image2r'].cuda()
+
+    def run(i, j):
+        f = flow.encode_features((L[i:i + 1], R[i:i + 1]))
+        cn = flow.encode_context(L[i:i + 1])
+        f2 = flow.encode_features((L[j:j + 1], R[j:j + 1]))
+        c2 = flow.encode_context(L[j:j + 1])
+        fm1, cnn = torch.cat((f[:1], f2[:1])), torch.cat((cn, c2))
+        preds, hid, inp = flow(None, None, fmaps=(fm1, f2), cnet=cnn)
+        low, _, _ = flow(None, None, upsample=False, fmaps=(fm1, f2), cnet=cnn)
+        return f, cn, preds[-1], hid, inp, low[-1]
+    pairs = [(0, 1), (1, 2), (2, 3), (3, 0), (0, 1)]
+    monkeypatch.setattr(raft, 'FRAME_OPLISTS', False)
+    ref = [run(i, j) for i, j in pairs]
+    monkeypatch.setattr(raft, 'FRAME_OPLISTS', True)
+    for m in (flow.fnet, flow.cnet, flow):
+        if getattr(m, '_recorded', None) is not None:
+            m._recorded.clear()
+    got = [run(i, j) for i, j in pairs]
+    for a, b in zip(got, ref):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert got[0][2].data_ptr() != got[1][2].data_ptr() or got[1][2].data_ptr() != got[2][2].data_ptr()      # fresh outputs, not one buffer
+    assert torch.equal(got[0][0], ref[0][0]) and torch.equal(got[0][2], ref[0][2])                             # ... still intact after later replays
+    for m in (flow.fnet, flow.cnet, flow):
+        assert len(m._recorded._progs) >= 1, type(m).__name__
+    assert not any(torch.equal(ref[0][2], r[2]) for r in ref[1:4])                                             # the inputs really differ
+
+
+def test_tracker_poses_do_not_depend_on_the_launch_route(models, monkeypatch):
+    """PoseEstimator over 7 frames: recorded passes + launch lists vs every launch dispatched from Python -- the same poses, bit for bit."""
+    model, om, synth = models
+    from rpe_amd import pose_estimator, raft
+    import warnings
+    fr = synth.stereo_frames(31, 7, H, W)
+    L, R, M = fr['image2l'].cuda(), fr['image2r'].cuda(), fr['mask2'].cuda()
+    slam = dict(frame2frame=True, depth_clipping=[1, 250], lbgfs_iters=8, conf_weighing=True)
+
+    def walk():
+        est = pose_estimator.PoseEstimator(slam, fr['K'][0], 7.2 * 250.0, model, (W, H)).cuda()
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for t in range(7):
+                out.append(est(L[t:t + 1], R[t:t + 1], M[t:t + 1].clone())[0].data.clone())
+        return torch.cat(out)
+    monkeypatch.setattr(raft, 'FRAME_OPLISTS', False)
+    monkeypatch.setattr(raft, 'LOOP_OPLIST', False)
+    ref = walk()
+    monkeypatch.setattr(raft, 'FRAME_OPLISTS', True)
+    monkeypatch.setattr(raft, 'LOOP_OPLIST', True)
+    assert torch.equal(walk(), ref) and torch.equal(walk(), ref)
+
+
+def test_launch_list_times_its_lookups_when_asked(models, monkeypatch):
+    """raft.LOOKUP_EVENT_SINK (bench.py's roofline of the lookup inside the timed region): the launch list records the caller's raw HIP
+    events around every iteration's lookup; without a sink the cells are empty and the same list runs untimed.  Results are unchanged."""
+    model, om, synth = models
+    from rpe_amd import raft, _lib
+    fr = synth.stereo_frames(12, 1, H, W)
+    i1, i2 = fr['image1l'].cuda(), fr['image2l'].cuda()
+    ref, _, _ = model.flow(i1, i2)
+    ev = _lib.RawEvents(24)
+    asked = []
+
+    def sink(iters):
+        asked.append(iters)
+        return ev.handles[:2 * iters]
+    monkeypatch.setattr(raft, 'LOOKUP_EVENT_SINK', sink)
+    out, _, _ = model.flow(i1, i2)
+    torch.cuda.synchronize()
+    ms = [ev.elapsed_ms(2 * k, 2 * k + 1) for k in range(12)]
+    assert asked == [12] and torch.equal(out[0], ref[0]) and all(0.0 < t < 5.0 for t in ms), ms
+    monkeypatch.setattr(raft, 'LOOKUP_EVENT_SINK', None)
+    out, _, _ = model.flow(i1, i2)
+    assert torch.equal(out[0], ref[0])
+
+
+def test_run_ops_reports_the_failing_op(rpe):
+    """rpe_run_ops stops at the first op whose entry point refuses its arguments and says which one (no partial silent success)."""
+    import ctypes
+    from rpe_amd import ops, _lib
+    x = torch.zeros(1, 4, 8, 8, device='cuda')
+    good = _lib.CopyPlanesArgs(x.data_ptr(), 256, x.data_ptr(), 256, 1, 4, 64)
+    bad = _lib.CopyPlanesArgs(None, 256, x.data_ptr(), 256, 1, 4, 64)
+    arr = (_lib.Op * 3)(_lib.Op(_lib.OP_COPY_PLANES, 0, ctypes.addressof(good)), _lib.Op(_lib.OP_COPY_PLANES, 0, ctypes.addressof(bad)),
+                        _lib.Op(_lib.OP_COPY_PLANES, 0, ctypes.addressof(good)))
+    streams = (ctypes.c_void_p * 1)(ops.raw_stream())
+    failed = ctypes.c_int(-7)
+    assert _lib.lib().rpe_run_ops(arr, 3, streams, 1, ctypes.byref(failed)) == -1 and failed.value == 1
+    assert _lib.lib().rpe_run_ops(arr, 1, streams, 1, ctypes.byref(failed)) == 0 and failed.value == -1
+    arr[0].kind = 999
+    assert _lib.lib().rpe_run_ops(arr, 1, streams, 1, None) == -1
+    arr[0].kind, arr[0].stream = _lib.OP_COPY_PLANES, 1
+    assert _lib.lib().rpe_run_ops(arr, 1, streams, 1, None) == -1
+    torch.cuda.synchronize()
+
+
 def test_whole_infer_is_graph_capturable(models):
     """PoseNet.infer enqueues ~200 kernels (incl. the side stream of small passes) and never synchronises with the host: the whole
     call can be captured into one HIP graph; its replay gives the eager result bit for bit."""
