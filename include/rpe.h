@@ -49,8 +49,13 @@ const char *rpe_version(void);
 /* Layout version of this header's structs (rpe_conv_desc, rpe_solve_opts) and signatures: a binding compares it with the
  * RPE_ABI_VERSION it was written against before the first call (the ctypes binding does, robust-pose-estimator_amd/_lib.py).
  * 5: rpe_conv_desc is 200 bytes (stats_tiles), stride-2 statistics are one record per 32 output pixels, rpe_pose_solve_ex, rpe_pose_gate_chain.
- * Entry points added since (rpe_conv_wino_x3*) change no struct and no existing signature: the version stays 5. */
+ * Entry points are only ever ADDED under one RPE_ABI_VERSION (they change no struct and no existing signature); RPE_ABI_MINOR counts those
+ * additions, so a binding can require "version 5, minor >= m" for the newest entry point it calls -- or probe with dlsym:
+ *   minor 0: the 68 entry points of round 4;  1: rpe_conv_wino_x3*, rpe_conv1x1_x3*, rpe_conv_wino1d_x3* (9, round 5);  2: rpe_run_ops and
+ *   the rpe_*_args structs of the prepared launch lists, rpe_corr_lookup_conv1x1* (round 6). */
 #define RPE_ABI_VERSION 5
+#define RPE_ABI_MINOR 2
+int rpe_abi_minor(void);
 int rpe_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -130,8 +135,10 @@ typedef struct rpe_solve_opts {
     double tolerance_grad;       /* 1e-7 */
     double tolerance_change;     /* 1e-9 */
     int partition_rows;          /* 0 = n */
-    int reserved;                /* 0 */
+    int reserved;                /* flags; 0 = defaults.  RPE_SOLVE_LAUNCH_PER_EVALUATION (bit 0): one launch per evaluation even where the whole
+                                  * solve would run as one persistent launch (identical results; for A/B measurements) */
 } rpe_solve_opts;
+#define RPE_SOLVE_LAUNCH_PER_EVALUATION 1
 int rpe_pose_solve_ex(const float *flow, const float *pcl1, const float *pcl2, const float *w1, const float *w2,
                       const uint8_t *mask1, const uint8_t *mask2, const float *K, const float *loss_weight,
                       int n, int h, int w, int mode, int iters, const rpe_solve_opts *opts, double *T_out, float *vec7,
@@ -218,6 +225,20 @@ int rpe_corr_build_ex(const float *fmap1, const float *fmap2, int b, int c, int 
  * window).  radius must be 4, levels <= 4. */
 int rpe_corr_lookup(const void *pyramid, const float *coords, int b, int h8, int w8, int levels, int radius,
                     float *out, void *stream);
+/* The lookup FUSED into the convolution that consumes it: out (b, 256, h8, w8) = act(convc1(lookup(coords))) without the 324-channel
+ * tensor ever reaching memory -- BasicMotionEncoder.forward's first layer (upstream core/RAFT/core/update.py: cor = F.relu(self.convc1(corr)),
+ * 1x1, 324 -> 256; the reference's call site is core/pose/pose_net.py:65).  A workgroup looks the four levels of 64 queries up into LDS
+ * and contracts them on the f32 matrix cores; the products are added in rpe_conv1x1's order, so the result is BIT-IDENTICAL to
+ * rpe_corr_lookup followed by rpe_conv1x1 (or rpe_conv_fused) with the same weights.  packed = rpe_corr_lookup_conv1x1_pack of the
+ * (256, 324, 1, 1) weight (rpe_corr_lookup_conv1x1_packed_floats floats; 0 for any other shape); bias (256) or NULL; relu != 0: ReLU;
+ * out / out2 (may be NULL): channel slices given by their batch strides (floats).  levels must be 4, radius 4, w8 % 8 == 0; anything else
+ * -> RPE_E_UNSUPPORTED (the caller runs the two entry points).  rpe_corr_lookup stays the stand-alone entry point (and the kernel the
+ * HBM roofline of bench.py is stated on). */
+size_t rpe_corr_lookup_conv1x1_packed_floats(int cout, int cin);
+int rpe_corr_lookup_conv1x1_pack(const float *weight, int cout, int cin, float *packed, void *stream);
+int rpe_corr_lookup_conv1x1(const void *pyramid, const float *coords, int b, int h8, int w8, int levels, int radius, const float *packed,
+                            const float *bias, int relu, float *out, long long out_batch_stride, float *out2, long long out2_batch_stride,
+                            void *stream);
 /* Integer taps of the lookup for index-parity tests: x0,y0 (b,levels,2r+1,h8*w8) int32 = floor of the
  * un-normalised grid_sample position of window tap i on each axis (x0[..,i,q] pairs with x offset i-r,
  * y0[..,j,q] with y offset j-r) -- the very indices rpe_corr_lookup reads.  -1000000 marks a non-finite tap. */
@@ -384,8 +405,13 @@ int rpe_conv1x1(const rpe_conv_desc *desc, void *stream);
 /* LABELLED VARIANT of rpe_conv1x1 (never in a headline number; bench.py --conv-bf16x3): the same GEMM with every f32 product as six bf16
  * products of a three-way split on the 16-bit matrix cores, f32 accumulation (csrc/conv1x1_x3.hip; BasicMotionEncoder.convc1,
  * core/RAFT/core/update.py; call sites core/pose/pose_net.py:47,65,129).  Same descriptor; supported: bias, out, out2, mode LINEAR / RELU;
- * h * w % 4 == 0, 16-byte aligned input slice; anything else -> RPE_E_UNSUPPORTED (use rpe_conv1x1).  desc->packed must come from
- * rpe_conv1x1_x3_pack (rpe_conv1x1_x3_packed_bytes bytes; 16-byte aligned). */
+ * h * w % 4 == 0, 16-byte aligned input and output slices; anything else -> RPE_E_UNSUPPORTED (use rpe_conv1x1).  desc->packed must come from
+ * rpe_conv1x1_x3_pack (rpe_conv1x1_x3_packed_bytes bytes; 16-byte aligned).
+ * SPECIAL VALUES (all three bf16x3 entry points; the f32 kernels do not share this): the split x = hi + mid + lo turns an infinite input into
+ * hi = +-Inf, mid = Inf - Inf = NaN, so +-Inf in an activation or weight gives NaN in every output it reaches, where the f32 kernels give
+ * +-Inf (or NaN only for Inf - Inf / 0 * Inf).  NaN inputs give NaN in both.  rpe_conv1x1_x3 with cin % 16 != 0 additionally reads channel
+ * cin - 1 a second time against zero weights in its padded last K step: a NaN there is harmless (it is NaN anyway), an Inf falls under the
+ * rule above.  Finite inputs, including denormals and values up to FLT_MAX / 4, are unaffected (tests/test_gpu_conv_x3.py). */
 size_t rpe_conv1x1_x3_packed_bytes(int cout, int cin);
 int rpe_conv1x1_x3_pack(const float *weight, int cout, int cin, void *packed, void *stream);
 int rpe_conv1x1_x3(const rpe_conv_desc *desc, void *stream);
@@ -455,6 +481,7 @@ int rpe_instnorm_finalize(const float *partials, int tiles, int b, int c, int hw
 #define RPE_OP_INSTNORM_APPLY 13   /*       const rpe_instnorm_apply_args * -> rpe_instnorm_apply_ex */
 #define RPE_OP_UPSAMPLE_CONVEX 14  /*       const rpe_upsample_convex_args *               */
 #define RPE_OP_CORR_BUILD 15       /*       const rpe_corr_build_args * -> rpe_corr_build_ex */
+#define RPE_OP_LOOKUP_CONV1X1 16    /*       const rpe_lookup_conv1x1_args * -> rpe_corr_lookup_conv1x1 */
 #define RPE_OP_EVENT_RECORD 32     /*       void *const * (address of a hipEvent_t handle; NULL handle = no-op) */
 #define RPE_OP_STREAM_WAIT 33      /*       void *const * (the same)                       */
 typedef struct rpe_op {
@@ -463,6 +490,10 @@ typedef struct rpe_op {
     const void *args;
 } rpe_op;
 typedef struct rpe_corr_lookup_args { const void *pyramid; const float *coords; int b, h8, w8, levels, radius; float *out; } rpe_corr_lookup_args;
+typedef struct rpe_lookup_conv1x1_args {
+    const void *pyramid; const float *coords; int b, h8, w8, levels, radius; const float *packed, *bias; int relu; float *out;
+    long long out_batch_stride; float *out2; long long out2_batch_stride;
+} rpe_lookup_conv1x1_args;
 typedef struct rpe_corr_build_args { const float *fmap1, *fmap2; int b, c, h8, w8, levels, feature_dtype; void *pyramid; } rpe_corr_build_args;
 typedef struct rpe_stem_conv_args {
     const float *image; int b, cin, h, w, stride; float div, mul, sub; const float *packed; int cout; const float *bias, *scale; int relu;

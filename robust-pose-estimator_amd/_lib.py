@@ -43,6 +43,11 @@ class CorrLookupArgs(_c.Structure):
     _fields_ = [('pyramid', _vp), ('coords', _vp), ('b', _i), ('h8', _i), ('w8', _i), ('levels', _i), ('radius', _i), ('out', _vp)]
 
 
+class LookupConv1x1Args(_c.Structure):
+    _fields_ = [('pyramid', _vp), ('coords', _vp), ('b', _i), ('h8', _i), ('w8', _i), ('levels', _i), ('radius', _i), ('packed', _vp), ('bias', _vp),
+                ('relu', _i), ('out', _vp), ('out_batch_stride', _ll), ('out2', _vp), ('out2_batch_stride', _ll)]
+
+
 class CorrBuildArgs(_c.Structure):
     _fields_ = [('fmap1', _vp), ('fmap2', _vp), ('b', _i), ('c', _i), ('h8', _i), ('w8', _i), ('levels', _i), ('feature_dtype', _i), ('pyramid', _vp)]
 
@@ -77,10 +82,12 @@ class UpsampleConvexArgs(_c.Structure):
 # RPE_OP_* of include/rpe.h
 OP_CONV_FUSED, OP_CONV_WINO, OP_CONV_WINO1D, OP_CONV1X1, OP_CONV_WINO_X3, OP_CONV_WINO1D_X3, OP_CONV1X1_X3 = 1, 2, 3, 4, 5, 6, 7
 OP_CORR_LOOKUP, OP_STEM_CONV, OP_FLOW_UPDATE, OP_COPY_PLANES, OP_INSTNORM_FINALIZE, OP_INSTNORM_APPLY, OP_UPSAMPLE_CONVEX, OP_CORR_BUILD = 8, 9, 10, 11, 12, 13, 14, 15
+OP_LOOKUP_CONV1X1 = 16
 OP_EVENT_RECORD, OP_STREAM_WAIT = 32, 33
 OP_OF_ENTRY = {'rpe_conv_fused': OP_CONV_FUSED, 'rpe_conv_wino': OP_CONV_WINO, 'rpe_conv_wino1d': OP_CONV_WINO1D, 'rpe_conv1x1': OP_CONV1X1,
                'rpe_conv_wino_x3': OP_CONV_WINO_X3, 'rpe_conv_wino1d_x3': OP_CONV_WINO1D_X3, 'rpe_conv1x1_x3': OP_CONV1X1_X3}
 
+ABI_MINOR = 2              # RPE_ABI_MINOR: the newest additions this binding calls (rpe_run_ops)
 ABI_VERSION = 5            # RPE_ABI_VERSION of include/rpe.h these struct mirrors were written against
 
 
@@ -93,6 +100,7 @@ class SolveOpts(_c.Structure):
 SIGNATURES = {
     'rpe_version': (_c.c_char_p, []),
     'rpe_abi_version': (_i, []),
+    'rpe_abi_minor': (_i, []),
     'rpe_se3_exp': (_i, [_vp, _vp, _i64, _i, _vp]),
     'rpe_se3_log': (_i, [_vp, _vp, _i64, _i, _vp]),
     'rpe_se3_mul': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
@@ -116,6 +124,9 @@ SIGNATURES = {
     'rpe_corr_build': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_build_ex': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rpe_corr_lookup': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rpe_corr_lookup_conv1x1_packed_floats': (_sz, [_i, _i]),
+    'rpe_corr_lookup_conv1x1_pack': (_i, [_vp, _i, _i, _vp, _vp]),
+    'rpe_corr_lookup_conv1x1': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _ll, _vp, _ll, _vp]),
     'rpe_corr_lookup_taps': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_corr_lookup_rounds': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rpe_corr_export_level': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -203,6 +214,8 @@ def lib():
             fn.argtypes = args
         if L.rpe_abi_version() != ABI_VERSION:
             raise RpeError(f'{LIB_PATH} has ABI version {L.rpe_abi_version()}, this binding expects {ABI_VERSION} (struct layouts of include/rpe.h): rebuild')
+        if L.rpe_abi_minor() < ABI_MINOR:
+            raise RpeError(f'{LIB_PATH} has ABI minor {L.rpe_abi_minor()}, this binding calls entry points added in minor {ABI_MINOR}: rebuild')
         _lib = L
     return _lib
 

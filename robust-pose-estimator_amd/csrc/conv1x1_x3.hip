@@ -311,7 +311,10 @@ extern "C" int rpe_conv1x1_x3(const rpe_conv_desc* d, void* stream) {
     if (d->add || d->hidden || d->zgate || d->scale || d->residual || d->stats || d->pre_norm) return RPE_E_UNSUPPORTED;
     const long long hw = (long long)d->h * d->w;
     if ((hw & 3) || hw < 4 || (((uintptr_t)d->x) & 15) || (d->x_batch_stride & 3) || (((uintptr_t)d->packed) & 15)) return RPE_E_UNSUPPORTED;
-    if (hw * 4 * 4 >= (1ll << 31)) return RPE_E_UNSUPPORTED;                         // (32-bit byte offsets inside a group of four channel planes)
+    // the epilogue stores 16-byte pieces: destination slices aligned like the input
+    if ((((uintptr_t)d->out) & 15) || (d->out_batch_stride & 3) || (d->out2 && ((((uintptr_t)d->out2) & 15) || (d->out2_batch_stride & 3)))) return RPE_E_UNSUPPORTED;
+    // 32-bit byte offsets: inside a group of four channel planes, or -- a ragged last step (cin % 16 != 0) addresses up to 16 planes from one base -- sixteen
+    if (hw * 4 * ((d->cin & (G3K - 1)) ? 16 : 4) >= (1ll << 31)) return RPE_E_UNSUPPORTED;
     G1X3P P;
     P.x = d->x; P.xbs = d->x_batch_stride; P.wp = (const unsigned short*)d->packed; P.cin = d->cin; P.cout = d->cout; P.coP = g3_cop(d->cout);
     P.hw = (int)hw; P.bias = d->bias; P.out = d->out; P.obs = d->out_batch_stride; P.out2 = d->out2; P.o2bs = d->out2_batch_stride; P.mode = d->mode;

@@ -700,6 +700,7 @@ struct LkCtx {
     unsigned gmask[8];                           // bits 0-11: box rows to fetch, bits 16-31: slots to fetch
     int ld_x, ld_half, ld_hi, yoff;
     bool store_ok, any_dev, nt_store;
+    bool to_tile;                                // the destination is an LDS tile (fused lookup + convc1): plain stores
 };
 
 // Consumer of one staged pass: box rows LK_RPP*pass .. +LK_RPP-1.  DEV = false: no tap of any lane of the wave deviates
@@ -729,7 +730,7 @@ __device__ __forceinline__ void consume_pass(const LkCtx& C, const TapAxis& X, c
                 for (int i = 0; i < WIN; ++i) {
                     const float val = DEV ? hm2[i] * w0 + hm1[i] * w1 + hc[i] * w2 : hm2[i] * w0 + hm1[i] * w1;
                     float* dst = (float*)(C.outb + (size_t)(oj + (unsigned)(i * WIN) * C.nq4));
-                    if ((LK_NT & 2) || ((LK_NT & 4) && C.nt_store)) __builtin_nontemporal_store(val, dst); else *dst = val;
+                    if (!C.to_tile && ((LK_NT & 2) || ((LK_NT & 4) && C.nt_store))) __builtin_nontemporal_store(val, dst); else *dst = val;
                 }
             }
         }
@@ -779,6 +780,30 @@ __device__ __forceinline__ void lookup_pass(const LkCtx& C, const TapAxis& X, co
     }
 }
 
+// The same with the loads of ALL passes of the round issued up front (3 x 12 x 16 bytes per lane in flight: one memory round trip per round
+// instead of three).  For the fused lookup + convc1 kernel, whose four waves per CU have nothing else to hide the latency behind and 512
+// registers each to hold the data.  (Measured: no gain -- 330 vs 325 us at batch 32 --: the kernel is bound by its matrix phase; kept, it is
+// never slower.)
+template <int PASS>
+__device__ __forceinline__ void stage_and_consume(const LkCtx& C, const TapAxis& X, const TapAxis& Y, float (&hm2)[WIN], float (&hm1)[WIN],
+                                                  f32x4 (&v)[LK_NPASS][LK_NI]) {
+#pragma unroll
+    for (int i = 0; i < LK_NI; ++i) {
+        const int g = (2 * i) / LK_RPP, row = (2 * i) % LK_RPP;
+        *(f32x4*)(C.wstage + g * LK_GSTRIDE + (row + C.ld_hi) * (LK_BOXW * GQ) + C.ld_x * GQ + C.ld_half * 4) = v[PASS][i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (C.any_dev) consume_pass<true, PASS>(C, X, Y, hm2, hm1);
+    else consume_pass<false, PASS>(C, X, Y, hm2, hm1);
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (PASS + 1 < LK_NPASS) stage_and_consume<PASS + 1>(C, X, Y, hm2, hm1, v);
+}
+template <int PASS>
+__device__ __forceinline__ void issue_all(const LkCtx& C, f32x4 (&v)[LK_NPASS][LK_NI]) {
+    issue_loads<PASS>(C, v[PASS]);
+    if constexpr (PASS + 1 < LK_NPASS) issue_all<PASS + 1>(C, v);
+}
+
 // The round rule (shared by k_corr_lookup and the k_corr_rounds diagnostic): per group the staging box is anchored at the topmost
 // pending window row and, among the lanes within one row of it, the leftmost window column; a lane is served in this round when
 // its 11 x 11 window fits the 12 x 16 box.
@@ -797,21 +822,14 @@ __device__ __forceinline__ LkRound plan_round(bool pending, int ylo, int sx, int
     return R;
 }
 
-// One workgroup = 4 independent waves; a wave = 8 consecutive groups (64 queries) of one (batch item, level).
-__global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
-                                                                      float* __restrict__ out, PyrGeom G) {
-    __shared__ __attribute__((aligned(16))) float stage[LK_WAVES * LK_WAVE_FLOATS];
-    int bx = blockIdx.x, l = blockIdx.y, bz = blockIdx.z;
-    if (LK_XCD) {   // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous range of the grid
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z, L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned c = L & 7, sidx = L >> 3, q8 = total >> 3, r8 = total & 7;
-        const unsigned nl = c * q8 + (c < r8 ? c : r8) + sidx;
-        bx = nl % gridDim.x; l = (nl / gridDim.x) % gridDim.y; bz = nl / (gridDim.x * gridDim.y);
-    }
+// The lookup of ONE wave: 8 consecutive groups (64 queries, first group wave_g0) of one (batch item bz, level l), staged through the
+// wave's own LDS stage.  The 81 values of a lane's query go to outb + obase + (i * 9 + j) * nq4 (bytes): channel planes of the (b, 324,
+// h8, w8) output for k_corr_lookup, or rows of a workgroup's LDS tile for the fused lookup + convc1 kernel (a generic pointer serves both).
+template <bool DEEP>
+__device__ __forceinline__ void lookup_wave(const float* __restrict__ pyr, const float* __restrict__ coords, char* outb, unsigned nq4, int tile_q,
+                                            float* wstage, const PyrGeom& G, int wave_g0, int l, int bz) {
     const int nq = G.h8 * G.w8;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wave_g0 = (bx * LK_WAVES + wv) * 8;                     // first group of this wave
-    if (wave_g0 >= G.ngroups) return;                                 // (whole wave; there is no workgroup barrier below)
+    const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, k = lane & 7;
     const int Gi = wave_g0 + grp;
     const int qy = Gi / G.gx, qx = (Gi % G.gx) * GQ + k;
@@ -838,11 +856,12 @@ __global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const fl
     const int sx = X.lo + sk - (k >> l);                              // window start in skewed columns
 
     LkCtx C;
-    C.row_bytes = (unsigned)wp * GQ * 4; C.nq4 = (unsigned)nq * 4;
+    C.row_bytes = (unsigned)wp * GQ * 4; C.nq4 = nq4;
     C.lvl = (const char*)(pyr + G.base[l]) + (size_t)bz * G.ngroups * hl * C.row_bytes;       // (a level of one batch item is < 4 GB)
-    C.outb = (char*)(out + (size_t)bz * G.levels * WIN * WIN * nq);
-    C.obase = ((unsigned)l * WIN * WIN * nq + q) * 4;
-    C.wstage = stage + wv * LK_WAVE_FLOATS;
+    C.outb = outb;
+    C.obase = ((unsigned)l * WIN * WIN * (nq4 / 4) + (unsigned)(tile_q >= 0 ? tile_q : q)) * 4;
+    C.wstage = wstage;
+    C.to_tile = tile_q >= 0;
     // loader role: lane -> (16-B piece: x' slot ld_x of the staged row, half ld_half; row selector ld_hi)
     C.ld_x = (lane >> 1) & 15; C.ld_half = lane & 1; C.ld_hi = lane >> 5;
     const unsigned my_rows = (unsigned)Gi * hl;                       // first pyramid row of this lane's group
@@ -879,13 +898,146 @@ __global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const fl
         float hm2[WIN], hm1[WIN];
 #pragma unroll
         for (int i = 0; i < WIN; ++i) { hm2[i] = 0.0f; hm1[i] = 0.0f; }
-        f32x4 v0[LK_NI];
-        issue_loads<0>(C, v0);
-        lookup_pass<0>(C, X, Y, hm2, hm1, v0);
+        if constexpr (DEEP) {
+            f32x4 v[LK_NPASS][LK_NI];
+            issue_all<0>(C, v);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_and_consume<0>(C, X, Y, hm2, hm1, v);
+        } else {
+            f32x4 v0[LK_NI];
+            issue_loads<0>(C, v0);
+            lookup_pass<0>(C, X, Y, hm2, hm1, v0);
+        }
         pending = pending && !fits;
         first = false;
         if (!__any(pending)) break;
     }
+}
+
+// One workgroup = LK_WAVES independent waves; a wave = 8 consecutive groups (64 queries) of one (batch item, level).
+__global__ __launch_bounds__(64 * LK_WAVES, LK_MINW) void k_corr_lookup(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                                      float* __restrict__ out, PyrGeom G) {
+    __shared__ __attribute__((aligned(16))) float stage[LK_WAVES * LK_WAVE_FLOATS];
+    int bx = blockIdx.x, l = blockIdx.y, bz = blockIdx.z;
+    if (LK_XCD) {   // consecutive workgroup ids go round-robin over the 8 XCDs: give each XCD a contiguous range of the grid
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z, L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned c = L & 7, sidx = L >> 3, q8 = total >> 3, r8 = total & 7;
+        const unsigned nl = c * q8 + (c < r8 ? c : r8) + sidx;
+        bx = nl % gridDim.x; l = (nl / gridDim.x) % gridDim.y; bz = nl / (gridDim.x * gridDim.y);
+    }
+    const int nq = G.h8 * G.w8;
+    const int wv = threadIdx.x >> 6;
+    const int wave_g0 = (bx * LK_WAVES + wv) * 8;                     // first group of this wave
+    if (wave_g0 >= G.ngroups) return;                                 // (whole wave; there is no workgroup barrier below)
+    lookup_wave<false>(pyr, coords, (char*)(out + (size_t)bz * G.levels * WIN * WIN * nq), (unsigned)nq * 4, -1, stage + wv * LK_WAVE_FLOATS, G, wave_g0, l, bz);
+}
+
+// ------------------------------------------------------------------------------------------------ lookup fused into convc1
+// BasicMotionEncoder.forward starts with cor = relu(convc1(corr)) (upstream core/RAFT/core/update.py, restated in oracle/raft.py; the
+// reference's call site is core/pose/pose_net.py:65): the 324-channel lookup result exists only to be contracted to 256 channels by a 1x1
+// convolution.  k_lookup_conv1x1 never writes it: a workgroup = 4 waves looks up the four levels of 64 queries (wave = level; the loader /
+// consumer of k_corr_lookup, lookup_wave) into an LDS tile [336 channels][64 queries] (84 KB; rows 324..335 are zeros: the K padding of
+// the last 16-channel step), and after one barrier the same four waves run the GEMM out[256][64] = W[256][324] tile on the f32 matrix
+// cores: wave = 64 output channels x 64 queries (2 x 2 blocks of v_mfma_f32_32x32x2_f32), B fragments from the tile, A fragments straight
+// from global memory (the 332 KB of packed weights live in L2; each lane's 16 values of a step are one contiguous 64-byte piece,
+// fetched one step ahead).  The products are added in k_conv1x1's order (per 16-channel step, matrix instruction j adds channels j and
+// 8 + j): the result is BIT-IDENTICAL to rpe_corr_lookup followed by rpe_conv1x1 / rpe_conv_fused (tests/test_gpu_corr.py).
+// Measured (MI355X, 640x512; tools/bench_lookup_conv.py): 2 pairs (a tracker frame) 35.3 us against 16.1 + 30.9 = 45 us back to back;
+// 32 pairs (the bench step) 325-330 us against 308-312: with 150 KB of LDS one workgroup owns a CU, so its lookup phase (memory) and its
+// matrix phase never overlap, which two kernels at 3+ workgroups per CU do -- the host side uses it for small passes only (raft.py).
+// Tried on top, both measured: all three passes' loads of a round in flight at once (lookup_wave<DEEP>: 330 vs 325, kept); the 21 steps
+// written out with the next step's fragments requested ahead of the matrix instructions (361 us: the compiler hoists 48 weight loads in
+// front of the lookup; dropped).
+#define FZ_COUT 256
+#define FZ_CIN (MAX_LEVELS * WIN * WIN)                            // 324
+#define FZ_STEPS ((FZ_CIN + 15) / 16)                              // 21
+#define FZ_TILE_FLOATS (FZ_STEPS * 16 * 64)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct FzP {
+    const float* pyr; const float* coords; const float* wp; const float* bias;
+    float* out; long long obs; float* out2; long long o2bs;
+    int relu;
+};
+
+template <bool OUT2>
+__global__ __launch_bounds__(256, 1) void k_lookup_conv1x1(FzP P, PyrGeom G) {
+    __shared__ __attribute__((aligned(16))) float tile[FZ_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float stage[4 * LK_WAVE_FLOATS];
+    __shared__ float bias_s[FZ_COUT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bz = blockIdx.y;
+    const int wave_g0 = blockIdx.x * 8;                                 // the workgroup's 8 groups = 64 consecutive queries (w8 % 8 == 0)
+    const int nq = G.h8 * G.w8;
+    for (int i = tid; i < (FZ_STEPS * 16 - FZ_CIN) * 64; i += 256) tile[FZ_CIN * 64 + i] = 0.0f;
+    bias_s[tid] = P.bias ? P.bias[tid] : 0.0f;
+    // A fragments of step 0 are requested before the lookup: they arrive during it
+    const f32x4* wsrc = (const f32x4*)P.wp + ((size_t)wv * FZ_STEPS * 64 + lane) * 4;
+    f32x4 a_cur[4], a_nxt[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_cur[c] = wsrc[c];
+    lookup_wave<true>(P.pyr, P.coords, (char*)tile, 64u * 4u, lane, stage + wv * LK_WAVE_FLOATS, G, wave_g0, wv, bz);
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* b_l = tile + (8 * lh) * 64 + l31;
+#pragma unroll 1
+    for (int s = 0; s < FZ_STEPS; ++s) {
+        if (s + 1 < FZ_STEPS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a_nxt[c] = wsrc[(size_t)(s + 1) * 256 + c];
+        }
+        const float* b = b_l + s * (16 * 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a0 = a_cur[j >> 1][(j & 1) * 2], a1 = a_cur[j >> 1][(j & 1) * 2 + 1];
+            const float b0 = b[j * 64], b1 = b[j * 64 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
+    }
+    // ---- epilogue (k_conv1x1's): C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* ob = P.out + (size_t)bz * P.obs;
+    float* ob2 = OUT2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+    const int co_w = wv * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wave_g0 * GQ + j * 32 + l31;
+        const bool qok = q < nq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_w + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bias_s[co];
+                if (P.relu) v = v < 0.0f ? 0.0f : v;                            // NaN stays NaN, like torch.relu
+                if (qok) {
+                    ob[(size_t)co * nq + q] = v;
+                    if (OUT2) ob2[(size_t)co * nq + q] = v;
+                }
+            }
+    }
+}
+
+// weight (256, 324, 1, 1) -> [wave = co / 64][step = ci / 16][lane][16]: value 2 j + i of lane (l31, lh) = W[64 wave + 32 i + l31][16 step + j + 8 lh]
+// (zero beyond ci = 323): a lane's fragments of a step are one 64-byte piece
+__global__ void k_lookup_conv_pack(const float* __restrict__ w, float* __restrict__ wp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 4 * FZ_STEPS * 64 * 16) return;
+    const int v = e & 15, lane = (e >> 4) & 63, step = (e >> 10) % FZ_STEPS, wave = (e >> 10) / FZ_STEPS;
+    const int j = v >> 1, i = v & 1, l31 = lane & 31, lh = lane >> 5;
+    const int co = 64 * wave + 32 * i + l31, ci = 16 * step + j + 8 * lh;
+    wp[e] = ci < FZ_CIN ? w[(size_t)co * FZ_CIN + ci] : 0.0f;
 }
 
 __global__ void k_corr_taps(const float* __restrict__ coords, int32_t* x0, int32_t* y0, PyrGeom G) {
@@ -1022,6 +1174,31 @@ extern "C" int rpe_corr_lookup(const void* pyramid, const float* coords, int b, 
     if (!pyramid || !coords || !out || radius != RADIUS || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
     hipLaunchKernelGGL(k_corr_lookup, dim3(ceil_div(G.ngroups, 8 * LK_WAVES), levels, b), dim3(64 * LK_WAVES), 0, (hipStream_t)stream,
                        (const float*)pyramid, coords, out, G);
+    return rpe_check_launch();
+}
+
+extern "C" size_t rpe_corr_lookup_conv1x1_packed_floats(int cout, int cin) {
+    return (cout == FZ_COUT && cin == FZ_CIN) ? (size_t)4 * FZ_STEPS * 64 * 16 : 0;
+}
+
+extern "C" int rpe_corr_lookup_conv1x1_pack(const float* weight, int cout, int cin, float* packed, void* stream) {
+    if (!weight || !packed) return RPE_E_BADARG;
+    if (cout != FZ_COUT || cin != FZ_CIN) return RPE_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_lookup_conv_pack, dim3(ceil_div(4 * FZ_STEPS * 64 * 16, 256)), dim3(256), 0, (hipStream_t)stream, weight, packed);
+    return rpe_check_launch();
+}
+
+extern "C" int rpe_corr_lookup_conv1x1(const void* pyramid, const float* coords, int b, int h8, int w8, int levels, int radius, const float* packed,
+                                       const float* bias, int relu, float* out, long long out_batch_stride, float* out2, long long out2_batch_stride,
+                                       void* stream) {
+    PyrGeom G;
+    if (!pyramid || !coords || !packed || !out || radius != RADIUS || !make_geom(b, h8, w8, levels, G)) return RPE_E_BADARG;
+    // four levels (324 channels), rows of whole groups (the workgroup's 64 queries are 64 consecutive pixels), at most 65535 batch items
+    if (levels != MAX_LEVELS || (w8 % GQ) != 0 || b > 65535) return RPE_E_UNSUPPORTED;
+    FzP P{(const float*)pyramid, coords, packed, bias, out, out_batch_stride, out2, out2_batch_stride, relu};
+    const dim3 grid(ceil_div(G.ngroups, 8), b);
+    if (out2) hipLaunchKernelGGL(k_lookup_conv1x1<true>, grid, dim3(256), 0, (hipStream_t)stream, P, G);
+    else hipLaunchKernelGGL(k_lookup_conv1x1<false>, grid, dim3(256), 0, (hipStream_t)stream, P, G);
     return rpe_check_launch();
 }
 

@@ -22,6 +22,11 @@ static int run_one(const rpe_op& op, void* const* streams, int n_streams) {
         const auto* a = as<rpe_corr_lookup_args>(op);
         return rpe_corr_lookup(a->pyramid, a->coords, a->b, a->h8, a->w8, a->levels, a->radius, a->out, st);
     }
+    case RPE_OP_LOOKUP_CONV1X1: {
+        const auto* a = as<rpe_lookup_conv1x1_args>(op);
+        return rpe_corr_lookup_conv1x1(a->pyramid, a->coords, a->b, a->h8, a->w8, a->levels, a->radius, a->packed, a->bias, a->relu, a->out,
+                                       a->out_batch_stride, a->out2, a->out2_batch_stride, st);
+    }
     case RPE_OP_CORR_BUILD: {
         const auto* a = as<rpe_corr_build_args>(op);
         return rpe_corr_build_ex(a->fmap1, a->fmap2, a->b, a->c, a->h8, a->w8, a->levels, a->feature_dtype, a->pyramid, st);

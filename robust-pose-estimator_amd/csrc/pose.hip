@@ -24,6 +24,10 @@
 #define NPART 32          // doubles per partial row: loss2d, loss3d, g[6], H[21], pad
 #define HIST 100          // torch.optim.LBFGS history_size default
 #define RED_THREADS 256
+// a row's ticket and epoch words sit in their own 128-byte lines, 256 bytes from the next row's: 48 workgroups poll a row's epoch, and all
+// rows' words in one line put every poll, ticket and epoch store of the launch through one memory channel
+#define SYNC_STRIDE 64
+#define SYNC_EPOCH 32
 
 struct RowState {
     double T[7];
@@ -70,7 +74,7 @@ extern "C" size_t rpe_pose_workspace_bytes(int n, int h, int w) {
     size_t st = align_up(sizeof(RowState) * (size_t)n, 256) + align_up(sizeof(RowUniform) * (size_t)n, 256);
     size_t pa = align_up(sizeof(double) * NPART * (size_t)pose_nblk(1, h, w) * n, 256);   // room for any partition_rows (n = 1 has the most blocks per
                                                                                           // row; the Hessian launch never has more)
-    return st + pa + align_up(sizeof(int) * (size_t)n, 256) + 256;                        // + one ticket counter per row
+    return st + pa + sizeof(int) * SYNC_STRIDE * (size_t)n + 256;                         // + one ticket counter and one epoch word per row
 }
 
 struct PoseArgs {
@@ -176,26 +180,51 @@ __device__ __forceinline__ void pixel_terms(double* acc, double px, double py, d
     }
 }
 
+#ifdef RPE_POSE_PROBE
+// diagnostic build only (tools/probe_pose_tail.sh): 100 MHz wall-clock stamps of the last tail of row 0
+// per evaluation e < 32 of row 0: [8e+0] workgroup 0 leaves the poll, [8e+1..4] the tail's phases, [8e+5] the LAST workgroup leaves the pixel
+// loop, [8e+6] epoch words stored, [8e+7] workgroup 0 leaves the pixel loop
+__device__ long long g_pose_probe[256];
+__device__ int g_pose_probe_eval;
+extern "C" int rpe_pose_probe_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_probe), sizeof(long long) * 256) == hipSuccess ? 0 : -2; }
+#define PROBE(i) do { if (row == 0 && threadIdx.x == 0 && g_pose_probe_eval < 32) g_pose_probe[8 * g_pose_probe_eval + (i)] = wall_clock64(); } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
+
 struct SolveOpts { double tol_grad, tol_change; int history; };
 // what the tail of a solve's reduction needs (rpe_pose_reduce's stand-alone launches have no tail)
 struct TailArgs {
-    int* tickets;                 // one counter per row, zero between launches
+    int* tickets;                 // SYNC_STRIDE ints per row: [0] the ticket counter (zero between evaluations), [SYNC_EPOCH] the epoch word
+    int evals;                    // PERSIST: evaluations this launch runs
     int mode, max_iter;
     SolveOpts opt;
     double* T_out; float* vec7; float* log6; int32_t* info;
 };
-template <bool TAIL>
-__device__ void reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z);
+template <bool COH>
+__device__ bool reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z, double* line);
 
+#define EPOCH_STOPPED (1 << 30)
+// a workgroup-uniform double from LDS, moved to scalar registers
+__device__ __forceinline__ double lds_uniform(const double* p) {
+    const double v = *p;
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// TAIL: the launch belongs to a solve: the row's last workgroup runs the update, and the launch runs Z.evals evaluations -- between
+// evaluations a row's workgroups wait for the row's tail (an epoch word per row), so there is no launch boundary, no dispatch of 768
+// workgroups and no drained chip between them.  Z.evals > 1 needs every workgroup of the grid resident at once (the host checks; else it
+// launches this SAME kernel once per evaluation with Z.evals = 1: one instantiation, hence one set of floating-point contractions and
+// bit-identical sums, whichever way a solve is launched -- chunked tracking relies on that).
 template <bool HESS, int VEC, bool TAIL>
 __global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseArgs A, RowUniform* uni, RowState* states,
                                                                              double* __restrict__ partials, TailArgs Z) {
+    constexpr bool PERSIST = TAIL;
     constexpr int NACC = HESS ? 29 : 8;
     const int row = blockIdx.y;
     const int nblk = gridDim.x;
     double* prow = partials + ((size_t)row * nblk + blockIdx.x) * NPART;
     if (states && states[row].stop != 0) return;          // finished rows cost nothing (every workgroup of the row sees the same flag: no ticket is drawn)
-    const int64_t hw = (int64_t)A.h * A.w;
     const RowUniform& U = uni[row];
     double R[9], t[3], K[9];
 #pragma unroll
@@ -203,72 +232,136 @@ __global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseA
     t[0] = U.t[0]; t[1] = U.t[1]; t[2] = U.t[2];
     const double c2 = U.c2, c3 = U.c3;
     const double Wd = (double)A.w, Hd = (double)A.h;
-
-    const float* flx = A.flow + (size_t)row * 2 * hw; const float* fly = flx + hw;
-    const float* p1 = A.pcl1 + (size_t)row * 3 * hw;
-    const float* p2 = A.pcl2 + (size_t)row * 3 * hw;
-    const float* w1 = A.w1 + (size_t)row * hw; const float* w2 = A.w2 + (size_t)row * hw;
-    const uint8_t* m1 = A.m1 + (size_t)row * hw; const uint8_t* m2 = A.m2 + (size_t)row * hw;
-
-    double acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-
-    const int64_t nvec = (hw + VEC - 1) / VEC;
-    for (int64_t vq = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; vq < nvec; vq += (int64_t)nblk * RED_THREADS) {
-        const int64_t base = vq * VEC;
-        float f0[VEC], f1[VEC], a0[VEC], a1[VEC], a2[VEC], b0[VEC], b1[VEC], b2[VEC], ww1[VEC], ww2[VEC];
-        uint8_t mm1[VEC], mm2[VEC];
-        if constexpr (VEC == 4) {
-            *(float4*)f0 = *(const float4*)(flx + base); *(float4*)f1 = *(const float4*)(fly + base);
-            *(float4*)a0 = *(const float4*)(p1 + base); *(float4*)a1 = *(const float4*)(p1 + hw + base);
-            *(float4*)a2 = *(const float4*)(p1 + 2 * hw + base);
-            *(float4*)b0 = *(const float4*)(p2 + base); *(float4*)b1 = *(const float4*)(p2 + hw + base);
-            *(float4*)b2 = *(const float4*)(p2 + 2 * hw + base);
-            *(float4*)ww1 = *(const float4*)(w1 + base); *(float4*)ww2 = *(const float4*)(w2 + base);
-            *(uint32_t*)mm1 = *(const uint32_t*)(m1 + base); *(uint32_t*)mm2 = *(const uint32_t*)(m2 + base);
-        } else {
-            f0[0] = flx[base]; f1[0] = fly[base];
-            a0[0] = p1[base]; a1[0] = p1[hw + base]; a2[0] = p1[2 * hw + base];
-            b0[0] = p2[base]; b1[0] = p2[hw + base]; b2[0] = p2[2 * hw + base];
-            ww1[0] = w1[base]; ww2[0] = w2[base]; mm1[0] = m1[base]; mm2[0] = m2[base];
-        }
-        const int y = (int)(base / A.w);
-        const int x = (int)(base - (int64_t)y * A.w);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            double p[3] = {(double)a0[k], (double)a1[k], (double)a2[k]};
-            double q[3] = {(double)b0[k], (double)b1[k], (double)b2[k]};
-            pixel_terms<HESS>(acc, (double)(x + k) + 0.5, (double)y + 0.5, (double)f0[k], (double)f1[k], p, q,
-                              (double)ww1[k], (double)ww2[k], mm1[k] != 0, mm2[k] != 0, R, t, K, c2, c3, Wd, Hd);
-            if (VEC > 1) __builtin_amdgcn_sched_barrier(0);   // one pixel at a time: bounds f64 live ranges
-        }
-    }
-
     __shared__ double red[RED_THREADS / RPE_WAVE][NPART];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int is_last, epoch_seen;
+    int* const ticket = Z.tickets + (size_t)row * SYNC_STRIDE;
+    double* const line = (double*)(ticket + SYNC_EPOCH);      // the row's pose line: [epoch | R0..R6 || epoch | R7 R8 t0 t1 t2 | - -], 128-byte aligned
+
+#pragma nounroll
+    for (int it = 0; it < (PERSIST ? Z.evals : 1); ++it) {
+        // PERSIST: the plane pointers and the per-thread offsets are recomputed per evaluation from two values the compiler cannot see
+        // through -- hoisted out of the evaluation loop (every address of every pass of the pixel loop) they cost 150 spilled registers
+        int64_t hw = (int64_t)A.h * A.w;
+        unsigned tid = threadIdx.x;
+        if constexpr (PERSIST) { asm volatile("" : "+s"(hw)); asm volatile("" : "+v"(tid)); }
+        const float* flx = A.flow + (size_t)row * 2 * hw; const float* fly = flx + hw;
+        const float* p1 = A.pcl1 + (size_t)row * 3 * hw;
+        const float* p2 = A.pcl2 + (size_t)row * 3 * hw;
+        const float* w1 = A.w1 + (size_t)row * hw; const float* w2 = A.w2 + (size_t)row * hw;
+        const uint8_t* m1 = A.m1 + (size_t)row * hw; const uint8_t* m2 = A.m2 + (size_t)row * hw;
+        struct Quad { float f0[VEC], f1[VEC], a0[VEC], a1[VEC], a2[VEC], b0[VEC], b1[VEC], b2[VEC], ww1[VEC], ww2[VEC]; uint8_t mm1[VEC], mm2[VEC]; };
+        auto load_quad = [&](int64_t vq, Quad& Q) {
+            const int64_t base = vq * VEC;
+            if constexpr (VEC == 4) {
+                *(float4*)Q.f0 = *(const float4*)(flx + base); *(float4*)Q.f1 = *(const float4*)(fly + base);
+                *(float4*)Q.a0 = *(const float4*)(p1 + base); *(float4*)Q.a1 = *(const float4*)(p1 + hw + base);
+                *(float4*)Q.a2 = *(const float4*)(p1 + 2 * hw + base);
+                *(float4*)Q.b0 = *(const float4*)(p2 + base); *(float4*)Q.b1 = *(const float4*)(p2 + hw + base);
+                *(float4*)Q.b2 = *(const float4*)(p2 + 2 * hw + base);
+                *(float4*)Q.ww1 = *(const float4*)(w1 + base); *(float4*)Q.ww2 = *(const float4*)(w2 + base);
+                *(uint32_t*)Q.mm1 = *(const uint32_t*)(m1 + base); *(uint32_t*)Q.mm2 = *(const uint32_t*)(m2 + base);
+            } else {
+                Q.f0[0] = flx[base]; Q.f1[0] = fly[base];
+                Q.a0[0] = p1[base]; Q.a1[0] = p1[hw + base]; Q.a2[0] = p1[2 * hw + base];
+                Q.b0[0] = p2[base]; Q.b1[0] = p2[hw + base]; Q.b2[0] = p2[2 * hw + base];
+                Q.ww1[0] = w1[base]; Q.ww2[0] = w2[base]; Q.mm1[0] = m1[base]; Q.mm2[0] = m2[base];
+            }
+        };
+        const int64_t nvec = (hw + VEC - 1) / VEC;
+        int64_t vq = (int64_t)blockIdx.x * RED_THREADS + tid;
+        // (Measured and NOT adopted: the first pass's loads issued before the wait for the row's tail -- the 42 registers held across the
+        // poll spill, and the solve went from 406 to 459 us.)
+        if (PERSIST && it > 0) {
+            // The row's tail of evaluation it - 1 publishes the new pose in the row's 128-byte pose line: each 64-byte half carries its own
+            // copy of the epoch word in front of its part of (R, t), written after the data has been acknowledged -- a half that shows
+            // epoch >= it shows the new data (one memory transaction per half).  Wave 0 polls the line with one 16-lane load: the pose
+            // arrives WITH the epoch, not a round trip later.
+            if (threadIdx.x < 64) {
+                double v = 0.0;
+                for (;;) {
+                    if (threadIdx.x < 16) v = __hip_atomic_load(line + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int ea = __builtin_amdgcn_readlane(__double2loint(v), 0), eb = __builtin_amdgcn_readlane(__double2loint(v), 8);
+                    if ((ea & ~EPOCH_STOPPED) >= it && (eb & ~EPOCH_STOPPED) >= it) { if (threadIdx.x == 0) epoch_seen = ea; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                // lanes 1..7: R[0..6], lanes 9..13: R[7], R[8], t[0..2]
+                if ((threadIdx.x >= 1 && threadIdx.x < 8) || (threadIdx.x >= 9 && threadIdx.x < 14)) red[0][threadIdx.x < 8 ? threadIdx.x - 1 : threadIdx.x - 2] = v;
+            }
+            __syncthreads();
+            if (epoch_seen & EPOCH_STOPPED) return;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        double s = wave_sum(acc[i]);
-        if (lane == 0) red[wv][i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NPART) {
-        double s = 0.0;
-        if (threadIdx.x < NACC) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        prow[threadIdx.x] = s;
-    }
-    if constexpr (TAIL) {
-        // the row's last workgroup to get here runs the update: partial row visible device-wide (fence), then one ticket per workgroup
-        __shared__ int is_last;
-        __threadfence();
+            for (int i = 0; i < 9; ++i) R[i] = lds_uniform(&red[0][i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t[i] = lds_uniform(&red[0][9 + i]);
+            __syncthreads();                                  // (red is the reduction's scratch again below)
+        }
+#ifdef RPE_POSE_PROBE
+        if (TAIL && row == 0 && threadIdx.x == 0) { if (blockIdx.x == 0) { g_pose_probe_eval = it; g_pose_probe[8 * it + 0] = wall_clock64(); } }
+#endif
+        double acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+        auto compute_quad = [&](int64_t vq_, const Quad& Q) {
+            const int64_t base = vq_ * VEC;
+            const int y = (int)(base / A.w);
+            const int x = (int)(base - (int64_t)y * A.w);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                double p[3] = {(double)Q.a0[k], (double)Q.a1[k], (double)Q.a2[k]};
+                double q[3] = {(double)Q.b0[k], (double)Q.b1[k], (double)Q.b2[k]};
+                pixel_terms<HESS>(acc, (double)(x + k) + 0.5, (double)y + 0.5, (double)Q.f0[k], (double)Q.f1[k], p, q,
+                                  (double)Q.ww1[k], (double)Q.ww2[k], Q.mm1[k] != 0, Q.mm2[k] != 0, R, t, K, c2, c3, Wd, Hd);
+                if (VEC > 1) __builtin_amdgcn_sched_barrier(0);   // one pixel at a time: bounds f64 live ranges
+            }
+        };
+        for (; vq < nvec; vq += (int64_t)nblk * RED_THREADS) {
+            Quad Q;
+            load_quad(vq, Q);
+            compute_quad(vq, Q);
+        }
+
+#ifdef RPE_POSE_PROBE
+        if (TAIL && row == 0 && threadIdx.x == 0 && it < 32) { atomicMax((unsigned long long*)&g_pose_probe[8 * it + 5], (unsigned long long)wall_clock64());
+                                                                 if (blockIdx.x == 0) g_pose_probe[8 * it + 7] = wall_clock64(); }
+#endif
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+            double s = wave_sum(acc[i]);
+            if (lane == 0) red[wv][i] = s;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) is_last = atomicAdd(&Z.tickets[row], 1) == nblk - 1;
-        __syncthreads();
-        if (!is_last) return;
-        __threadfence();                                   // (acquire side: the other workgroups' partial rows)
-        if (threadIdx.x == 0) Z.tickets[row] = 0;          // for the next evaluation's launch
-        reduce_tail<TAIL>(A, uni, states, partials, row, nblk, Z);
+        if (threadIdx.x < NPART) {
+            double s = 0.0;
+            if (threadIdx.x < NACC) s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+            // TAIL: the partial row is read by ANOTHER workgroup of this launch (possibly on another XCD, behind another L2): a device-scope
+            // store (written through) here and device-scope loads there.  A device-scope FENCE instead would write back and invalidate the
+            // whole L2 of this XCD once per workgroup: measured 141 us per evaluation instead of 51.
+            if constexpr (TAIL) __hip_atomic_store(prow + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else prow[threadIdx.x] = s;
+        }
+        if constexpr (TAIL) {
+            // the row's last workgroup to get here runs the update.  The barrier waits for this workgroup's stores above (they have reached
+            // the device's point of coherence when they are acknowledged); then one ticket per workgroup.
+            __syncthreads();
+            if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1;
+            __syncthreads();
+            if (!is_last) {
+                if constexpr (PERSIST) continue; else return;
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next evaluation
+            const bool stopped = reduce_tail<PERSIST>(A, uni, states, partials, row, nblk, Z, line);
+            if constexpr (PERSIST) {
+                // the tail's device-scope stores (pose line data, state) are acknowledged when this barrier lets the workgroup through; then
+                // the two epoch words of the pose line
+                __syncthreads();
+                if (threadIdx.x < 2) __hip_atomic_store((long long*)line + 8 * threadIdx.x, (long long)((it + 1) | (stopped ? EPOCH_STOPPED : 0)), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+#ifdef RPE_POSE_PROBE
+                if (row == 0 && threadIdx.x == 0 && it < 32) g_pose_probe[8 * it + 6] = wall_clock64();
+#endif
+            }
+        }
     }
 }
 
@@ -332,13 +425,25 @@ __device__ __forceinline__ void sum_partials(const double* partials, int row, in
     const int j = tid & 31, part = tid >> 5;
     const double* p = partials + (size_t)row * nblk * NPART + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    // part p takes blocks p, p + 8, ...: rounds of four go to s0..s3, the rest to s0 -- the ORDER is the contract (it fixes the bits); the
+    // loads of up to eight blocks (two rounds, or a round and the rest) are issued together: a device-scope load is a ~1.2 us round trip
+    // to the memory side, and three dependent trips were most of the tail's 5 us "loads + sum"
     int b = part;
-    for (; b + 24 < nblk; b += 32) {
-        const double v0 = ld_partial<COHERENT>(p + (size_t)b * NPART), v1 = ld_partial<COHERENT>(p + (size_t)(b + 8) * NPART);
-        const double v2 = ld_partial<COHERENT>(p + (size_t)(b + 16) * NPART), v3 = ld_partial<COHERENT>(p + (size_t)(b + 24) * NPART);
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    while (b < nblk) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = b + 8 * i < nblk ? ld_partial<COHERENT>(p + (size_t)(b + 8 * i) * NPART) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int bb = b + 32 * r;
+            if (bb + 24 < nblk) { s0 += v[4 * r]; s1 += v[4 * r + 1]; s2 += v[4 * r + 2]; s3 += v[4 * r + 3]; }
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (bb + 8 * i < nblk) s0 += v[4 * r + i];
+            }
+        }
+        b += 64;
     }
-    for (; b < nblk; b += 8) s0 += ld_partial<COHERENT>(p + (size_t)b * NPART);
     red[part][j] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (tid < NPART) {
@@ -370,9 +475,25 @@ __device__ __forceinline__ void finalize_row(const RowState& S, int row, double*
     if (info) { info[row * 4 + 0] = S.n_iter; info[row * 4 + 1] = S.evals; info[row * 4 + 2] = S.stop; info[row * 4 + 3] = 0; }
 }
 
-template <bool TAIL>
-__device__ void reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z) {
+// COH (the persistent launch): the row's state was last written by the tail of the previous evaluation, which may have run on another XCD
+// behind another L2 -- every access to it is a device-scope load / store (written through, never answered by a stale line).  A fence pair
+// per tail instead (buffer_inv + buffer_wbl2 of the whole L2) was measured at +55 us per evaluation.
+template <bool COH>
+__device__ __forceinline__ double ldd(const double* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void std_(double* p, double v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// returns (to every thread) whether the row has stopped
+template <bool COH>
+__device__ bool reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z, double* line) {
     const int lane = threadIdx.x;
+    PROBE(1);
     RowState& G = states[row];
     constexpr int HEAD = 31;                                  // doubles in front of old_dirs (T, g, prev_g, d, t, loss, prev_loss, H_diag, 4 ints)
     static_assert(offsetof(RowState, old_dirs) == HEAD * sizeof(double), "RowState head");
@@ -382,23 +503,30 @@ __device__ void reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states
     __shared__ double h_al[HIST], Lc[6][6];
     __shared__ int wb[2];                                     // history entries [wb[0], wb[1]) changed
     // the state's loads go out first, the partial rows' right behind them: one round trip for both
-    if (lane < HEAD) ((double*)&S)[lane] = ((const double*)&G)[lane];
-    if (lane < (int)(sizeof(RowUniform) / sizeof(double))) ((double*)&U)[lane] = ((const double*)&uni[row])[lane];
+    if (lane < HEAD) ((double*)&S)[lane] = ldd<COH>((const double*)&G + lane);
+    if (lane < (int)(sizeof(RowUniform) / sizeof(double))) ((double*)&U)[lane] = ldd<COH>((const double*)&uni[row] + lane);
     if (Z.mode != RPE_SOLVER_GN) {
-        const int nold = G.num_old;
-        for (int e = lane; e < nold * 6; e += UPD_THREADS) { (&S.old_dirs[0][0])[e] = (&G.old_dirs[0][0])[e]; (&S.old_stps[0][0])[e] = (&G.old_stps[0][0])[e]; }
-        for (int e = lane; e < nold; e += UPD_THREADS) S.ro[e] = G.ro[e];
+        // the history is fetched without waiting for its length (a dependent round trip): it never holds more pairs than iterations
+        const int nold = Z.max_iter < Z.opt.history ? Z.max_iter : Z.opt.history;
+        for (int e = lane; e < nold * 6; e += UPD_THREADS) { (&S.old_dirs[0][0])[e] = ldd<COH>(&G.old_dirs[0][0] + e); (&S.old_stps[0][0])[e] = ldd<COH>(&G.old_stps[0][0] + e); }
+        for (int e = lane; e < nold; e += UPD_THREADS) S.ro[e] = ldd<COH>(&G.ro[e]);
     }
     if (lane == 0) { wb[0] = 0; wb[1] = 0; }
     sum_partials<true>(partials, row, nblk, lane, vals, red);             // (ends with a barrier)
+    PROBE(2);
     if (lane == 0) pose_update_row(S, U, h_al, Lc, wb, vals, A.lw, row, A.h, A.w, Z.mode, Z.max_iter, Z.opt);
+    PROBE(3);
     __syncthreads();
-    if (lane < HEAD) ((double*)&G)[lane] = ((const double*)&S)[lane];
-    if (lane < 12) ((double*)&uni[row])[lane] = ((const double*)&U)[lane];          // R, t (write_rt)
-    for (int e = wb[0] * 6 + lane; e < wb[1] * 6; e += UPD_THREADS) { (&G.old_dirs[0][0])[e] = (&S.old_dirs[0][0])[e]; (&G.old_stps[0][0])[e] = (&S.old_stps[0][0])[e]; }
-    for (int e = wb[0] + lane; e < wb[1]; e += UPD_THREADS) G.ro[e] = S.ro[e];
+    if (lane < HEAD) std_<COH>((double*)&G + lane, ((const double*)&S)[lane]);
+    if (lane < 12) std_<COH>((double*)&uni[row] + lane, ((const double*)&U)[lane]);          // R, t (write_rt)
+    if (COH && lane < 12) std_<COH>(line + (lane < 7 ? 1 + lane : 2 + lane), ((const double*)&U)[lane]);   // ... and into the row's pose line (see the poll)
+    for (int e = wb[0] * 6 + lane; e < wb[1] * 6; e += UPD_THREADS) { std_<COH>(&G.old_dirs[0][0] + e, (&S.old_dirs[0][0])[e]); std_<COH>(&G.old_stps[0][0] + e, (&S.old_stps[0][0])[e]); }
+    for (int e = wb[0] + lane; e < wb[1]; e += UPD_THREADS) std_<COH>(&G.ro[e], S.ro[e]);
     // a row that has stopped is never touched again: its outputs are written here, once (DeclarativeFunctionLie.forward's vec7 / log6)
-    if (lane == 64 && S.stop != 0) finalize_row(S, row, Z.T_out, Z.vec7, Z.log6, Z.info);
+    const bool stopped = S.stop != 0;
+    if (lane == 64 && stopped) finalize_row(S, row, Z.T_out, Z.vec7, Z.log6, Z.info);
+    PROBE(4);
+    return stopped;
 }
 
 __device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, double (*L)[6], int* wb, const double* vals, const float* lw, int row,
@@ -520,7 +648,9 @@ __device__ void pose_update_row(RowState& S, RowUniform& U, double* h_al, double
 __global__ void k_pose_init(RowState* states, RowUniform* uni, int* tickets, const float* K, const float* lw, int n, int h, int w) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
-    tickets[row] = 0;
+    tickets[(size_t)row * SYNC_STRIDE] = 0;
+    ((long long*)(tickets + (size_t)row * SYNC_STRIDE + SYNC_EPOCH))[0] = 0;       // the two epoch words of the row's pose line
+    ((long long*)(tickets + (size_t)row * SYNC_STRIDE + SYNC_EPOCH))[8] = 0;
     RowState& S = states[row];
     for (int i = 0; i < 6; ++i) { S.T[i] = 0.0; S.g[i] = 0.0; S.prev_g[i] = 0.0; S.d[i] = 0.0; }
     S.T[6] = 1.0;
@@ -556,20 +686,34 @@ __global__ __launch_bounds__(UPD_THREADS) void k_pose_pack(const double* partial
     else o[lane] = 0.0;
 }
 
-template <bool TAIL>
-static void launch_reduce(const PoseArgs& A, RowUniform* T, RowState* st, double* partials, int nblk, bool hess, hipStream_t s, const TailArgs& Z) {
-    dim3 grid(nblk, A.n), block(RED_THREADS);
+static bool pose_vec_ok(const PoseArgs& A) {
     bool vec = ((int64_t)A.h * A.w) % 4 == 0 && A.w % 4 == 0;
     const void* ptrs[] = {A.flow, A.pcl1, A.pcl2, A.w1, A.w2};
     for (const void* p : ptrs) vec = vec && ((uintptr_t)p % 16 == 0);
-    vec = vec && ((uintptr_t)A.m1 % 4 == 0) && ((uintptr_t)A.m2 % 4 == 0);
+    return vec && ((uintptr_t)A.m1 % 4 == 0) && ((uintptr_t)A.m2 % 4 == 0);
+}
+
+template <bool TAIL>
+static void launch_reduce(const PoseArgs& A, RowUniform* T, RowState* st, double* partials, int nblk, bool hess, hipStream_t s, const TailArgs& Z) {
+    dim3 grid(nblk, A.n), block(RED_THREADS);
     if (hess) {
-        if (vec) hipLaunchKernelGGL((k_pose_reduce<true, 4, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
+        if (pose_vec_ok(A)) hipLaunchKernelGGL((k_pose_reduce<true, 4, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
         else hipLaunchKernelGGL((k_pose_reduce<true, 1, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
     } else {
-        if (vec) hipLaunchKernelGGL((k_pose_reduce<false, 4, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
+        if (pose_vec_ok(A)) hipLaunchKernelGGL((k_pose_reduce<false, 4, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
         else hipLaunchKernelGGL((k_pose_reduce<false, 1, TAIL>), grid, block, 0, s, A, T, st, partials, Z);
     }
+}
+
+// Workgroups of the solve's kernel the current device holds at once (occupancy x compute units), 0 on any error: all evaluations go into
+// one launch only when the whole grid fits (a workgroup waiting for its row's tail never yields its slot).
+static int persistent_capacity(bool hess, bool vec) {
+    const void* fn = hess ? (vec ? (const void*)k_pose_reduce<true, 4, true> : (const void*)k_pose_reduce<true, 1, true>)
+                          : (vec ? (const void*)k_pose_reduce<false, 4, true> : (const void*)k_pose_reduce<false, 1, true>);
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RED_THREADS, 0) != hipSuccess) return 0;
+    return cus * per_cu;
 }
 
 static bool carve(void* ws, int n, int h, int w, RowState** st, RowUniform** uni, double** partials, int** tickets = nullptr) {
@@ -661,8 +805,13 @@ extern "C" int rpe_pose_solve_ex(const float* flow, const float* pcl1, const flo
     int evals = mode == RPE_SOLVER_LBFGS && iters == 0 ? 1 : iters;
     // every evaluation is ONE launch: the reduction, and in its tail (the row's last workgroup) the update, the stopping tests and -- for a
     // row that stops -- its outputs.  The last evaluation always stops a row (n_iter == max_iter at the latest).
-    const TailArgs Z{tickets, mode, iters, opt, T_out, vec7, log6, info};
-    for (int it = 0; it < evals; ++it) launch_reduce<true>(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s, Z);
+    // ... and all evaluations are ONE launch when every workgroup of the grid is resident at once (the default partition is sized for
+    // that: one round chip-wide): a row's workgroups then wait for their row's tail instead of for the next launch.  Otherwise the same
+    // kernel is launched once per evaluation.
+    const bool persist = evals > 1 && !(opts->reserved & RPE_SOLVE_LAUNCH_PER_EVALUATION) &&
+                         (long long)nblk * n <= persistent_capacity(mode == RPE_SOLVER_GN, pose_vec_ok(A));
+    const TailArgs Z{tickets, persist ? evals : 1, mode, iters, opt, T_out, vec7, log6, info};
+    for (int it = 0; it < (persist ? 1 : evals); ++it) launch_reduce<true>(A, uni, st, partials, nblk, mode == RPE_SOLVER_GN, s, Z);
     if (evals == 0) hipLaunchKernelGGL(k_pose_finalize, dim3(ceil_div(n, 64)), dim3(64), 0, s, st, n, T_out, vec7, log6, info);
     return rpe_check_launch();
 }

@@ -87,6 +87,7 @@ extern "C" {
 
 const char* rpe_version(void) { return "rpe-hip 0.1 gfx950"; }
 int rpe_abi_version(void) { return RPE_ABI_VERSION; }
+int rpe_abi_minor(void) { return RPE_ABI_MINOR; }
 
 int rpe_se3_exp(const void* xi, void* T, int64_t n, int dtype, void* stream) {
     if (!xi || !T || n < 0) return RPE_E_BADARG;

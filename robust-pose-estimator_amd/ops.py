@@ -272,10 +272,11 @@ def pose_reduce(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, T, need_
 
 
 def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mode=SOLVER_LBFGS,
-               tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, partition_rows=0):
+               tolerance_grad=1e-7, tolerance_change=1e-9, history_size=100, partition_rows=0, persistent=True):
     """Device-resident solve.  Returns (T f64 (n,7), vec7 f32 (n,7), log6 f32 (n,6), info int32 (n,4)).
     ``partition_rows=1``: every row's float64 sums are grouped as if it were solved alone (rpe_solve_opts), i.e. the result of a
-    row does not depend on the batch it is in, bit for bit."""
+    row does not depend on the batch it is in, bit for bit.  ``persistent=False`` (RPE_SOLVE_LAUNCH_PER_EVALUATION): one launch per
+    evaluation instead of one for the whole solve -- the same bits, for A/B measurements."""
     args, n, h, w = _pose_inputs(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight)
     dev = args[0].device
     T = torch.empty(n, 7, dtype=torch.float64, device=dev)
@@ -284,7 +285,8 @@ def pose_solve(flow, pcl1, pcl2, w1, w2, mask1, mask2, K, loss_weight, iters, mo
     info = torch.empty(n, 4, dtype=torch.int32, device=dev)
     ws = _workspace(n, h, w, dev)
     import ctypes
-    o = _lib.SolveOpts(ctypes.sizeof(_lib.SolveOpts), int(history_size), float(tolerance_grad), float(tolerance_change), int(partition_rows), 0)
+    o = _lib.SolveOpts(ctypes.sizeof(_lib.SolveOpts), int(history_size), float(tolerance_grad), float(tolerance_change), int(partition_rows),
+                       0 if persistent else 1)
     check(lib().rpe_pose_solve_ex(*[ptr(a) for a in args], n, h, w, int(mode), int(iters), ctypes.byref(o), ptr(T), ptr(vec7), ptr(log6),
                                   ptr(info), ptr(ws), stream_ptr()), 'rpe_pose_solve_ex')
     return T, vec7, log6, info
@@ -408,6 +410,38 @@ class CorrPyramid:
                                     stream_ptr()), 'rpe_corr_lookup')
         return out
 
+    def lookup_conv1x1(self, coords, packed, out, out2=None, relu=True, prepare=False):
+        """rpe_corr_lookup_conv1x1: act(convc1(lookup(coords))) in one kernel (``packed`` = PackedLookupConv of convc1's weight), written to the
+        channel slices ``out`` / ``out2`` (b, 256, h8, w8); bit-identical to lookup() + conv1x1.  ``prepare=True``: a launcher with ``.op``."""
+        co = _dev(coords, torch.float32, 'coords')
+        if co is not coords or tuple(co.shape) != (self.b, 2, self.h8, self.w8):
+            raise _lib.RpeError('corr lookup_conv1x1: coords must be a contiguous (b,2,h8,w8) tensor')
+        if not PackedLookupConv.supported(self.levels, self.radius, self.w8):
+            raise _lib.RpeError('corr lookup_conv1x1: needs 4 levels, radius 4 and w8 % 8 == 0 (use lookup + conv1x1)')
+        sl = []
+        for name, t in (('out', out), ('out2', out2)):
+            if t is None:
+                sl += [None, 0]
+                continue
+            if tuple(t.shape) != (self.b, packed.cout, self.h8, self.w8):
+                raise _lib.RpeError(f'corr lookup_conv1x1: {name} must be a ({self.b},{packed.cout},{self.h8},{self.w8}) channel slice')
+            pp, bs = _chan_slice(t, name)
+            sl += [pp.value, bs]
+        a = _lib.LookupConv1x1Args(self.buf.data_ptr(), co.data_ptr(), self.b, self.h8, self.w8, self.levels, self.radius, packed.packed.data_ptr(),
+                                   packed.bias.data_ptr() if packed.bias is not None else None, int(bool(relu)), sl[0], sl[1], sl[2], sl[3])
+        fn, keep = lib().rpe_corr_lookup_conv1x1, (self, co, packed, out, out2)
+
+        def launch():
+            if _REC is not None:
+                _REC.log(_lib.OP_LOOKUP_CONV1X1, a, keep)
+            check(fn(a.pyramid, a.coords, a.b, a.h8, a.w8, a.levels, a.radius, a.packed, a.bias, a.relu, a.out, a.out_batch_stride, a.out2,
+                     a.out2_batch_stride, stream_ptr()), 'rpe_corr_lookup_conv1x1')
+            return keep[3]
+        launch.keep, launch.op = keep, (_lib.OP_LOOKUP_CONV1X1, a)
+        if prepare:
+            return launch
+        return launch()
+
     def taps(self, coords):
         co = _dev(coords, torch.float32, 'coords')
         win = 2 * self.radius + 1
@@ -433,6 +467,24 @@ class CorrPyramid:
         check(lib().rpe_corr_export_level(ptr(self.buf), self.b, self.h8, self.w8, self.levels, level, ptr(dense),
                                           stream_ptr()), 'rpe_corr_export_level')
         return dense
+
+
+class PackedLookupConv:
+    """convc1's (256, 324, 1, 1) weight in rpe_corr_lookup_conv1x1's layout (a lane's fragments of a 16-channel step as one 64-byte piece)."""
+
+    def __init__(self, weight, bias=None):
+        w = _nchw(weight.detach().contiguous(), 'weight')
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        n = lib().rpe_corr_lookup_conv1x1_packed_floats(self.cout, self.cin) if (self.kh, self.kw) == (1, 1) else 0
+        if n == 0:
+            raise _lib.RpeError('PackedLookupConv: needs the (256, 324, 1, 1) weight of BasicMotionEncoder.convc1')
+        self.packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(lib().rpe_corr_lookup_conv1x1_pack(ptr(w), self.cout, self.cin, ptr(self.packed), stream_ptr()), 'rpe_corr_lookup_conv1x1_pack')
+        self.bias = None if bias is None else _nchw(bias.detach().contiguous(), 'bias')
+
+    @staticmethod
+    def supported(levels, radius, w8):
+        return levels == 4 and radius == 4 and w8 % 8 == 0
 
 
 # ------------------------------------------------------------------------------------------------- RAFT update

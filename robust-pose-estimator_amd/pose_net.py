@@ -41,7 +41,6 @@ class PoseNet(nn.Module):
         return self
 
     @torch.no_grad()
-    @torch.no_grad()
     def encode_frame(self, imagel, imager):
         """The encoder work of one new stereo frame -- fnet(left | right) and cnet(left) -- as ``infer(..., cache1=..., enc2=...)`` and
         ``flow2depth(..., enc=...)`` accept it: {'f': (2n,256,h/8,w/8), 'c': (n,256,h/8,w/8)}.  It depends on the frame's two images
@@ -50,6 +49,7 @@ class PoseNet(nn.Module):
         f, c = self._encode_both((imagel, imager), imagel)
         return dict(f=f, c=c)
 
+    @torch.no_grad()
     def flow2depth(self, imagel, imager, baseline, upsample=True, ret_cache=False, enc=None):
         """pose_net.py:127-135 -> (depth (n,1,h,w), stereo flow (n,2,h,w), valid (n,1,h,w) bool).
         ``upsample=False``: everything at 1/8 resolution, the flow in 1/8-pixel units and the depth divided by 8 (:131-132;

@@ -37,9 +37,10 @@ WINOGRAD = True          # 3x3 layers as F(2x2,3x3), the GRU's 1x5 / 5x1 as F(4,
 CORR_BF16X3 = False      # EXPERIMENT: correlation products as six bf16 products of an exact 3-way split (bench.py --corr-bf16x3)
 CONV_BF16X3 = False      # LABELLED VARIANT (bench.py --conv-bf16x3; never the headline): the update block's 3x3 layers with >= 128 input
 #                          channels (convc2, conv, FlowHead.conv1, the mask head's 3x3) through rpe_conv_wino_x3 -- Winograd products as six
-#                          bf16 products of an exact 3-way split -- and the correlation build through k_corr_build_x3.  The layers it does
-#                          NOT cover (measured no faster: short K loops) stay on the f32 matrix cores: the encoders, convf2, the GRU's
-#                          1x5 / 5x1 layers, convc1 and the other 1x1 layers, the stems.
+#                          bf16 products of an exact 3-way split --, the 1x1 layers with LINEAR / RELU epilogues (convc1, fnet's output layer,
+#                          the ReLU half of cnet's, the mask head's 1x1) through rpe_conv1x1_x3, and the correlation build through
+#                          k_corr_build_x3.  The layers it does NOT cover (measured no faster) stay on the f32 matrix cores: the encoders'
+#                          3x3 layers, convf2, the GRU's 1x5 / 5x1 layers (unless X3_GRU), the tanh half of cnet's output layer, the stems.
 X3_MIN_CIN = 128         # rpe_conv_wino_x3 pays from 8 K steps of 16 channels on
 X3_GRU = False           # under CONV_BF16X3, also the SepConvGRU's 1x5 / 5x1 layers on rpe_conv_wino1d_x3.  Off: in the bench step its launches
 #                          take 449 / 410 us (z|r, 1x5 / 5x1) and 251 / 237 us (q) against rpe_conv_wino1d's 407 / 395 and 240 / 224 -- one

@@ -31,8 +31,9 @@ torch.set_num_threads(_usable_cores())            # the CPU oracle is ~100x slow
 
 def pytest_addoption(parser):
     parser.addoption('--conv-bf16x3', action='store_true', default=False,
-                     help='run the suite with raft.CONV_BF16X3 = True (the labelled bf16x3 variant of the >= 128-channel 3x3 layers, the GRU '
-                          'convolutions and the correlation build): every parity test must pass unchanged under the switch')
+                     help='run the suite with raft.CONV_BF16X3 = True (the labelled bf16x3 variant: the >= 128-channel 3x3 layers of the update block, '
+                          'the 1x1 layers and the correlation build; the GRU keeps its f32 kernels unless a test sets raft.X3_GRU): every parity '
+                          'test must pass unchanged under the switch')
 
 
 def pytest_configure(config):

@@ -424,3 +424,33 @@ def test_x3_conv1x1_rejects_what_it_cannot_do_and_error_bars(rpe):
         xmax, xrms = _errs(x3, ref)
         print(f'1x1 {cin}->{cout}: f32 max {fmax:.2e} rms {frms:.2e}; bf16x3 max {xmax:.2e} rms {xrms:.2e}; ratios {xmax / fmax:.2f} / {xrms / frms:.2f}')
         assert xrms <= 1.25 * frms and xmax <= 1.25 * fmax
+
+
+def test_x3_conv1x1_special_values_as_documented(rpe):
+    """include/rpe.h (rpe_conv1x1_x3, SPECIAL VALUES) at convc1's ragged shape (cin = 324: the padded last K step reads channel 323 a second
+    time against zero weights): a NaN poisons exactly the pixel it sits in -- in channel 323 too --, an Inf gives a non-finite value in exactly
+    its own pixel (NaN where the f32 kernel gives Inf: the documented deviation of the split), every other output equals the clean run bit
+    for bit, and subnormal-scale / large finite data comes through at the f32 kernel's accuracy."""
+    from rpe_amd import ops
+    rng = np.random.default_rng(17)
+    cin, cout, h, w = 324, 256, 16, 20
+    x, wt, bias = _rand(rng, 2, cin, h, w), _rand(rng, cout, cin, 1, 1, s=0.05), _rand(rng, cout, s=0.5)
+    px, pf = ops.PackedConv1x1X3(wt.cuda(), bias.cuda()), ops.PackedConv1x1(wt.cuda(), bias.cuda())
+    run = lambda t, p: ops.conv1x1(t.cuda(), p, ops.CONV_LINEAR, torch.empty(2, cout, h, w, device='cuda')).cpu()
+    clean = run(x, px)
+    y = x.clone()
+    y[0, 323, 3, 4] = float('nan'); y[0, 7, 9, 9] = float('nan'); y[1, 323, 5, 6] = float('inf'); y[1, 100, 0, 0] = float('-inf')
+    got, f32 = run(y, px), run(y, pf)
+    hit = torch.zeros(2, h, w, dtype=torch.bool)
+    hit[0, 3, 4] = hit[0, 9, 9] = hit[1, 5, 6] = hit[1, 0, 0] = True
+    bad = ~torch.isfinite(got)
+    assert bad.all(1)[hit].all() and not bad.any(1)[~hit].any()                          # exactly the four pixels, every output channel of them
+    assert torch.equal(got.permute(0, 2, 3, 1)[~hit], clean.permute(0, 2, 3, 1)[~hit])   # everything else untouched, bit for bit
+    assert torch.isnan(got[0, :, 3, 4]).all() and torch.isnan(f32[0, :, 3, 4]).all()     # NaN in, NaN out: both kernels
+    assert torch.isinf(f32[1, :, 5, 6]).all() and torch.isnan(got[1, :, 5, 6]).all()     # the documented deviation: Inf -> NaN under the split
+    for scale in (1e-30, 1e30):
+        xs = x * scale
+        ref = F.conv2d(xs.double(), wt.double(), bias.double() * (0.0 if scale < 1 else 1.0))
+        g = ops.conv1x1(xs.cuda(), ops.PackedConv1x1X3(wt.cuda(), (bias * (0.0 if scale < 1 else 1.0)).cuda()), ops.CONV_LINEAR,
+                        torch.empty(2, cout, h, w, device='cuda')).cpu().double()
+        assert (g - ref).abs().max() < 1e-5 * ref.abs().max(), scale

@@ -407,3 +407,51 @@ def test_build_launch_classes_agree_bitwise(rpe):
     coords = torch.rand(2, 2, h8, w8, device='cuda') * torch.tensor([w8, h8], device='cuda').view(1, 2, 1, 1)
     cb = torch.zeros(b, 2, h8, w8, device='cuda'); cb[5:7] = coords
     assert torch.equal(big.lookup(cb)[5:7], small.lookup(coords))
+
+
+@pytest.mark.parametrize('b,h8,w8,spread', [(2, 64, 80, 0.7), (1, 44, 48, 3.0), (3, 20, 24, 12.0), (2, 17, 16, 1.5)])
+def test_lookup_fused_into_convc1_is_bit_identical_to_the_two_kernels(rpe, b, h8, w8, spread):
+    """rpe_corr_lookup_conv1x1 (the 324-channel lookup result stays in LDS and is contracted there) against rpe_corr_lookup followed by
+    convc1 on both of its routes (rpe_conv1x1's GEMM and rpe_conv_fused's implicit GEMM, which are bit-identical to each other): torch.equal,
+    with smooth and rough flow (several staging rounds per group at spread 12), windows partly and wholly outside the maps, non-finite
+    coordinates, with and without ReLU, into channel slices, with the second destination, through the prepared launcher; a group count that
+    is not a multiple of the workgroup's eight (17 x 16)."""
+    from rpe_amd import ops
+    f1, f2 = fmaps(7 * b + h8, b, h8, w8)
+    pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda())
+    co = coords_for(b + w8, b, h8, w8, spread)
+    co[0, 0, 1, 2] = float('nan'); co[0, 1, 2, 3] = float('inf'); co[0, :, 3, 4] = -1.0e9; co[0, :, 0, 0] = -7.5; co[-1, 0, -1, -1] = w8 + 9.25
+    co = co.cuda()
+    rng = np.random.default_rng(h8)
+    wt = torch.from_numpy(rng.normal(0, 0.05, size=(256, 324, 1, 1)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.normal(0, 0.5, size=(256,)).astype(np.float32)).cuda()
+    corr = pyr.lookup(co)
+    packed = ops.PackedLookupConv(wt, bias)
+    for relu in (True, False):
+        mode = ops.CONV_RELU if relu else ops.CONV_LINEAR
+        ref_gemm = ops.conv1x1(corr, ops.PackedConv1x1(wt, bias), mode, torch.empty(b, 256, h8, w8, device='cuda'))
+        ref_igemm = ops.conv_fused(corr, ops.PackedConv(wt, bias), mode, torch.empty(b, 256, h8, w8, device='cuda'))
+        assert torch.equal(torch.nan_to_num(ref_gemm), torch.nan_to_num(ref_igemm)) and torch.equal(torch.isnan(ref_gemm), torch.isnan(ref_igemm))
+        obuf = torch.full((b, 264, h8, w8), -7.0, device='cuda'); o2 = torch.full((b, 260, h8, w8), -7.0, device='cuda')
+        pyr.lookup_conv1x1(co, packed, obuf[:, 4:260], out2=o2[:, 2:258], relu=relu)
+        got = obuf[:, 4:260]
+        assert torch.equal(torch.isnan(got), torch.isnan(ref_gemm)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(ref_gemm))
+        assert torch.equal(torch.nan_to_num(o2[:, 2:258]), torch.nan_to_num(got))
+        assert (obuf[:, :4] == -7.0).all() and (obuf[:, 260:] == -7.0).all() and (o2[:, :2] == -7.0).all() and (o2[:, 258:] == -7.0).all()
+        again = torch.empty(b, 256, h8, w8, device='cuda')
+        pyr.lookup_conv1x1(co, packed, again, relu=relu, prepare=True)()
+        assert torch.equal(torch.nan_to_num(again), torch.nan_to_num(got))
+    assert bool(torch.isfinite(ref_gemm).all())                       # non-finite coordinates sample zeros (rpe_corr_lookup), as in both routes above
+
+
+def test_lookup_fused_into_convc1_refuses_what_it_cannot_do(rpe):
+    from rpe_amd import ops
+    with pytest.raises(rpe.RpeError):
+        ops.PackedLookupConv(torch.zeros(256, 320, 1, 1, device='cuda'))
+    with pytest.raises(rpe.RpeError):
+        ops.PackedLookupConv(torch.zeros(128, 324, 1, 1, device='cuda'))
+    f1, f2 = fmaps(3, 1, 16, 20)
+    pyr = ops.CorrPyramid(1, 16, 20, device='cuda').build(f1.cuda(), f2.cuda())       # w8 = 20: rows are not whole groups of 8
+    with pytest.raises(rpe.RpeError):
+        pyr.lookup_conv1x1(coords_for(1, 1, 16, 20, 1.0).cuda(), ops.PackedLookupConv(torch.zeros(256, 324, 1, 1, device='cuda')),
+                           torch.empty(1, 256, 16, 20, device='cuda'))

@@ -242,3 +242,32 @@ def test_solve_is_graph_capturable(rpe):
     torch.cuda.synchronize()
     want = ops.pose_solve(*dev(synth.solver_args(c2)), iters=8)[0]
     assert torch.equal(T, want) and info[:, 0].tolist() == [8, 8]
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_one_launch_solve_equals_a_launch_per_evaluation(rpe, mode):
+    """The whole solve as ONE persistent launch (a row's workgroups wait for the row's tail between evaluations) against one launch per
+    evaluation (RPE_SOLVE_LAUNCH_PER_EVALUATION): the same block partition, the same fixed-order sums, so every output -- poses, float32
+    views, iteration / evaluation counts, stop reasons -- must be equal bit for bit.  Rows that stop early (masked out, NaN, converged)
+    sit next to rows that run all iterations; sizes from one workgroup per row to the full 640x512 frame; repeated (stale tickets /
+    epochs of a previous solve in a reused workspace would show)."""
+    from rpe_amd import ops
+    cases = [synth.solver_args(synth.solver_case(11, 5, 64, 96)), synth.solver_args(synth.solver_case(12, 2, 512, 640)),
+             synth.solver_args(synth.solver_case(13, 16, 128, 160)), synth.solver_args(synth.solver_case(14, 1, 33, 57))]
+    a0 = [t.clone() for t in cases[0]]
+    a0[5][1] = False                                    # row 1: mask1 all false -> optimal at start
+    a0[0][3, 0, 5, 5] = float('nan')                    # row 3: a NaN flow -> NaN pose, runs to the evaluation limit like the reference
+    cases.append(a0)
+    for args in cases:
+        for k in (1, 2, 8, 20):
+            a = rpe_solve(ops, args, k, mode, True)
+            for _ in range(2):
+                b = rpe_solve(ops, args, k, mode, False)
+                c = rpe_solve(ops, args, k, mode, True)
+                for x, y, z in zip(a, b, c):
+                    assert torch.equal(x, y, ) or (torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+                    assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(z)) and (torch.isnan(x) == torch.isnan(z)).all()
+
+
+def rpe_solve(ops, args, k, mode, persistent):
+    return [t.cpu() for t in ops.pose_solve(*dev(args), iters=k, mode=mode, persistent=persistent)]
