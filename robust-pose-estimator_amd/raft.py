@@ -63,6 +63,14 @@ LOOKUP_EVENT_SINK = None
 # entry points with the same arguments); keyed on shapes, stream and the weights' versions.  Larger passes (batch mode) keep the
 # call-by-call route: their host time is hidden behind 60 ms of kernels and their intermediates would pin gigabytes.
 FRAME_OPLISTS = True
+# The correlation lookup fused into convc1 (rpe_corr_lookup_conv1x1: the 324-channel lookup result never leaves LDS; bit-identical to the
+# two kernels) in the update loop's launch list, for passes of at most this many workgroups (64 queries each): ONE round of workgroups on
+# the chip.  Measured at 640x512 (tools/bench_lookup_conv.py; fused vs lookup + convc1 back to back): 1 pair 33 vs 33 us, 2 pairs (a tracker
+# frame: 160 workgroups) 35 vs 45, 4 pairs 67 vs 66, 8 pairs 103 vs 106, 16 pairs 171 vs 169, 32 pairs 331 vs 313 -- a workgroup takes
+# 33 us wherever it runs (20 us of matrix instructions behind a lookup phase that nothing overlaps: its 150 KB of LDS give it the CU to
+# itself), so the fusion pays exactly where the two kernels leave most of the chip idle.
+LOOKUP_FUSED = True
+LOOKUP_FUSED_MAX_WGS = 256
 FRAME_OPLISTS_MAX_IMAGES = 4                                      # images per encoder pass / flow pairs per RAFT pass up to which passes are recorded
 ENC_STREAMS = True                                                 # RAFT.encode_both: the context encoder on the side stream beside the feature encoder
 ENC_STREAMS_MIN = 8                                                # ... for at least this many context images (below: the fork / join costs more than it hides)
@@ -770,7 +778,7 @@ class RAFT(nn.Module):
         ub = self.update_block
         hx, rhx, z_buf, cat_buf, corr, coords1, flow = (ws[k] for k in ('hx', 'rhx', 'z', 'cat', 'corr', 'coords1', 'flow'))
         P = ub.packed_convs(hx.shape[-1])
-        key = (id(P), pyr.buf.data_ptr(), iters, None if side is None else side[0].cuda_stream)
+        key = (id(P), pyr.buf.data_ptr(), iters, None if side is None else side[0].cuda_stream, LOOKUP_FUSED, LOOKUP_FUSED_MAX_WGS)
         cached = ws.get('_program')
         if cached is not None and cached[0] == key:
             return cached[1], cached[2]
@@ -778,6 +786,12 @@ class RAFT(nn.Module):
         f1, f2 = ub.encoder.flow_branch_launchers(flow, corr, cat_buf, hx, rhx, P)
         seq = ub.gru_launchers(hx, rhx, z_buf, ws['ctx'], flow, coords1, True, P)
         lk = pyr.lookup(coords1, out=corr, prepare=True)
+        n_wgs = hx.shape[0] * -(-(hx.shape[2] * -(-hx.shape[3] // 8)) // 8)
+        if LOOKUP_FUSED and not CONV_BF16X3 and n_wgs <= LOOKUP_FUSED_MAX_WGS and ops.PackedLookupConv.supported(pyr.levels, pyr.radius, pyr.w8):
+            cor = P['cor_buf'](corr)
+            if 'convc1_lookup' not in P:
+                P['convc1_lookup'] = ops.PackedLookupConv(ub.encoder.convc1.weight, ub.encoder.convc1.bias)
+            lk, c1 = pyr.lookup_conv1x1(coords1, P['convc1_lookup'], cor, relu=True, prepare=True), None      # one launch for lookup -> convc1 -> ReLU
         prog = ops.OpList(n_cells=2 + 2 * iters)
         if side is not None:
             for cell, ev in ((0, side[1]), (1, side[2])):
@@ -788,7 +802,10 @@ class RAFT(nn.Module):
             marks.append(prog.mark())
             if side is not None:                                  # the flow branch needs only the flow: beside lookup -> convc1 -> convc2
                 prog.record(0, 0).wait(0, 1).add(f1, 1).add(f2, 1).record(1, 1)
-            prog.record(2 + 2 * itr, 0).add(lk).record(3 + 2 * itr, 0).add(c1).add(c2)
+            prog.record(2 + 2 * itr, 0).add(lk).record(3 + 2 * itr, 0)
+            if c1 is not None:
+                prog.add(c1)
+            prog.add(c2)
             if side is not None:
                 prog.wait(1, 0)
             else:

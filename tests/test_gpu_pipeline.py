@@ -455,6 +455,33 @@ def test_tracker_poses_do_not_depend_on_the_launch_route(models, monkeypatch):
     assert torch.equal(walk(), ref) and torch.equal(walk(), ref)
 
 
+def test_loop_with_the_lookup_fused_into_convc1_equals_the_two_kernels(models, monkeypatch):
+    """raft.LOOKUP_FUSED: the launch list's (lookup, convc1) pair as ONE rpe_corr_lookup_conv1x1 op -- flows, hidden state and every
+    intermediate prediction must be bit-identical to the two-kernel list (the fused kernel adds the products in rpe_conv1x1's order)."""
+    model, om, synth = models
+    from rpe_amd import raft
+    fr = synth.stereo_frames(41, 2, H, W)
+    i1, i2 = fr['image1l'].cuda(), fr['image2l'].cuda()
+    monkeypatch.setattr(raft, 'LOOKUP_FUSED', False)
+    ref, ref_h, _ = model.flow(i1, i2, all_flows=True)
+    monkeypatch.setattr(raft, 'LOOKUP_FUSED', True)
+    ran = []
+    real = ops_lookup_conv = None
+    from rpe_amd import ops
+    real = ops.CorrPyramid.lookup_conv1x1
+
+    def spy(self, *a, **k):
+        ran.append(1)
+        return real(self, *a, **k)
+    monkeypatch.setattr(ops.CorrPyramid, 'lookup_conv1x1', spy)
+    got, got_h, _ = model.flow(i1, i2, all_flows=True)
+    assert ran and len(got) == 12 and all(torch.equal(a, b) for a, b in zip(got, ref)) and torch.equal(got_h, ref_h)
+    monkeypatch.setattr(raft, 'LOOKUP_FUSED_MAX_WGS', 0)              # (threshold: large passes keep the two kernels)
+    ran.clear()
+    got, _, _ = model.flow(i1, i2)
+    assert not ran and torch.equal(got[-1], ref[-1])
+
+
 def test_launch_list_times_its_lookups_when_asked(models, monkeypatch):
     """raft.LOOKUP_EVENT_SINK (bench.py's roofline of the lookup inside the timed region): the launch list records the caller's raw HIP
     events around every iteration's lookup; without a sink the cells are empty and the same list runs untimed.  Results are unchanged."""

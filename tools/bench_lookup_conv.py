@@ -13,7 +13,7 @@ def med(fn, n=50):
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
     return statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
-for b in (32, 2):
+for b in (32, 16, 8, 4, 2, 1):
     g = torch.Generator(device='cpu').manual_seed(1)
     f1, f2 = torch.randn(b, 256, h8, w8, generator=g).to(dev), torch.randn(b, 256, h8, w8, generator=g).to(dev)
     pyr = ops.CorrPyramid(b, h8, w8, device=dev).build(f1, f2)

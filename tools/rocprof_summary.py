@@ -16,12 +16,18 @@ def from_db(path, last_step):
             "where s.kernel_name like '%k_permute_fmap%' order by d.start")]
         if starts:
             where, args = 'where d.start>=?', (starts[-1],)
-    if last_step == 'full':   # everything between the last two k_pose_finalize launches = one whole bench step
+    if last_step == 'full':   # everything between the last two solves = one whole bench step (round 6: a solve no longer ends with
+        #                           k_pose_finalize -- the window runs from the last-but-one k_pose_init to the last one)
         ends = [r[0] for r in c.execute(
             "select d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id "
             "where s.kernel_name like '%k_pose_finalize%' order by d.start")]
+        inits = [r[0] for r in c.execute(
+            "select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id "
+            "where s.kernel_name like '%k_pose_init%' order by d.start")]
         if len(ends) >= 2:
             where, args = 'where d.start>=? and d.end<=?', (ends[-2], ends[-1])
+        elif len(inits) >= 2:
+            where, args = 'where d.start>=? and d.start<?', (inits[-2], inits[-1])
     tot = c.execute(f"select sum(d.end-d.start) from rocpd_kernel_dispatch d {where}", args).fetchone()[0]
     rows = c.execute(
         "select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
