@@ -825,9 +825,12 @@ __device__ __forceinline__ LkRound plan_round(bool pending, int ylo, int sx, int
 // The lookup of ONE wave: 8 consecutive groups (64 queries, first group wave_g0) of one (batch item bz, level l), staged through the
 // wave's own LDS stage.  The 81 values of a lane's query go to outb + obase + (i * 9 + j) * nq4 (bytes): channel planes of the (b, 324,
 // h8, w8) output for k_corr_lookup, or rows of a workgroup's LDS tile for the fused lookup + convc1 kernel (a generic pointer serves both).
-template <bool DEEP>
+struct NoGate { __device__ __forceinline__ void operator()() const {} };
+// ``gate`` is called once, after the first round's loads have been issued and before anything is stored to ``outb`` (the pipelined fused
+// kernel waits there until the matrix waves are done with the tile rows this level overwrites).
+template <bool DEEP, typename Gate = NoGate>
 __device__ __forceinline__ void lookup_wave(const float* __restrict__ pyr, const float* __restrict__ coords, char* outb, unsigned nq4, int tile_q,
-                                            float* wstage, const PyrGeom& G, int wave_g0, int l, int bz) {
+                                            float* wstage, const PyrGeom& G, int wave_g0, int l, int bz, Gate gate = Gate()) {
     const int nq = G.h8 * G.w8;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, k = lane & 7;
@@ -902,10 +905,12 @@ __device__ __forceinline__ void lookup_wave(const float* __restrict__ pyr, const
             f32x4 v[LK_NPASS][LK_NI];
             issue_all<0>(C, v);
             __builtin_amdgcn_sched_barrier(0);
+            if (first) gate();
             stage_and_consume<0>(C, X, Y, hm2, hm1, v);
         } else {
             f32x4 v0[LK_NI];
             issue_loads<0>(C, v0);
+            if (first) gate();
             lookup_pass<0>(C, X, Y, hm2, hm1, v0);
         }
         pending = pending && !fits;
@@ -1026,6 +1031,127 @@ __global__ __launch_bounds__(256, 1) void k_lookup_conv1x1(FzP P, PyrGeom G) {
                     if (OUT2) ob2[(size_t)co * nq + q] = v;
                 }
             }
+    }
+}
+
+// The same for passes of MORE than one round of workgroups: a PERSISTENT workgroup of 8 waves walks its tiles (64 queries each) with the two
+// phases pipelined through the ONE tile the LDS has room for.  Waves 0-3 (matrix waves, one per SIMD) contract tile n; waves 4-7 (lookup
+// waves, wave = level) look tile n + 1 up meanwhile: their loads go out at once, and a level's rows of the tile are overwritten as soon as
+// the matrix waves have passed the last 16-channel step that reads them (level l occupies rows 81 l .. 81 l + 80: free after steps 5, 10, 15,
+// 20).  The matrix waves in turn wait for a level only at the step that first reads it (steps 0, 5, 10, 15) -- by then the lookup of that
+// level has long finished, so the matrix pipe runs tile after tile and the lookup costs no time of its own.  Progress words in LDS (a
+// step counter per matrix wave, a tile counter per level), polled; no workgroup barrier after the prologue.  Same products in the same
+// order as k_lookup_conv1x1: bit-identical.
+struct TileGate {
+    volatile int* prog; int need;                                   // the four matrix waves' step counters; steps that must be complete
+    __device__ __forceinline__ void operator()() const {
+        if (need <= 0) return;
+        for (int spin = 0; spin < (1 << 24); ++spin) {
+            const int a = prog[0], b = prog[1], c = prog[2], d = prog[3];
+            if (a >= need && b >= need && c >= need && d >= need) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+__device__ __forceinline__ void wait_level(volatile int* done, int need) {
+    for (int spin = 0; spin < (1 << 24); ++spin) {
+        if (*done >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool OUT2>
+__global__ __launch_bounds__(512, 1) void k_lookup_conv1x1_pipe(FzP P, PyrGeom G, int tiles_per_item, int total_tiles) {
+    __shared__ __attribute__((aligned(16))) float tile[FZ_TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float stage[4 * LK_WAVE_FLOATS];
+    __shared__ float bias_s[FZ_COUT];
+    __shared__ volatile int prog[4], done[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = G.h8 * G.w8;
+    for (int i = tid; i < (FZ_STEPS * 16 - FZ_CIN) * 64; i += 512) tile[FZ_CIN * 64 + i] = 0.0f;
+    if (tid < FZ_COUT) bias_s[tid] = P.bias ? P.bias[tid] : 0.0f;
+    if (tid < 4) { prog[tid] = 0; done[tid] = 0; }
+    __syncthreads();
+    const int ntiles = total_tiles > (int)blockIdx.x ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles blockIdx.x, + gridDim.x, ...
+
+    if (wv >= 4) {
+        // ---------------- lookup wave: level l of every tile of this workgroup
+        const int l = wv - 4;
+        for (int k = 0; k < ntiles; ++k) {
+            const int t = blockIdx.x + k * gridDim.x;
+            const int bz = t / tiles_per_item, wave_g0 = (t % tiles_per_item) * 8;
+            // rows 81 l .. 81 l + 80 are last read by step (81 l + 80) / 16 of the previous tile
+            const TileGate gate{prog, k == 0 ? 0 : (k - 1) * FZ_STEPS + (81 * l + 80) / 16 + 1};
+            lookup_wave<false>(P.pyr, P.coords, (char*)tile, 64u * 4u, lane, stage + l * LK_WAVE_FLOATS, G, wave_g0, l, bz, gate);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // (the wave's LDS stores are complete and ordered before the flag)
+            if (lane == 0) done[l] = k + 1;
+        }
+        return;
+    }
+    // -------------------- matrix wave: output channels 64 wv .. 64 wv + 63 of every tile
+    const f32x4* wsrc = (const f32x4*)P.wp + ((size_t)wv * FZ_STEPS * 64 + lane) * 4;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* b_l = tile + (8 * lh) * 64 + l31;
+    for (int k = 0; k < ntiles; ++k) {
+        const int t = blockIdx.x + k * gridDim.x;
+        const int bz = t / tiles_per_item, wave_g0 = (t % tiles_per_item) * 8;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        f32x4 a_cur[4], a_nxt[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a_cur[c] = wsrc[c];
+#pragma unroll 1
+        for (int s = 0; s < FZ_STEPS; ++s) {
+            // step s reads rows 16 s .. 16 s + 15: it is the first to read level (16 s + 15) / 81 when that differs from the step before
+            const int lv = (16 * s + 15) / 81;
+            if (s == 0 || lv != (16 * s - 1) / 81) wait_level(&done[lv < 4 ? lv : 3], k + 1);
+            if (s + 1 < FZ_STEPS) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a_nxt[c] = wsrc[(size_t)(s + 1) * 256 + c];
+            }
+            const float* b = b_l + s * (16 * 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a0 = a_cur[j >> 1][(j & 1) * 2], a1 = a_cur[j >> 1][(j & 1) * 2 + 1];
+                const float b0 = b[j * 64], b1 = b[j * 64 + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a_cur[c] = a_nxt[c];
+            // this step's fragment reads have returned (the matrix instructions consumed them): its rows may be overwritten
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) prog[wv] = k * FZ_STEPS + s + 1;
+        }
+        float* ob = P.out + (size_t)bz * P.obs;
+        float* ob2 = OUT2 ? P.out2 + (size_t)bz * P.o2bs : nullptr;
+        const int co_w = wv * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = wave_g0 * GQ + j * 32 + l31;
+            const bool qok = q < nq;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_w + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[i][j][r] + bias_s[co];
+                    if (P.relu) v = v < 0.0f ? 0.0f : v;
+                    if (qok) {
+                        ob[(size_t)co * nq + q] = v;
+                        if (OUT2) ob2[(size_t)co * nq + q] = v;
+                    }
+                }
+        }
     }
 }
 
@@ -1196,7 +1322,17 @@ extern "C" int rpe_corr_lookup_conv1x1(const void* pyramid, const float* coords,
     // four levels (324 channels), rows of whole groups (the workgroup's 64 queries are 64 consecutive pixels), at most 65535 batch items
     if (levels != MAX_LEVELS || (w8 % GQ) != 0 || b > 65535) return RPE_E_UNSUPPORTED;
     FzP P{(const float*)pyramid, coords, packed, bias, out, out_batch_stride, out2, out2_batch_stride, relu};
-    const dim3 grid(ceil_div(G.ngroups, 8), b);
+    const int tiles_per_item = ceil_div(G.ngroups, 8);
+    const long long total = (long long)tiles_per_item * b;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (total > cus && total < (1ll << 31)) {
+        // more than one round of workgroups: one persistent 8-wave workgroup per CU, lookup of tile n + 1 under the matrix phase of tile n
+        if (out2) hipLaunchKernelGGL(k_lookup_conv1x1_pipe<true>, dim3(cus), dim3(512), 0, (hipStream_t)stream, P, G, tiles_per_item, (int)total);
+        else hipLaunchKernelGGL(k_lookup_conv1x1_pipe<false>, dim3(cus), dim3(512), 0, (hipStream_t)stream, P, G, tiles_per_item, (int)total);
+        return rpe_check_launch();
+    }
+    const dim3 grid(tiles_per_item, b);
     if (out2) hipLaunchKernelGGL(k_lookup_conv1x1<true>, grid, dim3(256), 0, (hipStream_t)stream, P, G);
     else hipLaunchKernelGGL(k_lookup_conv1x1<false>, grid, dim3(256), 0, (hipStream_t)stream, P, G);
     return rpe_check_launch();

@@ -409,13 +409,16 @@ def test_build_launch_classes_agree_bitwise(rpe):
     assert torch.equal(big.lookup(cb)[5:7], small.lookup(coords))
 
 
-@pytest.mark.parametrize('b,h8,w8,spread', [(2, 64, 80, 0.7), (1, 44, 48, 3.0), (3, 20, 24, 12.0), (2, 17, 16, 1.5)])
+@pytest.mark.parametrize('b,h8,w8,spread', [(2, 64, 80, 0.7), (1, 44, 48, 3.0), (3, 20, 24, 12.0), (2, 17, 16, 1.5), (7, 64, 80, 1.0), (9, 44, 48, 6.0),
+                                            (40, 20, 24, 12.0)])
 def test_lookup_fused_into_convc1_is_bit_identical_to_the_two_kernels(rpe, b, h8, w8, spread):
     """rpe_corr_lookup_conv1x1 (the 324-channel lookup result stays in LDS and is contracted there) against rpe_corr_lookup followed by
     convc1 on both of its routes (rpe_conv1x1's GEMM and rpe_conv_fused's implicit GEMM, which are bit-identical to each other): torch.equal,
     with smooth and rough flow (several staging rounds per group at spread 12), windows partly and wholly outside the maps, non-finite
     coordinates, with and without ReLU, into channel slices, with the second destination, through the prepared launcher; a group count that
-    is not a multiple of the workgroup's eight (17 x 16)."""
+    is not a multiple of the workgroup's eight (17 x 16).  The last three cases have more 64-query tiles than the chip has CUs (560, 297,
+    320): they run the PERSISTENT pipelined kernel (lookup waves one tile ahead of the matrix waves through one LDS tile), with two or three
+    tiles per workgroup and rough flow (several staging rounds inside a gated lookup)."""
     from rpe_amd import ops
     f1, f2 = fmaps(7 * b + h8, b, h8, w8)
     pyr = ops.CorrPyramid(b, h8, w8, device='cuda').build(f1.cuda(), f2.cuda())

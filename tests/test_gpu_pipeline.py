@@ -475,7 +475,8 @@ def test_loop_with_the_lookup_fused_into_convc1_equals_the_two_kernels(models, m
         return real(self, *a, **k)
     monkeypatch.setattr(ops.CorrPyramid, 'lookup_conv1x1', spy)
     got, got_h, _ = model.flow(i1, i2, all_flows=True)
-    assert ran and len(got) == 12 and all(torch.equal(a, b) for a, b in zip(got, ref)) and torch.equal(got_h, ref_h)
+    assert bool(ran) == (not raft.CONV_BF16X3)                       # (the labelled variant keeps its own 1x1 GEMM: no fusion under the switch)
+    assert len(got) == 12 and all(torch.equal(a, b) for a, b in zip(got, ref)) and torch.equal(got_h, ref_h)
     monkeypatch.setattr(raft, 'LOOKUP_FUSED_MAX_WGS', 0)              # (threshold: large passes keep the two kernels)
     ran.clear()
     got, _, _ = model.flow(i1, i2)
