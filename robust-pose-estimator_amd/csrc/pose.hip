@@ -211,6 +211,10 @@ __device__ __forceinline__ double lds_uniform(const double* p) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// Waiting never deadlocks: a workgroup only ever waits for workgroups of ITS OWN ROW, a row's workgroups are contiguous in dispatch order,
+// and a row whose workgroups are all resident runs to its end and leaves -- so whatever else shares the device (another solve on another
+// stream), some row is always complete and progressing, and the slots it frees go to the rows that are not.  (The host still only asks
+// for one launch when the whole grid fits: the partition is sized so that nothing waits for a slot.)
 // TAIL: the launch belongs to a solve: the row's last workgroup runs the update, and the launch runs Z.evals evaluations -- between
 // evaluations a row's workgroups wait for the row's tail (an epoch word per row), so there is no launch boundary, no dispatch of 768
 // workgroups and no drained chip between them.  Z.evals > 1 needs every workgroup of the grid resident at once (the host checks; else it
@@ -711,8 +715,15 @@ static int persistent_capacity(bool hess, bool vec) {
     const void* fn = hess ? (vec ? (const void*)k_pose_reduce<true, 4, true> : (const void*)k_pose_reduce<true, 1, true>)
                           : (vec ? (const void*)k_pose_reduce<false, 4, true> : (const void*)k_pose_reduce<false, 1, true>);
     int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    // a fact about (device, kernel): asked once (the occupancy query costs tens of microseconds of host time, a solve is enqueued in ~10);
+    // a benign race between host threads writes the same value twice
+    static int known[16][2][2];
+    const bool cacheable = dev >= 0 && dev < 16;
+    if (cacheable && known[dev][hess][vec] > 0) return known[dev][hess][vec];
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RED_THREADS, 0) != hipSuccess) return 0;
+    if (cacheable) known[dev][hess][vec] = cus * per_cu;
     return cus * per_cu;
 }
 

@@ -382,7 +382,8 @@ class BasicEncoder(nn.Module):
         Small inference passes (FRAME_OPLISTS) are recorded once per (shapes, stream, weights) and replayed as one launch list."""
         images = list(x) if isinstance(x, (list, tuple)) else [x]
         first = images[0]
-        if FRAME_OPLISTS and raw255 and first.is_cuda and not torch.is_grad_enabled() and sum(im.shape[0] for im in images) <= FRAME_OPLISTS_MAX_IMAGES \
+        if FRAME_OPLISTS and raw255 and first.is_cuda and first.device.index == torch.cuda.current_device() and not torch.is_grad_enabled() \
+                and sum(im.shape[0] for im in images) <= FRAME_OPLISTS_MAX_IMAGES \
                 and all(im.is_contiguous() and im.dtype == torch.float32 and im.device == first.device for im in images) and not _overlap(images):
             if getattr(self, '_recorded', None) is None:
                 self._recorded = _Recorded()
@@ -900,8 +901,9 @@ class RAFT(nn.Module):
         dev = fmap1.device
         c = self.hidden_dim
         ts = (fmap1, fmap2, cnet)
-        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) or _overlap(ts) or tuple(cnet.shape) != (N, 2 * c, h8, w8):
-            return None
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev for t in ts) or _overlap(ts) \
+                or tuple(cnet.shape) != (N, 2 * c, h8, w8) or dev.index != torch.cuda.current_device():
+            return None                                               # (the call-by-call route raises what needs raising)
         if getattr(self, '_recorded', None) is None:
             self._recorded = _Recorded()
         if '_key_tensors' not in self.__dict__:
