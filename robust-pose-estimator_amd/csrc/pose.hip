@@ -424,8 +424,11 @@ __device__ __forceinline__ double ld_partial(const double* p) {
     if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
 }
-template <bool COHERENT>
-__device__ __forceinline__ void sum_partials(const double* partials, int row, int nblk, int tid, double* vals, double (*red)[NPART]) {
+struct Nothing { __device__ __forceinline__ void operator()() const {} };
+// ``between`` runs once, after the first eight loads have been requested and before any of them is used (the tail stores the row state it
+// requested earlier into LDS there: all of the tail's loads are then one round trip).
+template <bool COHERENT, typename F = Nothing>
+__device__ __forceinline__ void sum_partials(const double* partials, int row, int nblk, int tid, double* vals, double (*red)[NPART], F between = F()) {
     const int j = tid & 31, part = tid >> 5;
     const double* p = partials + (size_t)row * nblk * NPART + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -433,10 +436,11 @@ __device__ __forceinline__ void sum_partials(const double* partials, int row, in
     // loads of up to eight blocks (two rounds, or a round and the rest) are issued together: a device-scope load is a ~1.2 us round trip
     // to the memory side, and three dependent trips were most of the tail's 5 us "loads + sum"
     int b = part;
-    while (b < nblk) {
+    do {                                                            // (at least once: ``between`` must run in every thread)
         double v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = b + 8 * i < nblk ? ld_partial<COHERENT>(p + (size_t)(b + 8 * i) * NPART) : 0.0;
+        if (b == part) { __builtin_amdgcn_sched_barrier(0); between(); }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int bb = b + 32 * r;
@@ -447,7 +451,7 @@ __device__ __forceinline__ void sum_partials(const double* partials, int row, in
             }
         }
         b += 64;
-    }
+    } while (b < nblk);
     red[part][j] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (tid < NPART) {
@@ -496,7 +500,9 @@ __device__ __forceinline__ void std_(double* p, double v) {
 // returns (to every thread) whether the row has stopped
 template <bool COH>
 __device__ bool reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states, const double* partials, int row, int nblk, const TailArgs& Z, double* line) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));       // the tail's addresses are computed HERE: hoisted in front of the evaluation loop they are spilled, and every
+    //                                       reload of one is a wait for all outstanding loads (the tail's loads then go out one round trip at a time)
     PROBE(1);
     RowState& G = states[row];
     constexpr int HEAD = 31;                                  // doubles in front of old_dirs (T, g, prev_g, d, t, loss, prev_loss, H_diag, 4 ints)
@@ -506,17 +512,31 @@ __device__ bool reduce_tail(const PoseArgs& A, RowUniform* uni, RowState* states
     __shared__ RowUniform U;
     __shared__ double h_al[HIST], Lc[6][6];
     __shared__ int wb[2];                                     // history entries [wb[0], wb[1]) changed
-    // the state's loads go out first, the partial rows' right behind them: one round trip for both
-    if (lane < HEAD) ((double*)&S)[lane] = ldd<COH>((const double*)&G + lane);
-    if (lane < (int)(sizeof(RowUniform) / sizeof(double))) ((double*)&U)[lane] = ldd<COH>((const double*)&uni[row] + lane);
-    if (Z.mode != RPE_SOLVER_GN) {
-        // the history is fetched without waiting for its length (a dependent round trip): it never holds more pairs than iterations
-        const int nold = Z.max_iter < Z.opt.history ? Z.max_iter : Z.opt.history;
-        for (int e = lane; e < nold * 6; e += UPD_THREADS) { (&S.old_dirs[0][0])[e] = ldd<COH>(&G.old_dirs[0][0] + e); (&S.old_stps[0][0])[e] = ldd<COH>(&G.old_stps[0][0] + e); }
-        for (int e = lane; e < nold; e += UPD_THREADS) S.ro[e] = ldd<COH>(&G.ro[e]);
+    // Every load of the tail is requested before the first one is used: state head, row constants, the (y, s, rho) history and -- inside
+    // sum_partials -- the first eight partial rows share ONE round trip to the memory side (device-scope loads are not answered by a cache:
+    // ~1.2 us each; written as load -> LDS store pairs the compiler waited for each before requesting the next: six round trips)
+    constexpr int NU = (int)(sizeof(RowUniform) / sizeof(double));
+    // (unconditional loads at clamped indices: a load under a lane condition is its own basic block, and the compiler waits for every
+    // outstanding load at each of those)
+    const double v_head = ldd<COH>((const double*)&G + (lane < HEAD ? lane : HEAD - 1));
+    const double v_uni = ldd<COH>((const double*)&uni[row] + (lane < NU ? lane : NU - 1));
+    // the history is fetched without waiting for its length (a dependent round trip): it never holds more pairs than iterations
+    const int nold = Z.mode != RPE_SOLVER_GN ? (Z.max_iter < Z.opt.history ? Z.max_iter : Z.opt.history) : 0;
+    // (one element of each array per thread covers 42 pairs = every solve of up to 42 iterations; longer histories take the plain loop below)
+    const int e0 = lane < HIST * 6 ? lane : HIST * 6 - 1;
+    const double v_dir = ldd<COH>(&G.old_dirs[0][0] + e0), v_stp = ldd<COH>(&G.old_stps[0][0] + e0);
+    const double v_ro = ldd<COH>(&G.ro[lane < HIST ? lane : HIST - 1]);
+    sum_partials<true>(partials, row, nblk, lane, vals, red, [&]() {      // (ends with a barrier)
+        if (lane < HEAD) ((double*)&S)[lane] = v_head;
+        if (lane < NU) ((double*)&U)[lane] = v_uni;
+        if (lane < nold * 6) { (&S.old_dirs[0][0])[lane] = v_dir; (&S.old_stps[0][0])[lane] = v_stp; }
+        if (lane < nold) S.ro[lane] = v_ro;
+        if (lane == 0) { wb[0] = 0; wb[1] = 0; }
+    });
+    if (nold * 6 > UPD_THREADS) {                                    // (histories of more than 42 pairs: the rest, after the fact)
+        for (int e = lane + UPD_THREADS; e < nold * 6; e += UPD_THREADS) { (&S.old_dirs[0][0])[e] = ldd<COH>(&G.old_dirs[0][0] + e); (&S.old_stps[0][0])[e] = ldd<COH>(&G.old_stps[0][0] + e); }
+        __syncthreads();
     }
-    if (lane == 0) { wb[0] = 0; wb[1] = 0; }
-    sum_partials<true>(partials, row, nblk, lane, vals, red);             // (ends with a barrier)
     PROBE(2);
     if (lane == 0) pose_update_row(S, U, h_al, Lc, wb, vals, A.lw, row, A.h, A.w, Z.mode, Z.max_iter, Z.opt);
     PROBE(3);
