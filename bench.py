@@ -650,7 +650,9 @@ def live_lookup_traffic(args):
                                 '(3 passes x raft_iters launches) -- not only the launches whose coordinates roofline.coordinates describes'}
     if 'k_pose_reduce' in vals['FETCH_SIZE']:
         out['calibration_pose_reduce_read_bytes'] = 2.0 * 1024.0 * vals['FETCH_SIZE']['k_pose_reduce'][0]
-        out['calibration_pose_reduce_algorithmic_bytes'] = args.batch * args.height * args.width * 42
+        # (round 6: ONE k_pose_reduce launch runs all evaluations of a solve; L-BFGS with N iterations = N evaluations)
+        out['calibration_pose_reduce_algorithmic_bytes'] = args.batch * args.height * args.width * 42 * max(1, args.solver_iters)
+        out['calibration_note'] = 'k_pose_reduce: one launch = the whole solve (solver_iters evaluations of 42 B / pixel)'
     return out
 
 
