@@ -874,8 +874,8 @@ def tracker_split(model, seq, slam, frames, W, H, dev):
                 est(l, r, m.clone())
             torch.cuda.synchronize()
             res['tracker_launches_per_frame'] = {'entry_point_calls_from_python': counter.calls, 'ops_enqueued_by_launch_lists': counter.list_ops,
-                                                 'note': 'an entry point is one kernel launch except rpe_pose_solve_ex (2 per evaluation), rpe_unet_heads (15) and '
-                                                         'rpe_corr_build_ex; kernel counts per frame: profiles/r06_tracker_kernel_stats_last_frame.txt'}
+                                                 'note': 'an entry point is one kernel launch except rpe_pose_solve_ex (2: k_pose_init + one persistent k_pose_reduce), rpe_unet_heads (15) and '
+                                                         'rpe_corr_build_ex (2); kernel counts per frame: profiles/r06_tracker_kernel_stats_last_frame.txt'}
     finally:
         model.pose_head.problem.lbgfs_iters = keep
         raft_mod.LOOP_OPLIST, raft_mod.FRAME_OPLISTS = keep_list, keep_frame
