@@ -282,10 +282,14 @@ __global__ __launch_bounds__(RED_THREADS, HESS ? 2 : 3) void k_pose_reduce(PoseA
             // arrives WITH the epoch, not a round trip later.
             if (threadIdx.x < 64) {
                 double v = 0.0;
-                for (;;) {
+                // (bounded: ~4 M polls = seconds.  It never gets there -- see "Waiting never deadlocks" above --, but a kernel that can spin
+                // for ever takes the whole device with it if an assumption about the dispatcher ever fails; past the bound the workgroup goes on
+                // with what it has read, and the solve ends with a wrong pose instead of not at all)
+                for (int spin = 0; spin < (1 << 22); ++spin) {
                     if (threadIdx.x < 16) v = __hip_atomic_load(line + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const int ea = __builtin_amdgcn_readlane(__double2loint(v), 0), eb = __builtin_amdgcn_readlane(__double2loint(v), 8);
-                    if ((ea & ~EPOCH_STOPPED) >= it && (eb & ~EPOCH_STOPPED) >= it) { if (threadIdx.x == 0) epoch_seen = ea; break; }
+                    if (threadIdx.x == 0) epoch_seen = ea;
+                    if ((ea & ~EPOCH_STOPPED) >= it && (eb & ~EPOCH_STOPPED) >= it) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
                 // lanes 1..7: R[0..6], lanes 9..13: R[7], R[8], t[0..2]
