@@ -466,6 +466,10 @@ __device__ __forceinline__ void sum_partials(const double* partials, int row, in
     __syncthreads();
 }
 
+// EDITING THE TAIL: it is inlined into k_pose_reduce, whose pixel loop sits at 168 of the 170 registers three workgroups per CU allow -- the
+// register allocation of the LOOP moves with the tail's code.  Measured: the GN branch's 27 divisions written as six reciprocals (a tail-only
+// change) took the L-BFGS solve from 392 to 462 us; `noinline` on the tail does not compile ("illegal VGPR to SGPR copy").  After any edit
+// below: tools/bench_pose_solve.py, both solver modes.
 // One lane runs the iteration logic; every access it makes to the row's state used to be a dependent L2 round trip (28 us per
 // launch at batch 1).  The workgroup stages the state's head (poses, gradients, counters: 31 doubles), the (y, s, rho) history
 // and the row's rotation in LDS, lane 0 works there, and the workgroup writes back what changed.
