@@ -246,9 +246,20 @@ def conv_norm_act(conv, norm, x, relu, residual=None):
     raise NotImplementedError(type(norm))
 
 
-def _tensor_key(tensors):
-    """Versions and addresses of a fixed list of parameter / buffer tensors (in-place updates bump the version, .to() / .float() move the data)."""
-    return tuple(t._version for t in tensors) + tuple(t.data_ptr() for t in tensors)
+def _key_sources(module):
+    """(dict, name) of every parameter / buffer slot below ``module``: the slots are read afresh for every key (a Parameter object that is
+    REPLACED shows up, not only one that is updated in place), the walk over the module tree is done once."""
+    src = []
+    for m in module.modules():
+        src += [(m._parameters, n) for n in m._parameters] + [(m._buffers, n) for n in m._buffers]
+    return src
+
+
+def _tensor_key(sources):
+    """Versions and addresses of the tensors in the slots of _key_sources (in-place updates bump the version, .to() / .float() move the
+    data, an assignment puts another tensor into the slot)."""
+    ts = [d[n] for d, n in sources]
+    return tuple((t._version, t.data_ptr()) for t in ts if t is not None)
 
 
 def _overlap(tensors):
@@ -388,8 +399,8 @@ class BasicEncoder(nn.Module):
             if getattr(self, '_recorded', None) is None:
                 self._recorded = _Recorded()
             if '_key_tensors' not in self.__dict__:
-                self.__dict__['_key_tensors'] = [t for t in list(self.parameters()) + list(self.buffers()) if t is not None]
-            key = (tuple(tuple(im.shape) for im in images), first.device.index, ops.raw_stream(), split_act, WINOGRAD, CONV_BF16X3,
+                self.__dict__['_key_tensors'] = _key_sources(self)
+            key = (tuple(tuple(im.shape) for im in images), first.device.index, ops.raw_stream(), split_act, WINOGRAD, CONV_BF16X3, self.training,
                    _tensor_key(self.__dict__['_key_tensors']))
             rec = self._recorded.get(key)
             if rec is not None:
@@ -907,7 +918,7 @@ class RAFT(nn.Module):
         if getattr(self, '_recorded', None) is None:
             self._recorded = _Recorded()
         if '_key_tensors' not in self.__dict__:
-            self.__dict__['_key_tensors'] = [t for t in self.update_block.parameters()]
+            self.__dict__['_key_tensors'] = _key_sources(self.update_block)
         pyr = self._pyramid(N, h8, w8, dev)
         ws = self._workspace(N, h8, w8, dev)
         key = (N, h8, w8, dev.index, ops.raw_stream(), iters, upsample, self.mixed_precision, WINOGRAD, CORR_BF16X3, CONV_BF16X3, X3_GRU, SIDE_STREAM,

@@ -430,6 +430,45 @@ def test_recorded_passes_equal_call_by_call(models, monkeypatch):
     assert not any(torch.equal(ref[0][2], r[2]) for r in ref[1:4])                                             # the inputs really differ
 
 
+def test_recorded_passes_follow_the_weights(rpe, monkeypatch):
+    """A recorded pass holds pointers to packed weights: an in-place update (optimizer step, load_state_dict), a REPLACED Parameter object
+    and a dtype / device round trip must all lead to a new recording, never to a replay on stale weights."""
+    from rpe_amd import raft, synth, pose_net
+    model = synth.init_synthetic_weights(pose_net.PoseNet(synth.model_config(128, 160)), seed=3).eval().cuda()
+    flow = model.flow
+    img = (torch.rand(1, 3, 128, 160, device='cuda') * 255).contiguous()
+    rim = (torch.rand(1, 3, 128, 160, device='cuda') * 255).contiguous()
+
+    def both():
+        monkeypatch.setattr(raft, 'FRAME_OPLISTS', True)
+        a = [flow.encode_features((img, rim)), flow.encode_context(img)]
+        a += list(flow(None, None, fmaps=(a[0][:1], a[0][1:]), cnet=a[1])[:2])
+        monkeypatch.setattr(raft, 'FRAME_OPLISTS', False)
+        b = [flow.encode_features((img, rim)), flow.encode_context(img)]
+        b += list(flow(None, None, fmaps=(b[0][:1], b[0][1:]), cnet=b[1])[:2])
+        return a, b
+    for _ in range(3):                                            # (record, then replay twice)
+        a, b = both()
+    first = [t.clone() if torch.is_tensor(t) else t[-1].clone() for t in a]
+    def in_place():                                               # what an optimizer step does (an edit through ``.data`` bumps no version counter:
+        with torch.no_grad():                                     #  no cache of this package -- or of torch -- can see that one)
+            flow.fnet.layer2[0].conv1.weight.mul_(1.25)
+            flow.fnet.layer2[0].conv1.bias.add_(0.2)
+    steps = [in_place,
+             lambda: setattr(flow.cnet.conv1, 'weight', torch.nn.Parameter(flow.cnet.conv1.weight.detach() * 0.5)),      # a new Parameter object
+             lambda: setattr(flow.update_block.encoder.convc2, 'bias', torch.nn.Parameter(flow.update_block.encoder.convc2.bias.detach() + 0.3)),
+             lambda: flow.load_state_dict({k: v * 1.01 if v.is_floating_point() and 'running' not in k else v for k, v in flow.state_dict().items()})]
+    for step in steps:
+        step()
+        for _ in range(3):
+            a, b = both()
+            for x, y in zip(a, b):
+                x, y = (x[-1], y[-1]) if isinstance(x, list) else (x, y)
+                assert torch.equal(x, y)
+        now = [t if torch.is_tensor(t) else t[-1] for t in a]
+        assert not all(torch.equal(x, y) for x, y in zip(now, first))                                       # the change did change something
+
+
 def test_tracker_poses_do_not_depend_on_the_launch_route(models, monkeypatch):
     """PoseEstimator over 7 frames: recorded passes + launch lists vs every launch dispatched from Python -- the same poses, bit for bit."""
     model, om, synth = models
