@@ -232,8 +232,11 @@ int rpe_corr_lookup(const void *pyramid, const float *coords, int b, int h8, int
  * rpe_corr_lookup followed by rpe_conv1x1 (or rpe_conv_fused) with the same weights.  packed = rpe_corr_lookup_conv1x1_pack of the
  * (256, 324, 1, 1) weight (rpe_corr_lookup_conv1x1_packed_floats floats; 0 for any other shape); bias (256) or NULL; relu != 0: ReLU;
  * out / out2 (may be NULL): channel slices given by their batch strides (floats).  levels must be 4, radius 4, w8 % 8 == 0; anything else
- * -> RPE_E_UNSUPPORTED (the caller runs the two entry points).  rpe_corr_lookup stays the stand-alone entry point (and the kernel the
- * HBM roofline of bench.py is stated on). */
+ * -> RPE_E_UNSUPPORTED (the caller runs the two entry points).  Launches of at most one 64-query tile per compute unit run one workgroup per
+ * tile (35 us against 45 for the two kernels at 2 pairs of 640x512); larger ones run persistent workgroups that look tile n + 1 up under the
+ * matrix phase of tile n (315 us against 307 at 32 pairs: the f32 matrix pipe bounds both, so the two entry points remain the route for
+ * large batches; measured in NOTES.md, round 6).  rpe_corr_lookup stays the stand-alone entry point (and the kernel the HBM roofline of
+ * bench.py is stated on). */
 size_t rpe_corr_lookup_conv1x1_packed_floats(int cout, int cin);
 int rpe_corr_lookup_conv1x1_pack(const float *weight, int cout, int cin, float *packed, void *stream);
 int rpe_corr_lookup_conv1x1(const void *pyramid, const float *coords, int b, int h8, int w8, int levels, int radius, const float *packed,
