@@ -1,7 +1,7 @@
 // Stand-alone consumer of the C ABI (no Python, no torch): build with
 //   hipcc --offload-arch=gfx950 -I include tests/abi/abi_smoke.cpp -L robust-pose-estimator_amd -lrpe_hip -o abi_smoke
-// Runs rpe_se3_exp/log round trips, a tiny pose solve with a known answer, a correlation pyramid build + lookup and one
-// fused convolution checked against host loops, prints "ABI_SMOKE_OK".
+// Runs rpe_se3_exp/log round trips, a tiny pose solve with a known answer, a correlation pyramid build + lookup, one
+// fused convolution checked against host loops and a two-stream prepared launch list (rpe_run_ops), prints "ABI_SMOKE_OK".
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -121,6 +121,42 @@ int main() {
         }
         std::printf("conv_fused max err %.3e\n", verr);
         if (!(verr < 1e-5)) return 15;
+    }
+    // --- a prepared launch list (rpe_run_ops): the same convolution twice into two buffers on two streams, forked and joined by an event
+    //     pair, then a plane copy on the first stream that reads the second stream's result; a failing op is reported by index
+    {
+        const int cin = 16, cout = 16, hh = 8, ww = 12, hw2 = hh * ww;
+        std::vector<float> x((size_t)cin * hw2), wt((size_t)cout * cin * 9), ya((size_t)cout * hw2), yc((size_t)cout * hw2);
+        for (size_t i = 0; i < x.size(); ++i) x[i] = std::cos(0.07f * i);
+        for (size_t i = 0; i < wt.size(); ++i) wt[i] = 0.05f * std::sin(0.31f * i);
+        float *d_x, *d_wt, *d_pk, *d_ya, *d_yb, *d_yc;
+        const size_t pf = rpe_conv_packed_floats(cout, cin, 3, 3);
+        CK(hipMalloc(&d_x, x.size() * 4)); CK(hipMalloc(&d_wt, wt.size() * 4)); CK(hipMalloc(&d_pk, pf * 4));
+        CK(hipMalloc(&d_ya, ya.size() * 4)); CK(hipMalloc(&d_yb, ya.size() * 4)); CK(hipMalloc(&d_yc, ya.size() * 4));
+        CK(hipMemcpy(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+        if (rpe_conv_pack(d_wt, cout, cin, 3, 3, d_pk, st) != RPE_OK) return 16;
+        rpe_conv_desc da = {};
+        da.x = d_x; da.x_batch_stride = (long long)cin * hw2; da.packed = d_pk; da.out = d_ya; da.out_batch_stride = (long long)cout * hw2;
+        da.b = 1; da.cin = cin; da.cout = cout; da.h = hh; da.w = ww; da.kh = 3; da.kw = 3; da.mode = RPE_CONV_LINEAR; da.stride = 1;
+        rpe_conv_desc db = da; db.out = d_yb;
+        rpe_copy_planes_args cp = {d_yb, (long long)cout * hw2, d_yc, (long long)cout * hw2, 1, cout, hw2};
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        hipEvent_t fork, join; CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        void* cells[3] = {fork, join, nullptr};                           // (a NULL cell: the op is skipped)
+        const rpe_op list[] = {{RPE_OP_EVENT_RECORD, 0, &cells[0]}, {RPE_OP_STREAM_WAIT, 1, &cells[0]}, {RPE_OP_CONV_FUSED, 1, &db},
+                               {RPE_OP_EVENT_RECORD, 1, &cells[1]}, {RPE_OP_CONV_FUSED, 0, &da}, {RPE_OP_EVENT_RECORD, 0, &cells[2]},
+                               {RPE_OP_STREAM_WAIT, 0, &cells[1]}, {RPE_OP_COPY_PLANES, 0, &cp}};
+        void* streams[2] = {st, st2};
+        int failed = -5;
+        if (rpe_run_ops(list, 8, streams, 2, &failed) != RPE_OK || failed != -1) { std::printf("rpe_run_ops failed at op %d\n", failed); return 17; }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ya.data(), d_ya, ya.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(yc.data(), d_yc, yc.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ya.size(); ++i) if (ya[i] != yc[i]) { std::printf("launch list: the two streams disagree at %zu\n", i); return 18; }
+        rpe_copy_planes_args bad = cp; bad.src = nullptr;
+        const rpe_op list2[] = {{RPE_OP_COPY_PLANES, 0, &cp}, {RPE_OP_COPY_PLANES, 0, &bad}};
+        if (rpe_run_ops(list2, 2, streams, 2, &failed) != RPE_E_BADARG || failed != 1) return 19;
+        CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2));
+        std::printf("launch list ok (ABI %d.%d)\n", rpe_abi_version(), rpe_abi_minor());
     }
     std::printf("ABI_SMOKE_OK\n");
     return 0;
