@@ -4,6 +4,20 @@
 // Every op goes through the PUBLIC entry point it names: same argument checks, same kernels, same results as separate calls.
 #include "rpe_common.h"
 
+// the ctypes mirrors of robust-pose-estimator_amd/_lib.py were written against these sizes (tests/test_launch_lists_host.py holds them to the same numbers)
+static_assert(sizeof(rpe_op) == 16, "rpe_op: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_conv_desc) == 200, "rpe_conv_desc: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_corr_lookup_args) == 48, "rpe_corr_lookup_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_corr_build_args) == 48, "rpe_corr_build_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_stem_conv_args) == 96, "rpe_stem_conv_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_flow_update_args) == 96, "rpe_flow_update_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_copy_planes_args) == 48, "rpe_copy_planes_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_instnorm_finalize_args) == 40, "rpe_instnorm_finalize_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_instnorm_apply_args) == 64, "rpe_instnorm_apply_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_upsample_convex_args) == 40, "rpe_upsample_convex_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_lookup_conv1x1_args) == 96, "rpe_lookup_conv1x1_args: layout changed -- update _lib.py and RPE_ABI_VERSION");
+static_assert(sizeof(rpe_solve_opts) == 32, "rpe_solve_opts: layout changed -- update _lib.py and RPE_ABI_VERSION");
+
 template <typename A>
 static inline const A* as(const rpe_op& op) { return static_cast<const A*>(op.args); }
 

@@ -126,7 +126,8 @@ class Recorder(OpList):
         self._bound[name] = (sites, tuple(t.shape), t.dtype)
         return len(sites)
 
-    def replay(self, tensors):
+    def patch(self, tensors):
+        """Rewrite every pointer bound to ``name`` for the tensors given (same shape and dtype as at recording time, contiguous)."""
         for name, t in tensors.items():
             sites, shape, dtype = self._bound[name]
             if tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous():
@@ -134,6 +135,9 @@ class Recorder(OpList):
             base = t.data_ptr()
             for st, fname, off in sites:
                 setattr(st, fname, base + off)
+
+    def replay(self, tensors):
+        self.patch(tensors)
         self.run((raw_stream(),))
 
 
